@@ -1,0 +1,345 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING the reference.
+
+Runs only in the dev container (needs /root/reference; never on the GPU box):
+
+    cd /tmp && python /root/repo/tests/golden/make_golden.py
+
+What it does:
+  * puts /root/reference/codes on sys.path with bytecode writing disabled;
+  * registers placeholder THIRD-PARTY modules that the image lacks:
+      - the private ISP_Kernels plugin (whitebalance, gamma, demosaic,
+        globaltonemapping, spatialnoisereduction).  The stand-ins hold NO
+        reference arithmetic: the four differentiable options forward to the
+        build-defined OPSPEC in oracle/isp_oracle.py (so whole graphs can run and
+        the *combination logic* is pinned), every other option raises;
+      - empty cv2 / torchvision.utils / skimage.measure / lmdb / tensorboard;
+  * maps 'cuda' -> 'cpu' in Tensor.to / Module.to / Tensor.cuda;
+  * replaces the proxies' weight ``load`` (the .pth files are not distributed)
+    with seeded weights from oracle.make_weights;
+  * defines the three names isp_universal.py forgets to import (TenLayerNet,
+    TwoLayerNet, ToyNet -> NameError at isp_universal.py:92-94) as None in
+    that module's namespace so IspUniversal can be constructed.
+Only inputs / expected outputs are stored (small .npz); no reference text.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference/codes'
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, 'oracle'))
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import isp_oracle as O
+
+torch.manual_seed(0)
+torch.set_num_threads(4)
+
+
+# ---------------------------------------------------------------- placeholders
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _WB:
+    def run(self, img, option, params):
+        x = img.permute(0, 3, 1, 2)
+        if option == 'manual':
+            y = O.wb_manual(x, params['gain'] / 5.0)
+        elif option == 'grayworld':
+            y = O.grayworld(x)
+        else:
+            raise NotImplementedError(option)
+        return y.permute(0, 2, 3, 1)
+
+
+class _GM:
+    def run(self, img, option, params):
+        assert option == 'manual'
+        return O.gamma_manual(img.permute(0, 3, 1, 2), params['gamma']).permute(0, 2, 3, 1)
+
+
+class _DM:
+    def run(self, img, option, params):
+        if option == 'nearestneighbor':
+            return O.demosaic_nearest(img)
+        raise NotImplementedError(option)
+
+
+class _NA:
+    def run(self, img, option, params):
+        raise NotImplementedError(option)
+
+
+_mod('whitebalance', WhiteBalance=_WB)
+_mod('gamma', Gamma=_GM)
+_mod('demosaic', Demosaic=_DM)
+_mod('globaltonemapping', GlobalToneMapping=_NA)
+_mod('spatialnoisereduction', SpatialNoiseReduction=_NA)
+_mod('cv2')
+_mod('lmdb')
+_mod('torchvision')
+_mod('torchvision.utils', make_grid=None)
+_mod('skimage')
+_mod('skimage.measure', compare_ssim=None)
+
+# ---------------------------------------------------------------- device shims
+_t_to, _m_to = torch.Tensor.to, nn.Module.to
+
+
+def _fix(a):
+    if isinstance(a, torch.device) and a.type == 'cuda':
+        return torch.device('cpu')
+    if isinstance(a, str) and a.startswith('cuda'):
+        return 'cpu'
+    return a
+
+
+torch.Tensor.to = lambda self, *a, **k: _t_to(self, *[_fix(v) for v in a], **{q: _fix(v) for q, v in k.items()})
+nn.Module.to = lambda self, *a, **k: _m_to(self, *[_fix(v) for v in a], **{q: _fix(v) for q, v in k.items()})
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+# ---------------------------------------------------------------- reference
+import models.modules.tools_origin as T            # noqa: E402
+import models.modules.tools_proxy as TP            # noqa: E402
+import models.modules.isp_universal as IU          # noqa: E402
+import models.modules.origin_universal as OU       # noqa: E402
+import models.modules.super_prune_fifteen_demos_four_bayer_two as SP  # noqa: E402
+from models.modules.srcnn_res_arch import SRCNNRes  # noqa: E402
+from models.modules.srcnn_demosaic_arch import SRCNNDemosaic  # noqa: E402
+from models.modules.path_14l_bayer_arch import Path14lBayer  # noqa: E402
+from models.modules.path_14l_bgr_arch import Path14lBgr  # noqa: E402
+import utils.util_path_restore as UPR              # noqa: E402
+import utils.util as UU                            # noqa: E402
+
+for _n in ('TenLayerNet', 'TwoLayerNet', 'ToyNet'):
+    setattr(IU, _n, None)
+for _c in (TP.ProxyNet, TP.ProxyDemosaicNet, TP.PathRestore14lBayer, TP.PathRestore14lBgr):
+    _c.load = lambda self, path, strict: None
+
+
+def kind_of(m):
+    if isinstance(m, SRCNNRes):
+        return 'srcnn_res', m.srcnn[0].weight.shape[1] - 12
+    if isinstance(m, SRCNNDemosaic):
+        return 'srcnn_demosaic', 0
+    if isinstance(m, Path14lBayer):
+        return 'path14l_bayer', 0
+    if isinstance(m, Path14lBgr):
+        return 'path14l_bgr', 0
+    return None, 0
+
+
+def seed_module(m, seed):
+    kind, P = kind_of(m)
+    if kind is not None:
+        m.load_state_dict(O.make_weights(kind, seed, P))
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-28s %6.1f KB' % (name, os.path.getsize(path) / 1024.))
+
+
+def rnd(*shape, seed):
+    return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).random(shape).astype(np.float32))
+
+
+# ---------------------------------------------------------------- 1. pinned element-wise ops
+def gold_pointwise():
+    x = (rnd(2, 3, 16, 16, seed=1) * 1.3 - 0.15).requires_grad_(True)  # some values outside [0,1]
+    pq = rnd(2, 30, seed=2).mul(0.2).add(0.4).requires_grad_(True)
+    y = T.WbQuadratic()(x, pq)
+    gy = rnd(2, 3, 16, 16, seed=3) - 0.5
+    gx, gp = torch.autograd.grad(y, (x, pq), gy)
+    pg = rnd(2, 3, seed=4).requires_grad_(True)
+    xg = x.detach().clone()
+    xg[0, 0, 0, :4] = torch.tensor([0.0, 0.25, 0.5, 1.0])           # segment boundaries
+    xg.requires_grad_(True)
+    yg = T.GtmManual(4)(xg, pg)
+    ggx, ggp = torch.autograd.grad(yg, (xg, pg), gy)
+    kat = T.GtmManual(4)(torch.full((1, 3, 64, 64), 0.9), torch.tensor([[0.3, 0.5, 0.7]]))
+    npz('pointwise', x=x, wbq_p=pq, wbq_y=y, gy=gy, wbq_gx=gx, wbq_gp=gp,
+        gtm_x=xg, gtm_p=pg, gtm_y=yg, gtm_gx=ggx, gtm_gp=ggp,
+        gtm_kat=np.array([kat.min().item(), kat.max().item()], np.float32))
+
+
+# ---------------------------------------------------------------- 2. conditional heads
+def gold_conditional():
+    x = rnd(2, 3, 16, 16, seed=5)
+    out = {}
+    for tag, cls, inch, nout in (('gamma', T.ConditionalGamma, (12, 8), 1),
+                                 ('wbm', T.ConditionalWbManual, (12, 8), 3),
+                                 ('wbq', T.ConditionalWbQuadratic, (24, 16, 8), 30)):
+        m = cls(inch)
+        flat = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).standard_normal(m.total_params).astype(np.float32) * 0.05)
+        out[tag + '_flat'] = flat
+        out[tag + '_fc'] = m._fc_forward(x, flat)
+        out[tag + '_inch'] = np.array(inch)
+        if tag == 'wbq':
+            out['wbq_y'] = m(x, flat)
+    npz('conditional', x=x, **out)
+
+
+# ---------------------------------------------------------------- 3. CNN families
+def gold_cnn():
+    gy3 = rnd(2, 3, 16, 16, seed=13) - 0.5
+    for tag, mod, kind, P, xin in (
+            ('srcnn_res_p2', SRCNNRes(2), 'srcnn_res', 2, rnd(2, 3, 16, 16, seed=7) * 1.2 - 0.1),
+            ('srcnn_res_p5', SRCNNRes(5), 'srcnn_res', 5, rnd(2, 3, 16, 16, seed=8)),
+            ('srcnn_demosaic', SRCNNDemosaic(0), 'srcnn_demosaic', 0, rnd(2, 1, 16, 16, seed=9)),
+            ('path14l_bayer', Path14lBayer(0), 'path14l_bayer', 0, rnd(2, 1, 16, 16, seed=10)),
+            ('path14l_bgr', Path14lBgr(0), 'path14l_bgr', 0, rnd(2, 3, 16, 16, seed=11))):
+        mod.load_state_dict(O.make_weights(kind, 100 + P, P))
+        x = xin.clone().requires_grad_(True)
+        pv = rnd(2, P, seed=12).requires_grad_(True) if P else None
+        y = mod(x, pv)
+        gy = gy3 if y.shape[1] == 3 else gy3[:, :1]
+        grads = torch.autograd.grad(y, (x, pv) if P else (x,), gy)
+        extra = {'pv': pv, 'gpv': grads[1]} if P else {}
+        npz('cnn_' + tag, x=x, y=y, gy=gy, gx=grads[0], seed=np.array(100 + P), P=np.array(P), **extra)
+    # one non-square, larger case for tile-edge coverage of the conv kernels
+    mod = Path14lBayer(0)
+    mod.load_state_dict(O.make_weights('path14l_bayer', 77))
+    x = rnd(1, 1, 40, 72, seed=14)
+    npz('cnn_path14l_bayer_40x72', x=x, y=mod(x, None), seed=np.array(77))
+    mod = SRCNNRes(3)
+    mod.load_state_dict(O.make_weights('srcnn_res', 78, 3))
+    x, pv = rnd(1, 3, 36, 70, seed=15), rnd(1, 3, seed=16)
+    npz('cnn_srcnn_res_p3_36x70', x=x, pv=pv, y=mod(x, pv), seed=np.array(78), P=np.array(3))
+
+
+# ---------------------------------------------------------------- 4. super-net
+def seed_supernet(net, base):
+    for s, mods in enumerate(net.all_modules):
+        for k, m in enumerate(mods):
+            seed_module(m, base + 100 * s + k)
+
+
+def gold_supernet():
+    net = SP.SuperPruneFifteenDemosFourBayerTwo(n_step=2, threshold=0.2, module_path='/nonexistent/')
+    seed_supernet(net, 1000)
+    rng = np.random.Generator(np.random.PCG64(20))
+    with torch.no_grad():
+        for a in net.alphas:
+            a.copy_(torch.from_numpy(rng.standard_normal(a.shape).astype(np.float32)))
+        net.alpha_demosaic[3] = -20.0                      # DemosaicNet: not reproducible
+        net.alpha_step1[1] = -3.0                          # force a pruned parametrised op
+        for p in net.trainable_parameters:
+            if p.numel():
+                p.add_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32)) * 0.2)
+    x = rnd(2, 1, 16, 16, seed=21)
+    y = net(x)
+    gy = rnd(2, 3, 16, 16, seed=22) - 0.5
+    named = dict(net.named_parameters())
+    keys = sorted(named)
+    grads = torch.autograd.grad(y, [named[k] for k in keys], gy, allow_unused=True)
+    out = {'x': x, 'y': y, 'gy': gy, 'pruned_paths': np.array(net.pruned_paths)}
+    for i, m in enumerate(net.intermediate_results):
+        out['mid%d' % i] = m
+    for k, g in zip(keys, grads):
+        out['p_' + k] = named[k]
+        out['g_' + k] = g if g is not None else torch.zeros_like(named[k])
+    out['state_keys'] = np.array(list(net.state_dict().keys()))
+    out['n_trainable'] = np.array(len(net.trainable_parameters))
+    npz('supernet_n2', **out)
+
+
+# ---------------------------------------------------------------- 5. fixed pipelines
+def gold_fixed():
+    x = rnd(2, 1, 16, 16, seed=30)
+    arch = 'Bayer_01_02_Demosaic_01_sRGB_11_01_13_05_15'
+    net = OU.OriginUniversal(module_path='/nonexistent/', architecture=arch)
+    for k, m in enumerate(net.all_modules):
+        seed_module(m, 2000 + k)
+    y = net(x)
+    out = {'x': x, 'y': y, 'arch': np.array(arch),
+           'state_keys': np.array(list(net.state_dict().keys()))}
+    for i, m in enumerate(net.intermediate_results):
+        out['mid%d' % i] = m
+    npz('fixed_origin', **out)
+
+    arch = 'Bayer_02_Demosaic_03_sRGB_01_14_16_17_18_07'
+    np.random.seed(5)
+    net = IU.IspUniversal(module_path='/nonexistent/', indiv_module_paths=(None,) * 8, architecture=arch,
+                          gamma_in_channels=(12, 8), wb_manual_in_channels=(12, 8),
+                          wb_quadratic_in_channels=(24, 8))
+    for k, m in enumerate(net.all_modules):
+        seed_module(m, 3000 + k)
+    y = net(x)
+    out = {'x': x, 'y': y, 'arch': np.array(arch),
+           'state_keys': np.array(list(net.state_dict().keys()))}
+    for i, m in enumerate(net.intermediate_results):
+        out['mid%d' % i] = m
+    for k, v in net.state_dict().items():
+        out['p_' + k] = v
+    npz('fixed_isp', **out)
+
+
+# ---------------------------------------------------------------- 6. DARTS search step
+def gold_darts():
+    import models.darts_model as DM
+    from collections import OrderedDict
+    opt = OrderedDict(model='darts', gpu_ids=None, dist=False, is_train=True,
+                      network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=2,
+                                     n_modules=15, prune_threshold=0.2),
+                      path=dict(pretrain_model_G=None, strict_load=True),
+                      train=dict(lr_G=1e-2, momentum_G=0.9, lr_meta=1e-2, beta1=0.9, beta2=0.99,
+                                 pixel_criterion='l2', lr_scheme='MultiStepLR', lr_steps=[1000],
+                                 restarts=None, restart_weights=None, lr_gamma=0.5, clear_state=False))
+    model = DM.DartsModel(opt)
+    for net in (model.netG, model.netV):
+        seed_supernet(net, 1000)
+        with torch.no_grad():
+            net.alpha_demosaic[3] = -20.0
+    img, gt = rnd(2, 1, 16, 16, seed=40), rnd(2, 3, 16, 16, seed=41)
+    vimg, vgt = rnd(2, 1, 16, 16, seed=42), rnd(2, 3, 16, 16, seed=43)
+    out = {'img': img, 'gt': gt, 'val_img': vimg, 'val_gt': vgt}
+    for it in range(2):
+        model.feed_data((img, gt, vimg, vgt))
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.optimize_alphas()
+        out['it%d_val_loss' % it] = model.val_loss
+        for k, a in enumerate(model.netG.alphas):
+            out['it%d_alpha_grad%d' % (it, k)] = a.grad
+        model.optimize_parameters()
+        out['it%d_loss' % it] = np.array(model.log_dict['loss'], np.float32)
+        for k, v in model.netG.state_dict().items():
+            out['it%d_%s' % (it, k)] = v
+    npz('darts_step', **out)
+
+
+# ---------------------------------------------------------------- 7. tiling + metrics
+def gold_tiling():
+    img = rnd(50, 77, 3, seed=50).numpy()
+    patches, pos, cnt = UPR.whole2patch(img, (16, 20), (12, 14))
+    proc = patches * 0.5 + 0.1
+    whole = UPR.patch2whole(proc, pos, cnt, (12, 14))
+    npz('tiling', img=img, positions=pos, count_map=cnt, patches=patches, processed=proc, whole=whole,
+        mask=UPR.create_patch_mask((16, 20), (2, 3)))
+    t = rnd(1, 3, 8, 8, seed=51) * 1.2 - 0.1
+    u = rnd(1, 3, 8, 8, seed=52)
+    a, b = UU.tensor2bgr(t), UU.tensor2bgr(u)
+    npz('metrics', t=t, u=u, t_u8=a, u_u8=b, psnr=np.array(UU.psnr(a, b), np.float64))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling']
+    for w in which:
+        globals()['gold_' + w]()
