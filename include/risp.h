@@ -1,0 +1,196 @@
+/*
+ * risp.h - C ABI of libreconfigisp_hip.so, the MI355X (gfx950) implementation of
+ * ReconfigISP's per-image ISP forward path.
+ *
+ * What this boundary replaces (paths relative to the reference's codes/):
+ *   - the absent /DATA/ISP_Kernels plugin that models/modules/tools_origin.py:8-17
+ *     imports and calls as  Kernel().run(img, option, params_dict)  (14 call sites,
+ *     SURVEY.md section 8b);
+ *   - the torch-eager bodies of the in-tree operators (WbQuadratic, GtmManual, the
+ *     SRCNN / Path-Restore proxies, the mixed-op combiner, whole2patch/patch2whole).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  Every pointer is DEVICE memory
+ *     owned by the caller (PyTorch); the library keeps no reference past the call and
+ *     allocates nothing; scratch space is passed in explicitly.
+ *   - tensors are contiguous NCHW fp32; colour images are BGR (ch0=B, ch1=G, ch2=R),
+ *     Bayer mosaics are 1-channel RGGB; H and W are even.
+ *   - `stream` is a hipStream_t (NULL = default stream); launches are asynchronous.
+ *   - return value 0 = OK; non-zero = error, text via risp_last_error() (thread local).
+ *   - re-entrant: no mutable global state.
+ */
+#ifndef RISP_H
+#define RISP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RISP_VERSION 100
+
+int risp_version(void);
+const char *risp_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Element-wise operators.  `p` is the (N,P) per-image parameter block in [0,1]
+ * (what the reference passes as sigmoid(par).repeat(N,1)); gp is (N,P) and is
+ * fully written by the call.
+ * ------------------------------------------------------------------------- */
+
+/* demosaic.Demosaic().run(img,'nearestneighbor',..) - tools_origin.py:278-284.
+ * (N,1,H,W) RGGB -> (N,3,H,W) BGR.  OPSPEC: R,B replicated over the 2x2 quad,
+ * G takes the green sample of its own row. */
+int risp_demosaic_nearest_fwd(const float *bayer, float *bgr, int N, int H, int W, void *stream);
+int risp_demosaic_nearest_bwd(const float *g_bgr, float *g_bayer, int N, int H, int W, void *stream);
+
+/* whitebalance.WhiteBalance().run(img,'manual',{'gain':5p}) - tools_origin.py:211-221. P=3 */
+int risp_wb_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
+int risp_wb_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
+                       int N, int HW, void *stream);
+
+/* gamma.Gamma().run(img,'manual',{'gamma':g}) - tools_origin.py:59-69. P=1.
+ * OPSPEC: y = x^g (x >= 1/1024), y = x * (1/1024)^(g-1) below. */
+int risp_gamma_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
+int risp_gamma_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
+                   int N, int HW, void *stream);
+
+/* GtmManual(4).forward - tools_origin.py:414-440. P=3; knots come from p[0,:] only,
+ * so gp[0,:] holds the whole-batch gradient and gp[1:,:] = 0. */
+int risp_gtm_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
+int risp_gtm_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
+                        int N, int HW, void *stream);
+
+/* WbQuadratic.forward - tools_origin.py:317-359. P=30, coef[n,ch,j] = 10 p[n,10ch+j] - 5 */
+int risp_wb_quadratic_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
+int risp_wb_quadratic_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
+                          int N, int HW, void *stream);
+
+/* Per-image per-channel statistics of an (N,C,H,W) tensor (NC = N*C planes):
+ * stats[plane*4+{0,1,2}] = {min, sum, max}; arg[plane*2+{0,1}] = first (row-major) index of
+ * the min / max (may be NULL).  Used by SRCNNRes (srcnn_res_arch.py:36-40) and gray-world.
+ * scratch: risp_channel_stats_scratch_floats(NC,HW) floats.  Deterministic (no atomics). */
+size_t risp_channel_stats_scratch_floats(int NC, int HW);
+int risp_channel_stats(const float *x, float *stats, int32_t *arg, float *scratch, int NC, int HW,
+                       void *stream);
+/* backward of the statistics, in place on gx (NC planes): gx += g_mean[plane]/HW everywhere,
+ * gx[argmin] += g_min[plane], gx[argmax] += g_max[plane]; any of the three may be NULL. */
+int risp_stats_bwd(float *gx, const float *g_min, const float *g_mean, const float *g_max,
+                   const int32_t *arg, int NC, int HW, void *stream);
+
+/* Per-plane histogram with torch.histc(x, bins, min=0, max=1) semantics (raw counts as fp32;
+ * out-of-range values ignored; x == 1 in the last bin) - the conditional heads' feature,
+ * tools_origin.py:120-128 (computed on the CPU there).  hist is (NC,bins), fully written. */
+int risp_histc(const float *x, float *hist, int NC, int HW, int bins, void *stream);
+
+/* SRCNNRes broadcast-plane values (srcnn_res_arch.py:36-43): cvals (N,9+P) =
+ * [min_b,min_g,min_r | mean | max | pv (N,P)] from the stats of the (N,3,H,W) input. */
+int risp_srcnn_cvals(const float *stats, const float *pv, float *cvals, int N, int P, int HW, void *stream);
+
+/* whitebalance 'grayworld' - tools_origin.py:33-41 ("output is clipped to [0, 1]", :22).
+ * OPSPEC: gains[n,c] = gray_n / max(mean[n,c],1e-6), gray = mean over c of the channel means;
+ * y = clamp(x * gains).  Composition: risp_channel_stats -> risp_grayworld_gains_fwd ->
+ * risp_gain3_fwd; backward: risp_gain3_bwd -> risp_grayworld_gains_bwd -> risp_stats_bwd. */
+int risp_grayworld_gains_fwd(const float *stats, float *gains, int N, int HW, void *stream);
+int risp_grayworld_gains_bwd(const float *stats, const float *g_gains, float *g_mean, int N, int HW,
+                             void *stream);
+/* y[n,c] = clamp(x[n,c] * k[n,c], 0, 1); k is (N,3) */
+int risp_gain3_fwd(const float *x, const float *k, float *y, int N, int HW, void *stream);
+int risp_gain3_bwd(const float *x, const float *k, const float *gy, float *gx, float *gk, int N, int HW,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused element-wise segment of a fixed pipeline (isp_universal.py:210-232): one
+ * launch reads the segment input once and writes EVERY stage output
+ * (intermediate_results is API).  ops[k] in RISP_OP_*; params[k] = (N,P_k) or NULL;
+ * outs[k] = (N,3,H,W) (NULL for RISP_OP_SKIP, which aliases its input).
+ * The first op may be RISP_OP_DEMOSAIC_NEAREST (input (N,1,H,W)); all others take BGR.
+ * ------------------------------------------------------------------------- */
+enum {
+    RISP_OP_SKIP = 0,
+    RISP_OP_DEMOSAIC_NEAREST = 1,
+    RISP_OP_WB_MANUAL = 2,
+    RISP_OP_GAMMA = 3,
+    RISP_OP_GTM_MANUAL = 4,
+    RISP_OP_WB_QUADRATIC = 5,
+    RISP_OP_GAIN3 = 6 /* y_c = clamp(x_c * p[n,c]): gray-world apply with precomputed gains */
+};
+#define RISP_MAX_CHAIN 8
+int risp_chain_fwd(const float *in, int n_ops, const int *ops, const float *const *params,
+                   float *const *outs, int N, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Mixed-op combiner (super_prune_fifteen_demos_four_bayer_two.py:183-212):
+ * y = sum_k w[k] * o_k  over K op outputs of one slot (w = pruned, renormalised probs,
+ * host array).  bwd: go_k = w[k]*gy (written only where go[k] != NULL) and
+ * gw[k] = <gy, o_k> (device, K floats, fully written).
+ * ------------------------------------------------------------------------- */
+#define RISP_MAX_MIX 16
+int risp_mix_fwd(const float *const *outs, const float *w, int K, float *y, size_t numel, void *stream);
+int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *gy,
+                 float *const *go, float *gw, size_t numel, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Convolution layers of the learned proxies on fp32 MFMA
+ * (srcnn_res_arch.py:15-24, srcnn_demosaic_arch.py:14-25, path_14l_*_arch.py:6-57).
+ * Stride 1, 'same' zero padding, odd square kernels.
+ *
+ *   y = epilogue( conv(load(x), W) + bias )
+ *
+ * wpack: weights repacked on the device by risp_conv_pack_weights into the
+ * [chunk][tap][ci][cout_pad] slabs the kernel stages in LDS.
+ * ------------------------------------------------------------------------- */
+enum { /* how the kernel reads its input tensor */
+    RISP_LOAD_PLAIN = 0,      /* x is (N,cin,H,W) */
+    RISP_LOAD_UNSHUFFLE2 = 1, /* x is (N,cin/4,2H,2W); plane 4c+2i+j = x[c][2y+i][2x+j].  cin=4: the
+                                 Bayer -> [R,G1,G2,B] split (path_14l_bayer_arch.py:70-75); also the
+                                 backward of a PixelShuffle(2) store */
+    RISP_LOAD_CONSTCH = 2     /* channels >= cin_img are per-image constants cvals[n,ci-cin_img]
+                                 inside the image and 0 in the padding (SRCNNRes broadcast planes,
+                                 srcnn_res_arch.py:41-46) */
+};
+enum { /* epilogue flags */
+    RISP_EPI_RELU = 1,       /* y = max(y,0) */
+    RISP_EPI_ADD = 2,        /* y[:, :add_c] += add (N,add_c,H,W), before the activation */
+    RISP_EPI_MASK = 4,       /* y = (mask[n,co,h,w] > 0) ? y : 0   (backward through a ReLU) */
+    RISP_EPI_SHUFFLE2 = 8,   /* store through PixelShuffle(2): (N,cout,H,W) -> (N,cout/4,2H,2W) */
+    RISP_EPI_NOBIAS = 16
+};
+typedef struct {
+    int N, H, W;             /* H,W = conv resolution (half the source for RISP_LOAD_UNSHUFFLE2) */
+    int cin, cout, ksize;    /* cout <= 64; ksize in {1,3,5,9} */
+    int load_mode, cin_img;  /* cin_img: image channels when load_mode == RISP_LOAD_CONSTCH */
+    int epilogue, add_c;
+    const float *x, *wpack, *bias, *cvals, *add, *mask;
+    float *y;
+} risp_conv_desc;
+size_t risp_conv_wpack_floats(int cin, int cout, int ksize);
+/* w: device (cout,cin,k,k) torch layout.  transpose=1: w is the FORWARD layer's (cin,cout,k,k)
+ * tensor and the pack holds the backward-data convolution (roles swapped, taps rotated 180). */
+int risp_conv_pack_weights(const float *w, int cin, int cout, int ksize, int transpose, float *wpack,
+                           void *stream);
+int risp_conv2d(const risp_conv_desc *d, void *stream);
+
+/* sum over H,W of channels [c0, c0+nc) of an (N,C,H,W) tensor -> out (N,nc) (SRCNNRes
+ * gradient of the broadcast parameter planes). */
+int risp_plane_sums(const float *x, float *out, int N, int C, int c0, int nc, int HW, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Overlapped tiling (utils/util_path_restore.py:47-134), NCHW on device.
+ * positions: host int32 [T][2] (y,x).
+ * ------------------------------------------------------------------------- */
+int risp_tile_gather(const float *img, float *patches, const int32_t *pos_dev, int T, int C,
+                     int H, int W, int h, int w, void *stream);
+int risp_tile_blend(const float *patches, float *img, const int32_t *pos_dev, int T, int C,
+                    int H, int W, int h, int w, int eh, int ew, void *stream);
+
+/* tensor2bgr + psnr on device (utils/util.py:118-154): truncating uint8 conversion of
+ * both images, squared error accumulated in fp64 into sse[0] (zeroed by the call). */
+int risp_sse_uint8(const float *a, const float *b, double *sse, size_t numel, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RISP_H */

@@ -1,0 +1,223 @@
+"""DartsModel - one architecture-search iteration = optimize_alphas() + optimize_parameters()
+(mirror of models/darts_model.py:19-330).
+
+Second-order DARTS as the reference does it: virtual SGD step into a twin network netV,
+validation loss at the virtual weights, finite-difference Hessian-vector product with
+eps = 0.01/||dp||, alpha gradient ``dalpha - lr_meta * hessian`` where the reference computes
+``hessian = (pos - neg) / 2. * eps`` (sic, :323 - kept), Adam on alpha, SGD(momentum) on the
+module parameters.  5 forwards + 5 backwards of the super-net per iteration.
+
+Multi-GPU (one process per GPU, RCCL over xGMI): the weight step's gradients are averaged
+across ranks (what DDP's bucket all-reduce does in the reference, :31,173) by ONE flat
+all-reduce of the 146..216-float gradient vector; ``train.sync_arch_grads`` (default true, new)
+also averages the three architecture-step gradient sets so that W ranks reproduce one process
+with a W-times larger batch (the reference leaves them rank-local).
+"""
+import logging
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ..utils.util_loss import latency_loss, local_global_loss
+from . import networks
+from .base_model import BaseModel
+from .isp_model import make_schedulers
+
+logger = logging.getLogger('base')
+
+
+def _criterion(kind, train_opt, device):
+    if kind == 'l1':
+        return nn.L1Loss().to(device)
+    mse = nn.MSELoss().to(device)
+    if kind == 'l2':
+        return mse
+    if kind == 'local_global_l2':
+        return partial(local_global_loss, loss_func=mse)
+    if kind == 'l2_latency':
+        return partial(latency_loss, target_latency=train_opt['target_latency'], w=train_opt['w'],
+                       fidelity_loss=mse)
+    raise NotImplementedError('pixel_criterion [{}]'.format(kind))
+
+
+class DartsModel(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.distributed = bool(opt['dist'])
+        self.rank = dist.get_rank() if self.distributed else -1
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.netG = networks.define_G(opt).to(self.device)
+        self.netV = networks.define_G(opt).to(self.device)     # twin for the virtual step (not a deepcopy)
+        self.netG_attr = self.netG
+        if self.distributed:                                      # replicas must start identical
+            for t in list(self.netG.parameters()) + list(self.netV.parameters()):
+                dist.broadcast(t.data, src=0)
+        if self.rank <= 0:
+            self.print_network()
+        self.load()
+        self.img = self.gt = self.output = self.glb_flag = None
+        self.val_img = self.val_gt = self.val_loss = self.val_glb_flag = None
+        self.latency = self.latency_term = None
+
+        if self.is_train:
+            t = opt['train']
+            self.netG.train()
+            kind = t['pixel_criterion']
+            self.is_local_global = 'local_global' in kind
+            self.is_latency = 'latency' in kind
+            self.cri_pix = _criterion(kind, t, self.device)
+            self.cri_pix_v = _criterion(kind, t, self.device)
+            self.momentum_G = t['momentum_G']
+            self.lr_meta = t['lr_meta']
+            self.sync_arch_grads = bool(t.get('sync_arch_grads', True)) if hasattr(t, 'get') else True
+            self.optimizer_G = torch.optim.SGD(self.netG_attr.trainable_parameters, t['lr_G'],
+                                               momentum=self.momentum_G)
+            self.optimizer_alpha = torch.optim.Adam(self.netG_attr.alphas, lr=t['lr_G'],
+                                                    betas=(t['beta1'], t['beta2']))
+            self.optimizers += [self.optimizer_G, self.optimizer_alpha]
+            self.schedulers += make_schedulers(self.optimizers, t)
+        else:
+            self.netG.eval()
+        self.log_dict = OrderedDict()
+
+    # ------------------------------------------------------------------ plumbing
+    def print_network(self):
+        s, n = self.get_network_description(self.netG)
+        logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))
+        logger.info(s)
+
+    def get_current_log(self):
+        return self.log_dict
+
+    def load(self):
+        path = self.opt['path']['pretrain_model_G']
+        if path is not None:
+            logger.info('Loading model for G [{:s}] ...'.format(path))
+            self.load_network(path, self.netG, self.opt['path']['strict_load'])
+
+    def save(self, iter_label):
+        self.save_network(self.netG, 'G', iter_label)
+
+    def feed_data(self, data):
+        """(img, gt) | (img, gt, val_img, val_gt) | (img, gt, flag, val_img, val_gt, val_flag)"""
+        if len(data) == 4:
+            self.val_img, self.val_gt = data[2].to(self.device), data[3].to(self.device)
+        elif len(data) == 6:
+            self.glb_flag, self.val_glb_flag = data[2].to(self.device), data[5].to(self.device)
+            self.val_img, self.val_gt = data[3].to(self.device), data[4].to(self.device)
+        elif len(data) != 2:
+            raise ValueError('Invalid data format.')
+        self.img, self.gt = data[0].to(self.device), data[1].to(self.device)
+
+    def _loss(self, net, img, gt, flag, criterion):
+        if self.is_latency:
+            out, lat = net(img)
+            loss, term = criterion(out, gt, lat)
+            return loss, out, lat, term
+        out = net(img)
+        loss = criterion(out, gt, flag) if self.is_local_global else criterion(out, gt)
+        return loss, out, None, None
+
+    def _allreduce_mean(self, tensors):
+        """Average a list of small gradient tensors over the ranks with ONE flat all-reduce (RCCL)."""
+        if not self.distributed or self.world == 1:
+            return tensors
+        live = [t for t in tensors if t is not None and t.numel()]
+        if not live:
+            return tensors
+        flat = torch.cat([t.reshape(-1) for t in live])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= self.world
+        at = 0
+        for t in live:
+            t.copy_(flat[at: at + t.numel()].view_as(t))
+            at += t.numel()
+        return tensors
+
+    # ------------------------------------------------------------------ weight step
+    def optimize_parameters(self):
+        l_pix, self.output, self.latency, self.latency_term = self._loss(self.netG, self.img, self.gt,
+                                                                         self.glb_flag, self.cri_pix)
+        self.optimizer_G.zero_grad()
+        l_pix.backward()
+        self._allreduce_mean([p.grad for p in self.netG_attr.trainable_parameters])
+        self.optimizer_G.step()
+        self.log_dict['loss'] = l_pix.item()
+        if self.is_latency:
+            self.log_dict['latency'] = self.latency.item()
+            self.log_dict['latency_term'] = self.latency_term.item()
+
+    # ------------------------------------------------------------------ architecture step
+    def virtual_step(self):
+        """p' = p - lr_meta * (momentum * buf + dL_trn/dp) written into netV; alphas copied."""
+        loss = self._loss(self.netG, self.img, self.gt, self.glb_flag, self.cri_pix)[0]
+        params = self.netG_attr.trainable_parameters
+        grads = list(torch.autograd.grad(loss, params, allow_unused=True))
+        if self.sync_arch_grads:
+            self._allreduce_mean(grads)
+        with torch.no_grad():
+            for p, vp, g in zip(params, self.netV.trainable_parameters, grads):
+                if len(p) == 0:
+                    continue
+                if g is None:
+                    vp.copy_(p)
+                else:
+                    buf = self.optimizer_G.state[p].get('momentum_buffer', 0.) * self.momentum_G
+                    vp.copy_(p - self.lr_meta * (buf + g))
+            for a, va in zip(self.netG_attr.alphas, self.netV.alphas):
+                va.copy_(a)
+
+    def optimize_alphas(self):
+        self.optimizer_alpha.zero_grad()
+        self.virtual_step()
+        loss = self._loss(self.netV, self.val_img, self.val_gt, self.val_glb_flag, self.cri_pix_v)[0]
+        self.val_loss = loss
+        v_alphas, v_params = tuple(self.netV.alphas), tuple(self.netV.trainable_parameters)
+        grads = list(torch.autograd.grad(loss, v_alphas + v_params, allow_unused=True))
+        if self.sync_arch_grads:
+            self._allreduce_mean(grads)
+        dalpha, dp = grads[:len(v_alphas)], grads[len(v_alphas):]
+        hessian = self.compute_hessian(dp)
+        with torch.no_grad():
+            for idx, (alpha, da, h) in enumerate(zip(self.netG_attr.alphas, dalpha, hessian), start=1):
+                if da is None or h is None:
+                    alpha.grad = torch.zeros_like(alpha)
+                elif torch.isnan(h).any():
+                    print('Warning: NaN in hessian, for the {}-th alpha'.format(idx))
+                    alpha.grad = torch.zeros_like(alpha)
+                else:
+                    alpha.grad = da - self.lr_meta * h
+        self.optimizer_alpha.step()
+
+    def compute_hessian(self, dp):
+        """(dalpha L_trn(p + eps dp) - dalpha L_trn(p - eps dp)) / 2. * eps, eps = 0.01/||dp||."""
+        norm = torch.cat([w.view(-1) for w in dp if w is not None]).norm()
+        eps = 0. if norm < 1e-6 else 0.01 / norm
+        params = self.netG_attr.trainable_params
+
+        def shift(scale):
+            with torch.no_grad():
+                for p, d in zip(params, dp):
+                    if len(p) > 0 and d is not None:
+                        p += scale * d
+
+        def dalpha_at():
+            loss = self._loss(self.netG, self.img, self.gt, self.glb_flag, self.cri_pix)[0]
+            return list(torch.autograd.grad(loss, self.netG_attr.alphas))
+
+        shift(eps)
+        pos = dalpha_at()
+        shift(-2. * eps)
+        neg = dalpha_at()
+        shift(eps)
+        if self.sync_arch_grads:
+            self._allreduce_mean(pos + neg)
+        return [(p - n) / 2. * eps if p is not None and n is not None else None for p, n in zip(pos, neg)]
+
+    def test(self):
+        with torch.no_grad():
+            self.output = self.netG(self.img)
+        return self.output, self.netG_attr.intermediate_results

@@ -1,0 +1,102 @@
+"""IspModel - trains / tests ONE fixed pipeline (mirror of models/isp_model.py:14-151):
+Adam on the pipeline parameters, L1 / L2 pixel loss, ``test()`` returning
+``(output, intermediate_results)``.  Single device, as in the reference (:19-24)."""
+import logging
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import lr_scheduler, networks
+from .base_model import BaseModel
+
+logger = logging.getLogger('base')
+
+
+def make_schedulers(optimizers, train_opt):
+    scheme = train_opt['lr_scheme']
+    if scheme == 'MultiStepLR':
+        return [lr_scheduler.MultiStepLR_Restart(o, train_opt['lr_steps'], restarts=train_opt['restarts'],
+                                                 weights=train_opt['restart_weights'], gamma=train_opt['lr_gamma'],
+                                                 clear_state=train_opt['clear_state']) for o in optimizers]
+    if scheme == 'CosineAnnealingLR_Restart':
+        return [lr_scheduler.CosineAnnealingLR_Restart(o, train_opt['T_period'], eta_min=train_opt['eta_min'],
+                                                       restarts=train_opt['restarts'],
+                                                       weights=train_opt['restart_weights']) for o in optimizers]
+    raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
+
+
+def pixel_criterion(kind, device):
+    if kind == 'l1':
+        return nn.L1Loss().to(device)
+    if kind == 'l2':
+        return nn.MSELoss().to(device)
+    raise NotImplementedError('pixel_criterion [{}]'.format(kind))
+
+
+class IspModel(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.rank = -1
+        self.netG = networks.define_G(opt).to(self.device)
+        self.netG_attr = self.netG
+        self.print_network()
+        self.load()
+        self.img = self.gt = self.output = self.val_img = self.val_gt = self.l_pix = self.meta = None
+        if self.is_train:
+            train_opt = opt['train']
+            self.netG.train()
+            self.cri_pix = pixel_criterion(train_opt['pixel_criterion'], self.device)
+            self.cri_pix_v = pixel_criterion(train_opt['pixel_criterion'], self.device)
+            self.optimizer_G = torch.optim.Adam(self.netG.trainable_parameters, train_opt['lr_G'],
+                                                (train_opt['beta1'], train_opt['beta2']))
+            self.optimizers.append(self.optimizer_G)
+            self.schedulers += make_schedulers(self.optimizers, train_opt)
+        else:
+            self.netG.eval()
+        self.log_dict = OrderedDict()
+
+    def print_network(self):
+        s, n = self.get_network_description(self.netG)
+        if self.rank <= 0:
+            logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))
+            logger.info(s)
+
+    def get_current_log(self):
+        return self.log_dict
+
+    def load(self):
+        path = self.opt['path']['pretrain_model_G']
+        if path is not None:
+            logger.info('Loading model for G [{:s}] ...'.format(path))
+            self.load_network(path, self.netG, self.opt['path']['strict_load'])
+
+    def save(self, iter_label):
+        self.save_network(self.netG, 'G', iter_label)
+
+    def feed_data(self, data):
+        """(img, gt) | (img, gt, meta) | (img, gt, val_img, val_gt) | (img, gt, val_img, val_gt, meta)"""
+        if len(data) not in (2, 3, 4, 5):
+            raise ValueError('Invalid data format.')
+        if len(data) >= 4:
+            self.val_img, self.val_gt = data[2].to(self.device), data[3].to(self.device)
+        if len(data) in (3, 5):
+            self.meta = data[-1].to(self.device)
+        self.img, self.gt = data[0].to(self.device), data[1].to(self.device)
+
+    def _forward(self):
+        return self.netG(self.img) if self.meta is None else self.netG(self.img, self.meta)
+
+    def optimize_parameters(self):
+        self.output = self._forward()
+        self.l_pix = self.cri_pix(self.output, self.gt)
+        self.optimizer_G.zero_grad()
+        self.l_pix.backward()
+        self.optimizer_G.step()
+        self.log_dict['loss'] = self.l_pix.item()
+
+    def test(self):
+        # nothing back-propagates through test(): run the fused inference path
+        with torch.no_grad():
+            self.output = self._forward()
+        return self.output, self.netG.intermediate_results

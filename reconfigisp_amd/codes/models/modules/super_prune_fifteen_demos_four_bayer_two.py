@@ -1,0 +1,112 @@
+"""SuperPruneFifteenDemosFourBayerTwo - the DARTS super-net with online pruning.
+
+Slot 0: 2 Bayer ops, slot 1: 4 demosaic ops, slots 2..n_step+1: 15 sRGB ops each.  Mirror of
+models/modules/super_prune_fifteen_demos_four_bayer_two.py:13-230: same constructor, forward
+semantics (softmax -> prune strictly below threshold*max on detached probs -> renormalise by the
+detached sum -> weighted sum, 'dummy gradient' for pruned parametrised ops), properties and
+state-dict keys (alpha_bayer, alpha_demosaic, alpha_step<k>, param_step<k>_<name>).
+The weighted sum of a slot is one fused kernel (risp_mix_fwd/bwd) instead of K multiply-adds.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from .... import functional as F
+from . import registry as R
+
+
+class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
+    def __init__(self, n_step, threshold, module_path):
+        super().__init__()
+        self.threshold = threshold
+        self.middle_results = None
+        self.pruned_paths = [0] * (n_step + 2)     # bayer, demosaic, then the sRGB steps
+        self.all_modules, self.all_params, self.all_alphas = [], [], []
+        self.trainable_params = []
+        self.slot_names = []
+
+        def empty():
+            return nn.Parameter(torch.zeros(0))
+
+        for alpha_key, names in (('alpha_bayer', R.NAMES_BAYER), ('alpha_demosaic', R.NAMES_DEMOSAIC)):
+            setattr(self, alpha_key, nn.Parameter(torch.zeros(len(names))))
+            self.all_modules.append([R.make_op(n, module_path) for n in names])
+            self.all_params.append([empty() for _ in names])
+            self.all_alphas.append(getattr(self, alpha_key))
+            self.slot_names.append(list(names))
+
+        for k in range(1, n_step + 1):
+            mods, pars = [], []
+            for name in R.NAMES_SRGB:
+                mods.append(R.make_op(name, module_path))
+                init = R.PARAM_INIT[name]
+                if init:
+                    key = 'param_step{}_{}'.format(k, name)
+                    setattr(self, key, nn.Parameter(torch.tensor(init, dtype=torch.float32)))
+                    pars.append(getattr(self, key))
+                else:
+                    pars.append(empty())
+            setattr(self, 'alpha_step{}'.format(k), nn.Parameter(torch.zeros(len(R.NAMES_SRGB))))
+            self.trainable_params += pars          # includes the zero-size placeholders (:163)
+            self.all_modules.append(mods)
+            self.all_params.append(pars)
+            self.all_alphas.append(getattr(self, 'alpha_step{}'.format(k)))
+            self.slot_names.append(list(R.NAMES_SRGB))
+        self.param_and_alpha = self.trainable_params + self.all_alphas
+
+    def _apply(self, fn, *args, **kwargs):
+        # ops and zero-size placeholders are kept in plain lists (only alphas / param_step* are
+        # registered, as in the reference); make them follow .to()/.cuda() all the same
+        super()._apply(fn, *args, **kwargs)
+        for mods in self.all_modules:
+            for m in mods:
+                m._apply(fn, *args, **kwargs)
+        for pars in self.all_params:
+            for p in pars:
+                if p.numel() == 0:
+                    p.data = fn(p.data)
+        return self
+
+    def forward(self, x):
+        n = x.size(0)
+        self.middle_results = []
+        for slot, (mods, pars, alpha) in enumerate(zip(self.all_modules, self.all_params, self.all_alphas)):
+            probs = TF.softmax(alpha, dim=0)
+            keep_below = probs.detach() < self.threshold * probs.detach().max()
+            post = probs.clone()
+            post[keep_below] = 0
+            post = post / post.sum().detach()
+            weights = post.detach().cpu().tolist()       # one D2H per slot (the reference's .item())
+            self.pruned_paths[slot] = sum(1 for w in weights if w == 0.0)
+
+            outs, index, pruned_pars = [], [], []
+            for k, (op, par) in enumerate(zip(mods, pars)):
+                if weights[k] < 1e-9:
+                    if par.nelement() > 0:               # pruned, but must still receive a (zero) gradient
+                        pruned_pars.append(par)
+                    continue
+                par_tensor = torch.sigmoid(par).repeat(n, 1) if par.nelement() > 0 else None
+                outs.append(op(x, par_tensor))
+                index.append(k)
+            y = F.mix(post[index], outs)
+            if pruned_pars:
+                y = F.attach_zero_grad(y, pruned_pars)
+            self.middle_results.append(y)
+            x = y
+        return x
+
+    @property
+    def trainable_parameters(self):
+        return self.trainable_params
+
+    @property
+    def parameters_and_alpha(self):
+        return self.param_and_alpha
+
+    @property
+    def alphas(self):
+        return self.all_alphas
+
+    @property
+    def intermediate_results(self):
+        return self.middle_results

@@ -1,0 +1,260 @@
+"""Operator wrappers of the ISP registry - host-side mirror of the reference's
+models/modules/tools_origin.py (same class names, ``forward(img, params)`` contract and
+parameter scaling), bound to the HIP kernels.
+
+Two kinds of operator, as in the reference:
+  * plugin-backed ones go through the B1 boundary ``Kernel().run(img, option, params_dict)``
+    (reconfigisp_amd.isp_kernels, standing in for the private ISP_Kernels package);
+  * in-tree ones (WbQuadratic :313-359, GtmManual :409-440, Skip :256-262 and the conditional
+    FC-on-histogram heads :77-163) call the functional layer directly.
+``img`` is (N,C,H,W) fp32, ``params`` the (N,P) block in [0,1] or None.
+"""
+import torch
+import torch.nn as nn
+
+from .... import functional as F
+from ....isp_kernels import demosaic as dm
+from ....isp_kernels import gamma as gm
+from ....isp_kernels import globaltonemapping as gtm
+from ....isp_kernels import spatialnoisereduction as snr
+from ....isp_kernels import whitebalance as wb
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1)
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def _io_desc(width, height, fmt_in, bits_in, fmt_out='BGR', bits_out=8):
+    return {'input': {'width': width, 'height': height, 'format': fmt_in, 'bitdepth': bits_in},
+            'output': {'width': width, 'height': height, 'format': fmt_out, 'bitdepth': bits_out}}
+
+
+class _PluginOp(nn.Module):
+    """An operator whose arithmetic lives behind ``self.kernel.run``."""
+    kernel_cls = None
+
+    def __init__(self):
+        super().__init__()
+        self.kernel = self.kernel_cls()
+
+
+# ------------------------------------------------------------------ differentiable, plugin-backed
+class Grayworld(_PluginOp):  # output is clipped to [0, 1]
+    kernel_cls = wb.WhiteBalance
+
+    def forward(self, img, params=None):
+        x = _nhwc(img)
+        desc = _io_desc(x.shape[2], x.shape[1], 'BGR', 8)
+        return _nchw(self.kernel.run(x, 'grayworld', desc))
+
+
+class Gamma(_PluginOp):
+    kernel_cls = gm.Gamma
+
+    def forward(self, img, params):
+        # params: per-image gamma (N,1) in [0,1]
+        return _nchw(self.kernel.run(_nhwc(img), 'manual', {'gamma': params}))
+
+
+class WbManual(_PluginOp):
+    kernel_cls = wb.WhiteBalance
+
+    def forward(self, img, params=None):
+        # params (N,3) in [0,1] -> gain in [0,5]
+        return _nchw(self.kernel.run(_nhwc(img), 'manual', {'gain': params * 5}))
+
+
+class DemosaicNearest(_PluginOp):
+    kernel_cls = dm.Demosaic
+
+    def forward(self, img, params=None):
+        desc = _io_desc(img.shape[3], img.shape[2], 'RGGB', 10)
+        return self.kernel.run(img, 'nearestneighbor', desc)  # NCHW in, NCHW out
+
+
+class DemosaicNet(_PluginOp):
+    kernel_cls = dm.Demosaic
+
+    def forward(self, img, params=None):
+        desc = _io_desc(img.shape[3], img.shape[2], 'RGGB', 10)
+        return self.kernel.run(img, 'demosaicnet', desc)
+
+
+# ------------------------------------------------------------------ in-tree operators
+class Skip(nn.Module):
+    def forward(self, img, params=None):
+        return img  # the same tensor object, no copy
+
+
+class WbQuadratic(nn.Module):
+    def forward(self, img, params):
+        # params (N,30) in [0,1]; coefficient c[n,ch,j] = 10 p[n,10ch+j] - 5 is applied in the kernel
+        return F.wb_quadratic(img, params)
+
+
+class GtmManual(nn.Module):
+    def __init__(self, n_seg):
+        super().__init__()
+        if n_seg != 4:
+            raise NotImplementedError('GtmManual: every reference pipeline uses 4 segments (isp_universal.py:179)')
+        self.n_seg = n_seg
+
+    def forward(self, imgs, params):
+        # knots come from params[0] only - the same curve for the whole batch
+        return F.gtm_manual(imgs, params)
+
+
+# ------------------------------------------------------------------ conditional heads (sRGB 16-18)
+class ConditionalModuleBGR(nn.Module):
+    """FC layers on per-channel histograms predict the module parameters per image.
+
+    The flat parameter vector holds, per layer, an (in,out) row-major weight then a bias, and at
+    the end ``out_channel`` 'global' entries of which only the first is used (scalar add)."""
+
+    def __init__(self, in_channels, out_channel):
+        super().__init__()
+        if in_channels[0] % 3:
+            raise AssertionError('first FC width must be a multiple of 3 (per-channel histograms)')
+        self.hist_bin = in_channels[0] // 3
+        self.in_out_channels = list(in_channels) + [out_channel]
+        widths = self.in_out_channels
+        self.total_params = sum(widths[i] * widths[i + 1] + widths[i + 1] for i in range(len(widths) - 1))
+        self.total_params += out_channel
+        self.module_params = out_channel
+
+    def _fc_forward(self, img, params):
+        if params.size(0) != self.total_params:
+            raise AssertionError('expected %d conditional parameters, got %d' % (self.total_params, params.size(0)))
+        if img.size(1) != 3:
+            raise AssertionError('conditional modules take BGR images')
+        feat = F.hist_features(img, self.hist_bin)           # (N, 3*bins), raw counts, no gradient
+        widths, at = self.in_out_channels, 0
+        for li in range(len(widths) - 1):
+            fan_in, fan_out = widths[li], widths[li + 1]
+            weight = params[at: at + fan_in * fan_out].view(fan_in, fan_out)
+            at += fan_in * fan_out
+            feat = feat @ weight + params[at: at + fan_out]
+            at += fan_out
+            if li < len(widths) - 2:
+                feat = torch.relu(feat)
+        return torch.sigmoid(feat + params[at])
+
+
+class ConditionalGamma(ConditionalModuleBGR):
+    def __init__(self, in_channels):
+        super().__init__(in_channels, 1)
+        self.kernel = gm.Gamma()
+
+    def forward(self, img, params):
+        g = self._fc_forward(img, params)
+        return _nchw(self.kernel.run(_nhwc(img), 'manual', {'gamma': g}))
+
+
+class ConditionalWbManual(ConditionalModuleBGR):
+    def __init__(self, in_channels):
+        super().__init__(in_channels, 3)
+        self.kernel = wb.WhiteBalance()
+
+    def forward(self, img, params=None):
+        gain = self._fc_forward(img, params) * 5
+        return _nchw(self.kernel.run(_nhwc(img), 'manual', {'gain': gain}))
+
+
+class ConditionalWbQuadratic(ConditionalModuleBGR):
+    def __init__(self, in_channels):
+        super().__init__(in_channels, 30)
+
+    def forward(self, img, params):
+        return F.wb_quadratic(img, self._fc_forward(img, params))
+
+
+# ------------------------------------------------------------------ non-differentiable "Origin" kernels
+class _OriginOp(_PluginOp):
+    """8-bit-domain classical operators used by OriginUniversal at test time (tools_origin.py:445-804):
+    scale to 0..255, detach the parameters, run the plugin, scale back.  No gradient."""
+    option = None
+    fmt_in, bits_in = 'BGR', 8
+
+    def _params(self, params, desc):
+        return desc
+
+    def forward(self, img, params=None):
+        x = _nhwc(img) * 255.
+        desc = _io_desc(x.shape[2], x.shape[1], self.fmt_in, self.bits_in)
+        if params is not None:
+            desc = self._params(params.detach(), desc)
+        out = self.kernel.run(x, self.option, desc)
+        return _nchw(out.float() / 255.)
+
+
+class OriginDemosBilinear(_OriginOp):
+    kernel_cls, option, fmt_in, bits_in = dm.Demosaic, 'bilinear', 'RGGB', 10
+
+
+class OriginDemosLaplacian(_OriginOp):
+    kernel_cls, option, fmt_in, bits_in = dm.Demosaic, 'laplacian', 'RGGB', 10
+
+
+class OriginToneReinhard(_OriginOp):
+    kernel_cls, option = gtm.GlobalToneMapping, 'reinhard'
+
+    def _params(self, p, desc):
+        p = p.cpu().numpy()
+        desc.update(white_point=p[:, 0], middle_grey=p[:, 1])
+        return desc
+
+
+class OriginToneCrysis(_OriginOp):
+    kernel_cls, option = gtm.GlobalToneMapping, 'crysisengine'
+
+    def _params(self, p, desc):
+        desc.update(lum_adapted=p.cpu().numpy()[:, 0])
+        return desc
+
+
+class OriginToneFilmic(_OriginOp):
+    kernel_cls, option = gtm.GlobalToneMapping, 'filmic'
+
+    def _params(self, p, desc):
+        p = p.cpu().numpy()
+        desc.update(white_point=p[:, 0], exposure_bias=p[:, 1] * 9. + 1.)   # [0,1] -> [1,10]
+        return desc
+
+
+class OriginWbWhiteworld(_OriginOp):
+    kernel_cls, option = wb.WhiteBalance, 'whiteworld'
+
+    def _params(self, p, desc):
+        desc.update(white_point_ratio=p.cpu().numpy()[:, 0])
+        return desc
+
+
+class OriginNoiseBilateral(_OriginOp):
+    kernel_cls, option = snr.SpatialNoiseReduction, 'bilateral'
+
+    def _params(self, p, desc):
+        # .int() comes before *7 in the reference (:698), so the window is 3 for every p < 1
+        desc.update(window_length=(p[:, 0].int() * 7) * 2 + 3, sigma_color=p[:, 1] * 99 + 1,
+                    sigma_space=p[:, 2] * 99 + 1)
+        return desc
+
+
+class OriginNoiseMedian(_OriginOp):
+    kernel_cls, option = snr.SpatialNoiseReduction, 'median'
+
+    def _params(self, p, desc):
+        desc.update(size=2 * int(p.cpu().numpy()[0, 0] * 7) + 3)   # one size for the whole batch (:746)
+        return desc
+
+
+class OriginNoiseFastnlm(_OriginOp):
+    kernel_cls, option = snr.SpatialNoiseReduction, 'fastnlm'
+
+    def _params(self, p, desc):
+        desc.update(block_size=(p[:, 0].int() * 7) * 2 + 3, search_block=(p[:, 1].int() * 7) * 2 + 3,
+                    decay_factor=p[:, 2] * 99 + 1)
+        return desc

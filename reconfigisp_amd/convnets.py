@@ -1,0 +1,199 @@
+"""The four learned-proxy CNN families as sequences of fused MFMA convolution launches.
+
+One ``torch.autograd.Function`` per network: forward = the chain of ``risp_conv2d``
+launches (bias / ReLU / residual / space-to-depth / PixelShuffle / broadcast planes folded
+into each launch), backward = the transposed chain (backward-data only: the proxies'
+weights are frozen on the hot path - super_prune_fifteen_demos_four_bayer_two.py:50-52
+keeps them out of every optimizer).  References:
+  SRCNNRes       models/modules/srcnn_res_arch.py:26-53
+  SRCNNDemosaic  models/modules/srcnn_demosaic_arch.py:27-55
+  Path14lBayer   models/modules/path_14l_bayer_arch.py:59-88 (+ ResidualBlock :6-21)
+  Path14lBgr     models/modules/path_14l_bgr_arch.py:58-86
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .functional import _dev, _p, _stream, channel_stats
+
+LOAD_PLAIN, LOAD_UNSHUFFLE2, LOAD_CONSTCH = 0, 1, 2
+EPI_RELU, EPI_ADD, EPI_MASK, EPI_SHUFFLE2, EPI_NOBIAS = 1, 2, 4, 8, 16
+
+
+class PackedConv:
+    """Device-side packed weights of one layer, forward and backward-data."""
+
+    def __init__(self, weight, bias):
+        w = _dev(weight.detach(), 'weight')
+        self.cout, self.cin, self.k = w.shape[0], w.shape[1], w.shape[2]
+        self.bias = _dev(bias.detach(), 'bias')
+        lib = L.load()
+        self.fwd = torch.empty(lib.risp_conv_wpack_floats(self.cin, self.cout, self.k), device=w.device)
+        self.bwd = torch.empty(lib.risp_conv_wpack_floats(self.cout, self.cin, self.k), device=w.device)
+        L.call('risp_conv_pack_weights', _p(w), self.cin, self.cout, self.k, 0, _p(self.fwd), _stream())
+        L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
+
+
+def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None, epi=0, add=None, add_c=0,
+         mask=None, out=None):
+    """One fused convolution launch at resolution (h,w); returns the output tensor."""
+    cin, cout = (pc.cout, pc.cin) if transpose else (pc.cin, pc.cout)
+    if transpose:
+        epi |= EPI_NOBIAS
+    if out is None:
+        shape = (n, cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, cout, h, w)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
+                   epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(pc.bwd if transpose else pc.fwd),
+                   bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
+    L.call('risp_conv2d', C.byref(d), _stream())
+    return out
+
+
+class PackCache:
+    """Re-pack a module's conv weights only when a parameter changed (version counter / storage)."""
+
+    def __init__(self):
+        self._key, self._packs = None, None
+
+    def get(self, module, build):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
+        if key != self._key:
+            self._packs, self._key = build(), key
+        return self._packs
+
+
+# --------------------------------------------------------------------------- Path-Restore (14 layers)
+class _Path14l(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, packs, bayer):
+        x = _dev(x, 'img')
+        n = x.shape[0]
+        h, w = (x.shape[2] // 2, x.shape[3] // 2) if bayer else (x.shape[2], x.shape[3])
+        first, blocks, last = packs
+        r = conv(x, first, n, h, w, load=LOAD_UNSHUFFLE2 if bayer else LOAD_PLAIN, epi=EPI_RELU)
+        saved = [r]
+        for c1, c2 in blocks:
+            u = conv(r, c1, n, h, w, epi=EPI_RELU)
+            r = conv(u, c2, n, h, w, epi=EPI_ADD | EPI_RELU, add=r, add_c=64)
+            saved += [u, r]
+        y = conv(r, last, n, h, w, epi=EPI_SHUFFLE2 if bayer else 0)
+        ctx.save_for_backward(*saved)
+        ctx.packs, ctx.bayer, ctx.dims = packs, bayer, (n, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        first, blocks, last = ctx.packs
+        n, h, w = ctx.dims
+        gy = _dev(gy, 'grad')
+        # gradient at the pre-activation of the last ReLU output r6
+        g = conv(gy, last, n, h, w, transpose=True, load=LOAD_UNSHUFFLE2 if ctx.bayer else LOAD_PLAIN,
+                 epi=EPI_MASK, mask=saved[-1])
+        for k in range(len(blocks) - 1, -1, -1):
+            c1, c2 = blocks[k]
+            u, r_in = saved[1 + 2 * k], saved[2 * k]
+            gu = conv(g, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=u)
+            g = conv(gu, c1, n, h, w, transpose=True, epi=EPI_ADD | EPI_MASK, add=g, add_c=64, mask=r_in)
+        gx = conv(g, first, n, h, w, transpose=True, epi=EPI_SHUFFLE2 if ctx.bayer else 0)
+        return gx, None, None
+
+
+def build_path14l_packs(seq, flip_bgr):
+    """seq = module.path_restore_14l (conv_first, Sequential(6 blocks), ReLU, conv_last[, PixelShuffle])."""
+    first_w, first_b = seq[0].weight, seq[0].bias
+    last_w, last_b = seq[3].weight, seq[3].bias
+    if flip_bgr:  # x[:, [2,1,0]] on the way in and out == permuted weights (path_14l_bgr_arch.py:59,84)
+        first_w = first_w.detach().flip(1)
+        last_w, last_b = last_w.detach().flip(0), last_b.detach().flip(0)
+    blocks = [(PackedConv(b.basic[1].weight, b.basic[1].bias), PackedConv(b.basic[3].weight, b.basic[3].bias))
+              for b in seq[1]]
+    return PackedConv(first_w, first_b), blocks, PackedConv(last_w, last_b)
+
+
+def path14l(x, packs, bayer):
+    return _Path14l.apply(x, packs, bayer)
+
+
+# --------------------------------------------------------------------------- SRCNN (residual proxy)
+class _SrcnnRes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pv, packs):
+        x = _dev(x, 'img')
+        n, _, h, w = x.shape
+        c1, c2, c3 = packs
+        P = c1.cin - 12
+        pv = _dev(pv, 'params') if P else None
+        if P and (pv.dim() != 2 or pv.shape[0] != n or pv.shape[1] != P):
+            raise ValueError('SRCNNRes: param_vec must be (N=%d,%d), got %s' % (n, P, tuple(pv.shape)))
+        stats, arg = channel_stats(x)
+        cvals = torch.empty((n, 9 + P), device=x.device, dtype=torch.float32)
+        L.call('risp_srcnn_cvals', _p(stats), _p(pv), _p(cvals), n, P, h * w, _stream())
+        t1 = conv(x, c1, n, h, w, load=LOAD_CONSTCH, cin_img=3, cvals=cvals, epi=EPI_RELU)
+        t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
+        y = conv(t2, c3, n, h, w, epi=EPI_ADD, add=x, add_c=3)
+        ctx.save_for_backward(t1, t2, arg)
+        ctx.packs, ctx.dims = packs, (n, h, w, P)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t1, t2, arg = ctx.saved_tensors
+        c1, c2, c3 = ctx.packs
+        n, h, w, P = ctx.dims
+        gy = _dev(gy, 'grad')
+        g2 = conv(gy, c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2)
+        g1 = conv(g2, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1)
+        gf = conv(g1, c1, n, h, w, transpose=True, epi=EPI_ADD, add=gy, add_c=3)      # (N,12+P,H,W)
+        sums = []
+        for c0, nc in ((3, 3), (6, 3), (9, 3), (12, P)):
+            if nc == 0:
+                sums.append(None)
+                continue
+            s = torch.empty((n, nc), device=gy.device, dtype=torch.float32)
+            L.call('risp_plane_sums', _p(gf), _p(s), n, 12 + P, c0, nc, h * w, _stream())
+            sums.append(s)
+        gx = gf[:, :3].contiguous()
+        L.call('risp_stats_bwd', _p(gx), _p(sums[0]), _p(sums[1]), _p(sums[2]), _p(arg), n * 3, h * w, _stream())
+        return gx, sums[3], None
+
+
+def srcnn_res(x, pv, packs):
+    return _SrcnnRes.apply(x, pv, packs)
+
+
+# --------------------------------------------------------------------------- SRCNN demosaic proxy
+class _SrcnnDemosaic(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, packs):
+        x = _dev(x, 'img')
+        n, h, w = x.shape[0], x.shape[2] // 2, x.shape[3] // 2
+        c1, c2, c3 = packs
+        t1 = conv(x, c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU)
+        t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
+        y = conv(t2, c3, n, h, w, epi=EPI_SHUFFLE2)
+        ctx.save_for_backward(t1, t2)
+        ctx.packs, ctx.dims = packs, (n, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t1, t2 = ctx.saved_tensors
+        c1, c2, c3 = ctx.packs
+        n, h, w = ctx.dims
+        gy = _dev(gy, 'grad')
+        g2 = conv(gy, c3, n, h, w, transpose=True, load=LOAD_UNSHUFFLE2, epi=EPI_MASK, mask=t2)
+        g1 = conv(g2, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1)
+        gx = conv(g1, c1, n, h, w, transpose=True, epi=EPI_SHUFFLE2)
+        return gx, None
+
+
+def srcnn_demosaic(x, packs):
+    return _SrcnnDemosaic.apply(x, packs)
+
+
+def build_srcnn_packs(seq):
+    """seq = module.srcnn (conv, ReLU, conv, ReLU, conv[, PixelShuffle])."""
+    return tuple(PackedConv(seq[i].weight, seq[i].bias) for i in (0, 2, 4))

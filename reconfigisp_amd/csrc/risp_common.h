@@ -1,0 +1,64 @@
+// Shared helpers for the libreconfigisp_hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "risp.h"
+
+#define RISP_WAVE 64
+
+void risp_set_error(const char *fmt, ...);
+
+#define RISP_CHECK_ARG(cond, ...)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            risp_set_error(__VA_ARGS__);     \
+            return 1;                        \
+        }                                    \
+    } while (0)
+
+#define RISP_LAUNCH_CHECK(name)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            risp_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+// NaN-preserving clamp to [0,1] (torch.clamp semantics).
+__device__ __forceinline__ float clamp01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+// gradient gate of torch.clamp(v,0,1): passes where 0 <= v <= 1
+__device__ __forceinline__ float gate01(float v) { return (v >= 0.f && v <= 1.f) ? 1.f : 0.f; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Block-wide sum of NV per-thread partials; thread 0 of the block receives the totals in v[].
+// lds must hold NV * (blockDim.x/64) floats.  Contains barriers: call from all threads.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = wave_sum(v[i]);
+        if (lane == 0) lds[i * nw + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += lds[i * nw + w];
+            v[i] = s;
+        }
+    }
+    __syncthreads();
+}
+
+struct f3 {
+    float b, g, r;
+};

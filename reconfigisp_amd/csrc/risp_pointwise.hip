@@ -1,0 +1,496 @@
+// Element-wise ISP operators and the fused element-wise pipeline segment (gfx950).
+//
+// All of these are HBM-bound: every thread moves 16-byte vectors (float4) of planar
+// NCHW data, consecutive lanes touch consecutive 16-byte slots (1 KiB per wave
+// instruction), per-image parameters are wave-uniform (scalar loads), and parameter
+// gradients are reduced wave -> LDS -> one atomic per block.
+//
+// Reference arithmetic (codes/models/modules/tools_origin.py): WbQuadratic :317-359,
+// GtmManual :414-440; plugin-backed ops follow the build-defined OPSPEC restated in
+// oracle/isp_oracle.py (gamma_manual, wb_manual, demosaic_nearest).
+#include "risp_common.h"
+
+namespace {
+
+constexpr float kToe = 1.0f / 1024.0f;      // OPSPEC gamma toe (10 bits)
+constexpr float kLog2Toe = -10.0f;          // log2(kToe)
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ---------------------------------------------------------------- per-image op contexts
+struct WbManualCtx {
+    static constexpr int NP = 3;
+    float k[3];
+    __device__ WbManualCtx(const float *p, int n) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) k[c] = p[n * 3 + c] * 5.f;
+    }
+    __device__ f3 fwd(f3 v) const { return {v.b * k[0], v.g * k[1], v.r * k[2]}; }
+    __device__ f3 bwd(f3 x, f3 g, float *acc) const {
+        acc[0] += g.b * x.b;
+        acc[1] += g.g * x.g;
+        acc[2] += g.r * x.r;
+        return {g.b * k[0], g.g * k[1], g.r * k[2]};
+    }
+    __device__ static float pscale(int) { return 5.f; }
+    __device__ static int prow(int n) { return n; }
+};
+
+struct GammaCtx {
+    static constexpr int NP = 1;
+    float g, toe;  // toe = T^(g-1): slope of the linear segment below T
+    __device__ GammaCtx(const float *p, int n) {
+        g = p[n];
+        toe = __builtin_amdgcn_exp2f((g - 1.f) * kLog2Toe);
+    }
+    __device__ float f(float x) const {
+        return x >= kToe ? __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(x)) : x * toe;
+    }
+    __device__ f3 fwd(f3 v) const { return {f(v.b), f(v.g), f(v.r)}; }
+    __device__ float b1(float x, float gy, float *acc) const {
+        if (x >= kToe) {
+            float l2 = __builtin_amdgcn_logf(x);
+            float y = __builtin_amdgcn_exp2f(g * l2);
+            acc[0] += gy * y * (l2 * kLn2);
+            return gy * g * y / x;
+        }
+        acc[0] += gy * x * toe * (kLog2Toe * kLn2);
+        return gy * toe;
+    }
+    __device__ f3 bwd(f3 x, f3 gy, float *acc) const {
+        return {b1(x.b, gy.b, acc), b1(x.g, gy.g, acc), b1(x.r, gy.r, acc)};
+    }
+    __device__ static float pscale(int) { return 1.f; }
+    __device__ static int prow(int n) { return n; }
+};
+
+struct GtmCtx {  // 4 segments; knots from row 0 of p only (tools_origin.py:423)
+    static constexpr int NP = 3;
+    float ys[4], sl[4];
+    __device__ GtmCtx(const float *p, int) {
+        float k[5] = {0.f, p[0], p[1], p[2], 1.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            ys[s] = k[s];
+            sl[s] = (k[s + 1] - k[s]) / 0.25f;
+        }
+    }
+    __device__ float pre(float x, int &seg, float &slope) const {
+        // half-open segments [k/4,(k+1)/4); anything else (x<0, x>=1, NaN) passes through
+        seg = -1;
+        slope = 1.f;
+        float o = x;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float xs = 0.25f * s, xe = 0.25f * (s + 1);
+            if (x >= xs && x < xe) {
+                o = (x - xs) * sl[s] + ys[s];
+                seg = s;
+                slope = sl[s];
+            }
+        }
+        return o;
+    }
+    __device__ float f(float x) const {
+        int s;
+        float m;
+        return clamp01(pre(x, s, m));
+    }
+    __device__ f3 fwd(f3 v) const { return {f(v.b), f(v.g), f(v.r)}; }
+    __device__ float b1(float x, float gy, float *acc) const {
+        int s;
+        float m;
+        float o = pre(x, s, m);
+        float g = gy * gate01(o);
+        float t = (x - 0.25f * s) * 4.f;  // d out / d y_end ; (1-t) = d out / d y_start
+#pragma unroll
+        for (int j = 0; j < 3; ++j)     // knot j is the end of segment j and the start of segment j+1
+            acc[j] += (s == j ? g * t : 0.f) + (s == j + 1 ? g * (1.f - t) : 0.f);
+        return g * m;
+    }
+    __device__ f3 bwd(f3 x, f3 gy, float *acc) const {
+        return {b1(x.b, gy.b, acc), b1(x.g, gy.g, acc), b1(x.r, gy.r, acc)};
+    }
+    __device__ static float pscale(int) { return 1.f; }
+    __device__ static int prow(int) { return 0; }
+};
+
+struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR B G R 1
+    static constexpr int NP = 30;
+    float c[3][10];
+    __device__ WbqCtx(const float *p, int n) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) c[ch][j] = p[n * 30 + ch * 10 + j] * 10.f - 5.f;
+    }
+    __device__ float pre(const float *f, int ch) const {
+        float s = f[0] * c[ch][0];
+#pragma unroll
+        for (int j = 1; j < 10; ++j) s += f[j] * c[ch][j];
+        return s;
+    }
+    __device__ static void feats(f3 v, float *f) {
+        f[0] = v.b * v.b; f[1] = v.g * v.g; f[2] = v.r * v.r;
+        f[3] = v.b * v.g; f[4] = v.b * v.r; f[5] = v.g * v.r;
+        f[6] = v.b; f[7] = v.g; f[8] = v.r; f[9] = 1.f;
+    }
+    __device__ f3 fwd(f3 v) const {
+        float f[10];
+        feats(v, f);
+        return {clamp01(pre(f, 0)), clamp01(pre(f, 1)), clamp01(pre(f, 2))};
+    }
+    __device__ f3 bwd(f3 x, f3 gy, float *acc) const {
+        float f[10];
+        feats(x, f);
+        float g[3] = {gy.b * gate01(pre(f, 0)), gy.g * gate01(pre(f, 1)), gy.r * gate01(pre(f, 2))};
+        f3 o = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[ch * 10 + j] += g[ch] * f[j];
+            o.b += g[ch] * (2.f * x.b * c[ch][0] + x.g * c[ch][3] + x.r * c[ch][4] + c[ch][6]);
+            o.g += g[ch] * (2.f * x.g * c[ch][1] + x.b * c[ch][3] + x.r * c[ch][5] + c[ch][7]);
+            o.r += g[ch] * (2.f * x.r * c[ch][2] + x.b * c[ch][4] + x.g * c[ch][5] + c[ch][8]);
+        }
+        return o;
+    }
+    __device__ static float pscale(int) { return 10.f; }
+    __device__ static int prow(int n) { return n; }
+};
+
+struct Gain3Ctx {  // y_c = clamp(x_c * p[n,c]) : gray-world apply with precomputed gains
+    static constexpr int NP = 3;
+    float k[3];
+    __device__ Gain3Ctx(const float *p, int n) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) k[c] = p[n * 3 + c];
+    }
+    __device__ f3 fwd(f3 v) const { return {clamp01(v.b * k[0]), clamp01(v.g * k[1]), clamp01(v.r * k[2])}; }
+    __device__ f3 bwd(f3 x, f3 g, float *acc) const {
+        g.b *= gate01(x.b * k[0]);
+        g.g *= gate01(x.g * k[1]);
+        g.r *= gate01(x.r * k[2]);
+        acc[0] += g.b * x.b;
+        acc[1] += g.g * x.g;
+        acc[2] += g.r * x.r;
+        return {g.b * k[0], g.g * k[1], g.r * k[2]};
+    }
+    __device__ static float pscale(int) { return 1.f; }
+    __device__ static int prow(int n) { return n; }
+};
+
+// ---------------------------------------------------------------- planar BGR kernels
+// grid = (blocks per image, N); each thread walks float4 slots of one image.
+template <class Ctx>
+__global__ __launch_bounds__(256) void bgr_fwd_kernel(const float *__restrict__ x, const float *__restrict__ p,
+                                                      float *__restrict__ y, int hw4) {
+    const int n = blockIdx.y;
+    const Ctx ctx(p, n);
+    const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)n * 3 * hw4;
+    float4 *yb = reinterpret_cast<float4 *>(y) + (size_t)n * 3 * hw4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
+        float4 b = xb[i], g = xb[hw4 + i], r = xb[2 * hw4 + i];
+        f3 o0 = ctx.fwd({b.x, g.x, r.x}), o1 = ctx.fwd({b.y, g.y, r.y});
+        f3 o2 = ctx.fwd({b.z, g.z, r.z}), o3 = ctx.fwd({b.w, g.w, r.w});
+        yb[i] = make_float4(o0.b, o1.b, o2.b, o3.b);
+        yb[hw4 + i] = make_float4(o0.g, o1.g, o2.g, o3.g);
+        yb[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
+    }
+}
+
+template <class Ctx>
+__global__ __launch_bounds__(256) void bgr_bwd_kernel(const float *__restrict__ x, const float *__restrict__ p,
+                                                      const float *__restrict__ gy, float *__restrict__ gx,
+                                                      float *__restrict__ gp, int hw4) {
+    __shared__ float red[Ctx::NP * 4];
+    const int n = blockIdx.y;
+    const Ctx ctx(p, n);
+    const size_t base = (size_t)n * 3 * hw4;
+    const float4 *xb = reinterpret_cast<const float4 *>(x) + base;
+    const float4 *gb = reinterpret_cast<const float4 *>(gy) + base;
+    float4 *ob = reinterpret_cast<float4 *>(gx) + base;
+    float acc[Ctx::NP];
+#pragma unroll
+    for (int j = 0; j < Ctx::NP; ++j) acc[j] = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
+        float4 b = xb[i], g = xb[hw4 + i], r = xb[2 * hw4 + i];
+        float4 db = gb[i], dg = gb[hw4 + i], dr = gb[2 * hw4 + i];
+        f3 o0 = ctx.bwd({b.x, g.x, r.x}, {db.x, dg.x, dr.x}, acc);
+        f3 o1 = ctx.bwd({b.y, g.y, r.y}, {db.y, dg.y, dr.y}, acc);
+        f3 o2 = ctx.bwd({b.z, g.z, r.z}, {db.z, dg.z, dr.z}, acc);
+        f3 o3 = ctx.bwd({b.w, g.w, r.w}, {db.w, dg.w, dr.w}, acc);
+        ob[i] = make_float4(o0.b, o1.b, o2.b, o3.b);
+        ob[hw4 + i] = make_float4(o0.g, o1.g, o2.g, o3.g);
+        ob[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
+    }
+    block_sum<Ctx::NP>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < Ctx::NP; ++j) atomicAdd(&gp[Ctx::prow(n) * Ctx::NP + j], acc[j] * Ctx::pscale(j));
+    }
+}
+
+template <class Ctx>
+int launch_fwd(const char *name, const float *x, const float *p, float *y, int N, int HW, void *stream) {
+    RISP_CHECK_ARG(x && p && y && N > 0 && HW > 0 && HW % 4 == 0, "%s: bad arguments (HW must be a multiple of 4)", name);
+    const int hw4 = HW / 4;
+    int bx = (hw4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(bgr_fwd_kernel<Ctx>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, p, y, hw4);
+    RISP_LAUNCH_CHECK(name);
+    return 0;
+}
+
+template <class Ctx>
+int launch_bwd(const char *name, const float *x, const float *p, const float *gy, float *gx, float *gp, int N,
+               int HW, void *stream) {
+    RISP_CHECK_ARG(x && p && gy && gx && gp && N > 0 && HW > 0 && HW % 4 == 0, "%s: bad arguments", name);
+    const int hw4 = HW / 4;
+    int bx = (hw4 + 1023) / 1024;  // >= 4 vectors per thread so the reduction amortises
+    if (bx < 1) bx = 1;
+    if (bx > 32) bx = 32;
+    if (hipMemsetAsync(gp, 0, sizeof(float) * N * Ctx::NP, (hipStream_t)stream) != hipSuccess) {
+        risp_set_error("%s: memset failed", name);
+        return 2;
+    }
+    hipLaunchKernelGGL(bgr_bwd_kernel<Ctx>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, p, gy, gx, gp, hw4);
+    RISP_LAUNCH_CHECK(name);
+    return 0;
+}
+
+// ---------------------------------------------------------------- nearest-neighbour demosaic
+// One thread = QW horizontally adjacent 2x2 quads (QW=2: float4 rows).
+template <int QW>
+struct RowVec;
+template <>
+struct RowVec<2> { using T = float4; };
+template <>
+struct RowVec<1> { using T = float2; };
+
+template <int QW>
+__device__ __forceinline__ void load_row(const float *p, float *v) {
+    typename RowVec<QW>::T t = *reinterpret_cast<const typename RowVec<QW>::T *>(p);
+    const float *s = reinterpret_cast<const float *>(&t);
+#pragma unroll
+    for (int i = 0; i < 2 * QW; ++i) v[i] = s[i];
+}
+template <int QW>
+__device__ __forceinline__ void store_row(float *p, const float *v) {
+    typename RowVec<QW>::T t;
+    float *s = reinterpret_cast<float *>(&t);
+#pragma unroll
+    for (int i = 0; i < 2 * QW; ++i) s[i] = v[i];
+    *reinterpret_cast<typename RowVec<QW>::T *>(p) = t;
+}
+
+// Bayer rows r0 (R G1 R G1 ..), r1 (G2 B G2 B ..) -> BGR pixels px[row][col]
+template <int QW>
+__device__ __forceinline__ void demosaic_quads(const float *r0, const float *r1, f3 (*px)[2 * QW]) {
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+        float R = r0[2 * q], G1 = r0[2 * q + 1], G2 = r1[2 * q], B = r1[2 * q + 1];
+        px[0][2 * q] = px[0][2 * q + 1] = {B, G1, R};
+        px[1][2 * q] = px[1][2 * q + 1] = {B, G2, R};
+    }
+}
+
+template <int QW>
+__global__ __launch_bounds__(256) void demosaic_nearest_bwd_kernel(const float *__restrict__ g, float *__restrict__ gb,
+                                                                   int H, int W) {
+    const int n = blockIdx.y, wq = W / (2 * QW), hq = H / 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= wq * hq) return;
+    const int qy = t / wq, qx = t - qy * wq;
+    const size_t plane = (size_t)H * W;
+    const size_t off = (size_t)(2 * qy) * W + (size_t)qx * 2 * QW;
+    float v[3][2][2 * QW];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) load_row<QW>(g + ((size_t)n * 3 + c) * plane + off + (size_t)r * W, v[c][r]);
+    float o0[2 * QW], o1[2 * QW];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+        const int a = 2 * q, b = 2 * q + 1;
+        o0[a] = (v[2][0][a] + v[2][0][b]) + (v[2][1][a] + v[2][1][b]);  // R <- all four red grads
+        o0[b] = v[1][0][a] + v[1][0][b];                                // G1 <- even-row greens
+        o1[a] = v[1][1][a] + v[1][1][b];                                // G2 <- odd-row greens
+        o1[b] = (v[0][0][a] + v[0][0][b]) + (v[0][1][a] + v[0][1][b]);  // B
+    }
+    store_row<QW>(gb + (size_t)n * plane + off, o0);
+    store_row<QW>(gb + (size_t)n * plane + off + W, o1);
+}
+
+// ---------------------------------------------------------------- fused element-wise chain
+struct ChainArgs {
+    const float *in;
+    int n_ops, N, H, W;
+    int ops[RISP_MAX_CHAIN];
+    const float *params[RISP_MAX_CHAIN];
+    float *outs[RISP_MAX_CHAIN];
+};
+
+template <class Ctx, int NPX>
+__device__ __forceinline__ void apply_all(const float *p, int n, f3 *px) {
+    const Ctx ctx(p, n);
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) px[i] = ctx.fwd(px[i]);
+}
+
+template <int QW>
+__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
+    const int n = blockIdx.y, W = a.W, H = a.H, wq = W / (2 * QW);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= wq * (H / 2)) return;
+    const int qy = t / wq, qx = t - qy * wq;
+    const size_t plane = (size_t)H * W;
+    const size_t off = (size_t)(2 * qy) * W + (size_t)qx * 2 * QW;
+    f3 px[2][2 * QW];
+    int k0 = 0;
+    if (a.ops[0] == RISP_OP_DEMOSAIC_NEAREST) {
+        float r0[2 * QW], r1[2 * QW];
+        load_row<QW>(a.in + (size_t)n * plane + off, r0);
+        load_row<QW>(a.in + (size_t)n * plane + off + W, r1);
+        demosaic_quads<QW>(r0, r1, px);
+    } else {
+        float v[3][2][2 * QW];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) load_row<QW>(a.in + ((size_t)n * 3 + c) * plane + off + (size_t)r * W, v[c][r]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 2 * QW; ++i) px[r][i] = {v[0][r][i], v[1][r][i], v[2][r][i]};
+    }
+    for (int k = k0; k < a.n_ops; ++k) {
+        const int op = a.ops[k];
+        const float *p = a.params[k];
+        f3 *flat = &px[0][0];
+        switch (op) {
+            case RISP_OP_WB_MANUAL: apply_all<WbManualCtx, 4 * QW>(p, n, flat); break;
+            case RISP_OP_GAMMA: apply_all<GammaCtx, 4 * QW>(p, n, flat); break;
+            case RISP_OP_GTM_MANUAL: apply_all<GtmCtx, 4 * QW>(p, n, flat); break;
+            case RISP_OP_WB_QUADRATIC: apply_all<WbqCtx, 4 * QW>(p, n, flat); break;
+            case RISP_OP_GAIN3: apply_all<Gain3Ctx, 4 * QW>(p, n, flat); break;
+            default: break;  // SKIP, DEMOSAIC_NEAREST (already applied)
+        }
+        float *o = a.outs[k];
+        if (o == nullptr) continue;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float vb[2 * QW], vg[2 * QW], vr[2 * QW];
+#pragma unroll
+            for (int i = 0; i < 2 * QW; ++i) {
+                vb[i] = px[r][i].b;
+                vg[i] = px[r][i].g;
+                vr[i] = px[r][i].r;
+            }
+            store_row<QW>(o + ((size_t)n * 3 + 0) * plane + off + (size_t)r * W, vb);
+            store_row<QW>(o + ((size_t)n * 3 + 1) * plane + off + (size_t)r * W, vg);
+            store_row<QW>(o + ((size_t)n * 3 + 2) * plane + off + (size_t)r * W, vr);
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C ABI
+extern "C" {
+
+int risp_wb_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
+    return launch_fwd<WbManualCtx>("risp_wb_manual_fwd", x, p, y, N, HW, s);
+}
+int risp_wb_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
+    return launch_bwd<WbManualCtx>("risp_wb_manual_bwd", x, p, gy, gx, gp, N, HW, s);
+}
+int risp_gamma_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
+    return launch_fwd<GammaCtx>("risp_gamma_fwd", x, p, y, N, HW, s);
+}
+int risp_gamma_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
+    return launch_bwd<GammaCtx>("risp_gamma_bwd", x, p, gy, gx, gp, N, HW, s);
+}
+int risp_gtm_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
+    return launch_fwd<GtmCtx>("risp_gtm_manual_fwd", x, p, y, N, HW, s);
+}
+int risp_gtm_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
+    return launch_bwd<GtmCtx>("risp_gtm_manual_bwd", x, p, gy, gx, gp, N, HW, s);
+}
+int risp_wb_quadratic_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
+    return launch_fwd<WbqCtx>("risp_wb_quadratic_fwd", x, p, y, N, HW, s);
+}
+int risp_wb_quadratic_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
+    return launch_bwd<WbqCtx>("risp_wb_quadratic_bwd", x, p, gy, gx, gp, N, HW, s);
+}
+
+int risp_gain3_fwd(const float *x, const float *k, float *y, int N, int HW, void *s) {
+    return launch_fwd<Gain3Ctx>("risp_gain3_fwd", x, k, y, N, HW, s);
+}
+int risp_gain3_bwd(const float *x, const float *k, const float *gy, float *gx, float *gk, int N, int HW, void *s) {
+    return launch_bwd<Gain3Ctx>("risp_gain3_bwd", x, k, gy, gx, gk, N, HW, s);
+}
+
+static int chain_launch(const ChainArgs &a, void *stream) {
+    const bool wide = (a.W % 4 == 0);
+    const int nq = (a.W / (wide ? 4 : 2)) * (a.H / 2);
+    dim3 grid((nq + 255) / 256, a.N), block(256);
+    if (wide)
+        hipLaunchKernelGGL(chain_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(chain_kernel<1>, grid, block, 0, (hipStream_t)stream, a);
+    RISP_LAUNCH_CHECK("risp_chain_fwd");
+    return 0;
+}
+
+int risp_chain_fwd(const float *in, int n_ops, const int *ops, const float *const *params, float *const *outs, int N,
+                   int H, int W, void *stream) {
+    RISP_CHECK_ARG(in && ops && params && outs, "risp_chain_fwd: null argument");
+    RISP_CHECK_ARG(n_ops >= 1 && n_ops <= RISP_MAX_CHAIN, "risp_chain_fwd: n_ops %d out of range", n_ops);
+    RISP_CHECK_ARG(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && N <= 65535,
+                   "risp_chain_fwd: bad shape N=%d H=%d W=%d (H, W must be even)", N, H, W);
+    ChainArgs a;
+    a.in = in;
+    a.n_ops = n_ops;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    for (int k = 0; k < RISP_MAX_CHAIN; ++k) {
+        a.ops[k] = RISP_OP_SKIP;
+        a.params[k] = nullptr;
+        a.outs[k] = nullptr;
+    }
+    for (int k = 0; k < n_ops; ++k) {
+        const int op = ops[k];
+        RISP_CHECK_ARG(op >= RISP_OP_SKIP && op <= RISP_OP_GAIN3, "risp_chain_fwd: unknown op %d", op);
+        RISP_CHECK_ARG(op != RISP_OP_DEMOSAIC_NEAREST || k == 0, "risp_chain_fwd: demosaic must be the first op");
+        const bool needs_p = op >= RISP_OP_WB_MANUAL;
+        RISP_CHECK_ARG(!needs_p || params[k], "risp_chain_fwd: op %d at stage %d needs params", op, k);
+        RISP_CHECK_ARG(op == RISP_OP_SKIP || outs[k], "risp_chain_fwd: stage %d needs an output buffer", k);
+        a.ops[k] = op;
+        a.params[k] = params[k];
+        a.outs[k] = (op == RISP_OP_SKIP) ? nullptr : outs[k];
+    }
+    return chain_launch(a, stream);
+}
+
+int risp_demosaic_nearest_fwd(const float *bayer, float *bgr, int N, int H, int W, void *stream) {
+    const int op = RISP_OP_DEMOSAIC_NEAREST;
+    const float *p = nullptr;
+    return risp_chain_fwd(bayer, 1, &op, &p, &bgr, N, H, W, stream);
+}
+
+int risp_demosaic_nearest_bwd(const float *g_bgr, float *g_bayer, int N, int H, int W, void *stream) {
+    RISP_CHECK_ARG(g_bgr && g_bayer && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && N <= 65535,
+                   "risp_demosaic_nearest_bwd: bad arguments");
+    const bool wide = (W % 4 == 0);
+    const int nq = (W / (wide ? 4 : 2)) * (H / 2);
+    dim3 grid((nq + 255) / 256, N), block(256);
+    if (wide)
+        hipLaunchKernelGGL(demosaic_nearest_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g_bgr, g_bayer, H, W);
+    else
+        hipLaunchKernelGGL(demosaic_nearest_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, g_bgr, g_bayer, H, W);
+    RISP_LAUNCH_CHECK("risp_demosaic_nearest_bwd");
+    return 0;
+}
+
+}  // extern "C"

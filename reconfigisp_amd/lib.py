@@ -1,0 +1,96 @@
+"""ctypes binding of ``libreconfigisp_hip.so`` (C ABI declared in ``include/risp.h``).
+
+There is no CPU or PyTorch fallback behind this module: if the shared library is
+missing or fails to load, importing an operator raises ``RuntimeError`` telling the
+user to build it (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C reconfigisp_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libreconfigisp_hip.so')
+
+_f = C.c_void_p        # device float*
+_i = C.c_int
+_z = C.c_size_t
+_s = C.c_void_p        # hipStream_t
+_pp = C.POINTER(C.c_void_p)
+
+
+class ConvDesc(C.Structure):
+    """mirror of risp_conv_desc"""
+    _fields_ = [('N', _i), ('H', _i), ('W', _i), ('cin', _i), ('cout', _i), ('ksize', _i),
+                ('load_mode', _i), ('cin_img', _i), ('epilogue', _i), ('add_c', _i),
+                ('x', _f), ('wpack', _f), ('bias', _f), ('cvals', _f), ('add', _f), ('mask', _f),
+                ('y', _f)]
+
+
+def _pw(n_extra=0):
+    return [_f] * (3 + n_extra) + [_i, _i, _s]
+
+
+# name -> (restype, argtypes); every symbol include/risp.h declares
+SIGNATURES = {
+    'risp_version': (_i, []),
+    'risp_last_error': (C.c_char_p, []),
+    'risp_demosaic_nearest_fwd': (_i, [_f, _f, _i, _i, _i, _s]),
+    'risp_demosaic_nearest_bwd': (_i, [_f, _f, _i, _i, _i, _s]),
+    'risp_wb_manual_fwd': (_i, _pw()), 'risp_wb_manual_bwd': (_i, _pw(2)),
+    'risp_gamma_fwd': (_i, _pw()), 'risp_gamma_bwd': (_i, _pw(2)),
+    'risp_gtm_manual_fwd': (_i, _pw()), 'risp_gtm_manual_bwd': (_i, _pw(2)),
+    'risp_wb_quadratic_fwd': (_i, _pw()), 'risp_wb_quadratic_bwd': (_i, _pw(2)),
+    'risp_gain3_fwd': (_i, _pw()), 'risp_gain3_bwd': (_i, _pw(2)),
+    'risp_channel_stats_scratch_floats': (_z, [_i, _i]),
+    'risp_channel_stats': (_i, [_f, _f, _f, _f, _i, _i, _s]),
+    'risp_stats_bwd': (_i, [_f, _f, _f, _f, _f, _i, _i, _s]),
+    'risp_histc': (_i, [_f, _f, _i, _i, _i, _s]),
+    'risp_srcnn_cvals': (_i, [_f, _f, _f, _i, _i, _i, _s]),
+    'risp_grayworld_gains_fwd': (_i, [_f, _f, _i, _i, _s]),
+    'risp_grayworld_gains_bwd': (_i, [_f, _f, _f, _i, _i, _s]),
+    'risp_chain_fwd': (_i, [_f, _i, C.POINTER(_i), _pp, _pp, _i, _i, _i, _s]),
+    'risp_mix_fwd': (_i, [_pp, C.POINTER(C.c_float), _i, _f, _z, _s]),
+    'risp_mix_bwd': (_i, [_pp, C.POINTER(C.c_float), _i, _f, _pp, _f, _z, _s]),
+    'risp_conv_wpack_floats': (_z, [_i, _i, _i]),
+    'risp_conv_pack_weights': (_i, [_f, _i, _i, _i, _i, _f, _s]),
+    'risp_conv2d': (_i, [C.POINTER(ConvDesc), _s]),
+    'risp_plane_sums': (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
+    'risp_tile_gather': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
+    'risp_tile_blend': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
+    'risp_sse_uint8': (_i, [_f, _f, _f, _z, _s]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'reconfigisp_amd: %s is missing - the HIP extension has not been built. There is no '
+            'CPU fallback. Build it with `make -C reconfigisp_amd/csrc` (needs hipcc, gfx950).' % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. no HIP runtime on this machine
+        raise RuntimeError('reconfigisp_amd: cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI and this table diverge
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError with risp_last_error() on failure."""
+    lib = load()
+    status = getattr(lib, name)(*args)
+    if status != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, status, lib.risp_last_error().decode()))
+
+
+def ptr_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*[C.c_void_p(p) if p else None for p in ptrs])

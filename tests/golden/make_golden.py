@@ -315,13 +315,13 @@ def gold_darts():
         model.feed_data((img, gt, vimg, vgt))
         model.update_learning_rate(it, warmup_iter=-1)
         model.optimize_alphas()
-        out['it%d_val_loss' % it] = model.val_loss
+        out['it%d_val_loss' % it] = model.val_loss.detach().clone()
         for k, a in enumerate(model.netG.alphas):
-            out['it%d_alpha_grad%d' % (it, k)] = a.grad
+            out['it%d_alpha_grad%d' % (it, k)] = a.grad.clone()  # backward() later accumulates in place
         model.optimize_parameters()
         out['it%d_loss' % it] = np.array(model.log_dict['loss'], np.float32)
         for k, v in model.netG.state_dict().items():
-            out['it%d_%s' % (it, k)] = v
+            out['it%d_%s' % (it, k)] = v.detach().clone()
     npz('darts_step', **out)
 
 

@@ -1,0 +1,37 @@
+"""TEST-ONLY operator backend: binds the functional seam (reconfigisp_amd.functional._IMPL) to the
+CPU oracle so that the HOST logic of the product (registry, fixed pipelines, super-net, DARTS
+step, gloo multi-process path) can be exercised on a machine without a GPU.  The product never
+imports this file; `-m gpu` tests never use it."""
+import torch
+
+import isp_oracle as O
+
+
+def _sd(module):
+    return {k: v.detach() for k, v in module.state_dict().items()}
+
+
+class OracleImpl:
+    skip = staticmethod(lambda x, p=None: x)
+    wb_manual = staticmethod(O.wb_manual)
+    gamma = staticmethod(O.gamma_manual)
+    gtm_manual = staticmethod(O.gtm_manual)
+    wb_quadratic = staticmethod(O.wb_quadratic)
+    grayworld = staticmethod(lambda x, p=None: O.grayworld(x))
+    demosaic_nearest = staticmethod(lambda x, p=None: O.demosaic_nearest(x))
+
+    @staticmethod
+    def mix(w, outs):
+        y = 0
+        for wk, o in zip(w, outs):
+            y = y + o * wk
+        return y
+
+    @staticmethod
+    def histc01(x, bins):
+        return torch.stack([torch.cat([torch.histc(ch.detach(), bins=bins, min=0, max=1) for ch in im]) for im in x])
+
+    srcnn_res = staticmethod(lambda x, pv, m: O.srcnn_res(x, pv, _sd(m)))
+    srcnn_demosaic = staticmethod(lambda x, m: O.srcnn_demosaic(x, _sd(m)))
+    path14l_bayer = staticmethod(lambda x, m: O.path14l_bayer(x, _sd(m)))
+    path14l_bgr = staticmethod(lambda x, m: O.path14l_bgr(x, _sd(m)))

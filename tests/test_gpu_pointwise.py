@@ -1,0 +1,150 @@
+"""GPU parity: element-wise HIP kernels (through the C ABI) vs the CPU oracle and the
+golden vectors of the imported reference."""
+import numpy as np
+import pytest
+import torch
+
+import isp_oracle as O
+from conftest import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope='module')
+def F():
+    import reconfigisp_amd.functional as F
+    from reconfigisp_amd import lib
+    assert lib.load().risp_version() >= 100
+    return F
+
+
+def rnd(*shape, seed, lo=0.0, hi=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.random(shape) * (hi - lo) + lo).astype(np.float32))
+
+
+def _fwd_bwd(fn_gpu, fn_cpu, x, p, gy, what, rtol=1e-4):
+    xc, pc = x.clone().requires_grad_(True), (p.clone().requires_grad_(True) if p is not None else None)
+    yc = fn_cpu(xc, pc) if p is not None else fn_cpu(xc)
+    gc = torch.autograd.grad(yc, (xc, pc) if p is not None else (xc,), gy)
+    xg = x.cuda().requires_grad_(True)
+    pg = p.cuda().requires_grad_(True) if p is not None else None
+    yg = fn_gpu(xg, pg) if p is not None else fn_gpu(xg)
+    gg = torch.autograd.grad(yg, (xg, pg) if p is not None else (xg,), gy.cuda())
+    assert_close(yg, yc, rtol=rtol, what=what + ' y')
+    assert_close(gg[0], gc[0], rtol=rtol, what=what + ' gx')
+    if p is not None:
+        assert_close(gg[1], gc[1], rtol=rtol, what=what + ' gp')
+    return yg
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 16, 16), (3, 3, 34, 50), (1, 3, 256, 256)])
+def test_pointwise_vs_oracle(F, shape):
+    n = shape[0]
+    x = rnd(*shape, seed=1, lo=-0.15, hi=1.2)
+    gy = rnd(*shape, seed=2, lo=-0.5, hi=0.5)
+    _fwd_bwd(F.wb_manual, O.wb_manual, x, rnd(n, 3, seed=3), gy, 'wb_manual')
+    _fwd_bwd(F.gamma, O.gamma_manual, x, rnd(n, 1, seed=4, lo=0.2, hi=0.9), gy, 'gamma')
+    _fwd_bwd(F.gtm_manual, O.gtm_manual, x, rnd(n, 3, seed=5), gy, 'gtm')
+    _fwd_bwd(F.wb_quadratic, O.wb_quadratic, x, rnd(n, 30, seed=6, lo=0.4, hi=0.6), gy, 'wbq')
+    _fwd_bwd(F.grayworld, O.grayworld, rnd(*shape, seed=7), None, gy, 'grayworld')
+
+
+def test_wbq_gtm_vs_reference_golden(F):
+    g = load_golden('pointwise')
+    x, p = T(g['x']).cuda().requires_grad_(True), T(g['wbq_p']).cuda().requires_grad_(True)
+    y = F.wb_quadratic(x, p)
+    gx, gp = torch.autograd.grad(y, (x, p), T(g['gy']).cuda())
+    assert_close(y, g['wbq_y'], what='wbq y')
+    assert_close(gx, g['wbq_gx'], what='wbq gx')
+    assert_close(gp, g['wbq_gp'], what='wbq gp')
+    x, p = T(g['gtm_x']).cuda().requires_grad_(True), T(g['gtm_p']).cuda().requires_grad_(True)
+    y = F.gtm_manual(x, p)
+    gx, gp = torch.autograd.grad(y, (x, p), T(g['gy']).cuda())
+    assert_close(y, g['gtm_y'], what='gtm y')
+    assert_close(gx, g['gtm_gx'], what='gtm gx')
+    assert_close(gp, g['gtm_gp'], what='gtm gp')
+    # known answer of the reference's own smoke block (tools_origin.py:807-820)
+    k = F.gtm_manual(torch.full((1, 3, 64, 64), 0.9).cuda(), torch.tensor([[0.3, 0.5, 0.7]]).cuda())
+    assert abs(k.min().item() - 0.88) < 1e-6 and abs(k.max().item() - 0.88) < 1e-6
+
+
+@pytest.mark.parametrize('hw', [(6, 8), (10, 6), (256, 256)])
+def test_demosaic_nearest_bit_exact(F, hw):
+    h, w = hw
+    x = torch.arange(2 * h * w, dtype=torch.float32).view(2, 1, h, w)
+    y = F.demosaic_nearest(x.cuda())
+    assert torch.equal(y.cpu(), O.demosaic_nearest(x))                 # index map: bit exact
+    xr = rnd(2, 1, h, w, seed=9).requires_grad_(True)
+    gy = rnd(2, 3, h, w, seed=10)
+    gc, = torch.autograd.grad(O.demosaic_nearest(xr), xr, gy)
+    xg = xr.detach().cuda().requires_grad_(True)
+    gg, = torch.autograd.grad(F.demosaic_nearest(xg), xg, gy.cuda())
+    assert_close(gg, gc, what='demosaic gx')
+
+
+def test_gtm_segment_boundaries_and_passthrough(F):
+    x = torch.tensor([-0.5, 0.0, 0.25, 0.5, 0.75, 1.0, 1.5, 0.2499999, 0.9999999] + [0.3] * 3).view(1, 3, 2, 2)
+    p = torch.tensor([[0.1, 0.6, 0.7]])
+    assert torch.equal(F.gtm_manual(x.cuda(), p.cuda()).cpu(), O.gtm_manual(x, p))
+
+
+def test_chain_matches_per_op_and_oracle(F):
+    n, h, w = 3, 32, 48
+    bay = rnd(n, 1, h, w, seed=11)
+    sig = lambda v: torch.sigmoid(torch.tensor(v)).repeat(n, 1)
+    pw, pg, pt = sig(O.PARAM_INIT['wbmanual']), torch.full((n, 1), 0.45), rnd(1, 3, seed=12).repeat(n, 1)
+    pq = rnd(n, 30, seed=13, lo=0.45, hi=0.55)
+    ops = [F.OP_SKIP, F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL, F.OP_WB_QUADRATIC]
+    # SKIP before the demosaic is resolved by the host; the chain itself starts at the demosaic
+    outs = F.chain_forward(bay.cuda(), ops[1:], [None, pw.cuda(), pg.cuda(), pt.cuda(), pq.cuda()])
+    ref = O.demosaic_nearest(bay)
+    assert torch.equal(outs[0].cpu(), ref)
+    for o, fn, p in zip(outs[1:], (O.wb_manual, O.gamma_manual, O.gtm_manual, O.wb_quadratic), (pw, pg, pt, pq)):
+        ref = fn(ref, p)
+        assert_close(o, ref, what=fn.__name__)
+    # odd quad count per row (W % 4 == 2) takes the float2 path
+    bay2 = rnd(1, 1, 6, 10, seed=14)
+    o2 = F.chain_forward(bay2.cuda(), [F.OP_DEMOSAIC_NEAREST, F.OP_GAMMA], [None, torch.full((1, 1), 0.5).cuda()])
+    assert_close(o2[1], O.gamma_manual(O.demosaic_nearest(bay2), torch.full((1, 1), 0.5)))
+    # BGR-input chain with a leading skip aliasing its input
+    xb = rnd(2, 3, 8, 8, seed=15).cuda()
+    o3 = F.chain_forward(xb, [F.OP_SKIP, F.OP_WB_MANUAL], [None, sig(O.PARAM_INIT['wbmanual'])[:2].cuda()])
+    assert o3[0].data_ptr() == xb.data_ptr()
+    assert_close(o3[1], O.wb_manual(xb.cpu(), sig(O.PARAM_INIT['wbmanual'])[:2]))
+
+
+def test_channel_stats_first_occurrence(F):
+    x = rnd(2, 3, 16, 24, seed=16)
+    x[0, 0, 3, 5] = x[0, 0, 9, 1] = -1.0          # tie on the min: first (row-major) wins
+    x[1, 2, 0, 0] = x[1, 2, 15, 23] = 2.0
+    stats, arg = F.channel_stats(x.cuda())
+    flat = x.view(2, 3, -1)
+    assert torch.equal(stats[..., 0].cpu(), flat.min(dim=2)[0])
+    assert torch.equal(stats[..., 2].cpu(), flat.max(dim=2)[0])
+    assert_close(stats[..., 1], flat.sum(dim=2), rtol=1e-5)
+    assert arg[0, 0, 0].item() == 3 * 24 + 5 and arg[1, 2, 1].item() == 0
+
+
+def test_mix_fwd_bwd(F):
+    outs = [rnd(2, 3, 8, 8, seed=20 + k) for k in range(5)]
+    w = torch.tensor([0.1, 0.0, 0.4, 0.3, 0.2])
+    gy = rnd(2, 3, 8, 8, seed=30, lo=-1, hi=1)
+    oc = [o.clone().requires_grad_(True) for o in outs]
+    wc = w.clone().requires_grad_(True)
+    yc = sum(o * wk for o, wk in zip(oc, wc))
+    gc = torch.autograd.grad(yc, [wc] + oc, gy)
+    og = [o.cuda().requires_grad_(k != 1) for k, o in enumerate(outs)]
+    wg = w.cuda().requires_grad_(True)
+    yg = F.mix(wg, og)
+    gg = torch.autograd.grad(yg, [wg] + [o for o in og if o.requires_grad], gy.cuda())
+    assert_close(yg, yc)
+    assert_close(gg[0], gc[0], what='gw')
+    assert_close(gg[1], gc[1], what='go0')
+
+
+def test_cpu_tensor_raises(F):
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        F.gamma(torch.rand(1, 3, 4, 4), torch.rand(1, 1))

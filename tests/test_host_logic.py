@@ -1,0 +1,165 @@
+"""Host logic of the product (registry, fixed pipelines, super-net combiner, DARTS step) against
+golden vectors of the imported reference.
+
+Runs twice: on CPU with the operator seam bound to the oracle (``-m "not gpu"``: checks the host
+logic only) and on the GPU with the real HIP kernels (``-m gpu``: the end-to-end parity test)."""
+import numpy as np
+import pytest
+import torch
+
+import isp_oracle as O
+from conftest import assert_close, load_golden
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(params=['cpu-oracle-seam', pytest.param('hip', marks=pytest.mark.gpu)])
+def dev(request, monkeypatch):
+    import reconfigisp_amd.functional as F
+    if request.param == 'hip':
+        return torch.device('cuda')
+    from oracle_backend import OracleImpl
+    monkeypatch.setattr(F, '_IMPL', OracleImpl)
+    return torch.device('cpu')
+
+
+def weight_kind(name):
+    if name in O.PROXY_P:
+        return 'srcnn_res', O.PROXY_P[name]
+    return {'bilinear': ('srcnn_demosaic', 0), 'laplacian': ('srcnn_demosaic', 0),
+            'path_bayer': ('path14l_bayer', 0), 'path_bgr': ('path14l_bgr', 0)}.get(name, (None, 0))
+
+
+def seed_ops(ops, names, base):
+    for k, (op, name) in enumerate(zip(ops, names)):
+        kind, P = weight_kind(name)
+        if kind and hasattr(op, 'load_state_dict') and len(op.state_dict()):
+            op.load_state_dict(O.make_weights(kind, base + k, P))
+
+
+def build_supernet(n_step, dev):
+    from reconfigisp_amd.codes.models.modules.super_prune_fifteen_demos_four_bayer_two import \
+        SuperPruneFifteenDemosFourBayerTwo
+    net = SuperPruneFifteenDemosFourBayerTwo(n_step=n_step, threshold=0.2, module_path=None)
+    for s, (mods, names) in enumerate(zip(net.all_modules, net.slot_names)):
+        seed_ops(mods, names, 1000 + 100 * s)
+    return net.to(dev)
+
+
+def test_supernet_matches_reference(dev):
+    g = load_golden('supernet_n2')
+    net = build_supernet(2, dev)
+    assert list(net.state_dict().keys()) == list(g['state_keys'])
+    assert len(net.trainable_parameters) == int(g['n_trainable'])
+    with torch.no_grad():
+        for k, v in net.named_parameters():
+            v.copy_(T(g['p_' + k]))
+    y = net(T(g['x']).to(dev))
+    assert net.pruned_paths == list(g['pruned_paths'])                       # prune mask: bit exact
+    for i, m in enumerate(net.intermediate_results):
+        assert_close(m, g['mid%d' % i], what='slot %d' % i)
+    named = dict(net.named_parameters())
+    keys = sorted(named)
+    grads = torch.autograd.grad(y, [named[k] for k in keys], T(g['gy']).to(dev), allow_unused=True)
+    for k, gr in zip(keys, grads):
+        gr = torch.zeros_like(named[k]) if gr is None else gr
+        assert_close(gr, g['g_' + k], rtol=2e-4, what='grad ' + k)
+
+
+def test_origin_universal_matches_reference(dev):
+    from reconfigisp_amd.codes.models.modules.origin_universal import OriginUniversal
+    g = load_golden('fixed_origin')
+    net = OriginUniversal(module_path=None, architecture=str(g['arch']))
+    seed_ops(net.all_modules, net.step_names, 2000)
+    net = net.to(dev)
+    assert list(net.state_dict().keys()) == list(g['state_keys'])
+    x = T(g['x']).to(dev)
+    y = net(x)                                                              # autograd (per-op) path
+    for i, m in enumerate(net.intermediate_results):
+        assert_close(m, g['mid%d' % i], what='stage %d' % i)
+    assert_close(y, g['y'])
+    assert net.intermediate_results[1] is net.intermediate_results[0]       # Skip returns the same tensor
+    if dev.type == 'cuda':
+        with torch.no_grad():
+            y2 = net(x)                                                     # fused inference path
+        for i, m in enumerate(net.intermediate_results):
+            assert_close(m, g['mid%d' % i], what='fused stage %d' % i)
+        assert_close(y2, g['y'])
+
+
+def test_isp_universal_conditional_matches_reference(dev):
+    from reconfigisp_amd.codes.models.modules.isp_universal import IspUniversal
+    g = load_golden('fixed_isp')
+    net = IspUniversal(module_path=None, indiv_module_paths=(None,) * 8, architecture=str(g['arch']),
+                       gamma_in_channels=(12, 8), wb_manual_in_channels=(12, 8), wb_quadratic_in_channels=(24, 8))
+    seed_ops(net.all_modules, net.step_names, 3000)
+    assert list(net.state_dict().keys()) == list(g['state_keys'])
+    net.load_state_dict({k: T(g['p_' + k]) for k in net.state_dict()})
+    net = net.to(dev)
+    x = T(g['x']).to(dev)
+    y = net(x)
+    for i, m in enumerate(net.intermediate_results):
+        assert_close(m, g['mid%d' % i], what='stage %d %s' % (i, net.step_names[i]))
+    assert_close(y, g['y'])
+    if dev.type == 'cuda':
+        with torch.no_grad():
+            net(x)
+        for i, m in enumerate(net.intermediate_results):
+            assert_close(m, g['mid%d' % i], what='fused stage %d %s' % (i, net.step_names[i]))
+
+
+def test_registry_errors():
+    from reconfigisp_amd.codes.models.modules import registry as R
+    from reconfigisp_amd.codes.models import networks, create_model
+    with pytest.raises(ValueError, match='Domain'):
+        R.parse_architecture('01_02', R.NAMES_SRGB)
+    with pytest.raises(AssertionError):
+        R.parse_architecture('sRGB_16', R.NAMES_SRGB)
+    with pytest.raises(NotImplementedError):
+        R.make_op('ten_layer_net', None)
+    with pytest.raises(NotImplementedError, match='not recognized'):
+        networks.define_G({'network_G': {'which_model_G': 'Nope'}})
+    with pytest.raises(NotImplementedError, match='not recognized'):
+        create_model({'model': 'nope'})
+    assert [n for _, n in R.parse_architecture('Bayer_01_Demosaic_03_sRGB_01_13_11', R.NAMES_SRGB)] == \
+        ['path_bayer', 'laplacian', 'gamma', 'wbquadratic', 'wbmanual']
+
+
+def darts_opt(dev):
+    from collections import OrderedDict
+    return OrderedDict(model='darts', gpu_ids=[0] if dev.type == 'cuda' else None, dist=False, is_train=True,
+                       network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=2, n_modules=15,
+                                      prune_threshold=0.2, module_path=None),
+                       path=dict(pretrain_model_G=None, strict_load=True),
+                       train=dict(lr_G=1e-2, momentum_G=0.9, lr_meta=1e-2, beta1=0.9, beta2=0.99,
+                                  pixel_criterion='l2', lr_scheme='MultiStepLR', lr_steps=[1000], restarts=None,
+                                  restart_weights=None, lr_gamma=0.5, clear_state=False))
+
+
+def seed_darts(model):
+    for net in (model.netG, model.netV):
+        for s, (mods, names) in enumerate(zip(net.all_modules, net.slot_names)):
+            seed_ops(mods, names, 1000 + 100 * s)
+        net.to(model.device)
+        with torch.no_grad():
+            net.alpha_demosaic[3] = -20.0
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+def test_darts_search_step_matches_reference(dev):
+    from reconfigisp_amd.codes.models import create_model
+    g = load_golden('darts_step')
+    model = create_model(darts_opt(dev))
+    seed_darts(model)
+    data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
+    for it in range(2):
+        model.feed_data(data)
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.optimize_alphas()
+        assert_close(model.val_loss, g['it%d_val_loss' % it], rtol=2e-4, what='val loss')
+        for k, a in enumerate(model.netG.alphas):
+            assert_close(a.grad, g['it%d_alpha_grad%d' % (it, k)], rtol=5e-3, atol=1e-7, what='alpha grad %d' % k)
+        model.optimize_parameters()
+        assert abs(model.log_dict['loss'] - float(g['it%d_loss' % it])) <= 2e-4 * abs(float(g['it%d_loss' % it]))
+        for k, v in model.netG.state_dict().items():
+            assert_close(v, g['it%d_%s' % (it, k)], rtol=1e-3, atol=1e-6, what='it%d %s' % (it, k))
