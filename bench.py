@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py - MPix/s of the end-to-end 5-stage fixed ISP forward on 256x256 Bayer patches
+(BASELINE.json metric), one process per GPU, batch sharded across ranks (weak scaling, no
+data-path collective: every image is independent).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one forward of the pipeline over one batch of 64 synthetic 256x256 RGGB patches that is
+already resident in HBM.  Workloads (SURVEY.md section 8d / BASELINE.md):
+  hbm (headline `value`)  Bayer_02_Demosaic_01_sRGB_11_01_14 = skip -> nearest demosaic -> WbManual
+                          -> Gamma -> GtmManual, every stage output materialised; HBM roofline
+  cnn (`extra.cnn_*`)     Bayer_01_Demosaic_03_sRGB_01_13_11 (options/train/SID_isp.yml:28) =
+                          Path-Restore-Bayer -> proxy demosaic -> Gamma -> WbQuadratic -> WbManual;
+                          fp32-MFMA roofline
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+ARCH_HBM = 'Bayer_02_Demosaic_01_sRGB_11_01_14'
+ARCH_CNN = 'Bayer_01_Demosaic_03_sRGB_01_13_11'
+# algorithmic HBM bytes per pixel of the fused hbm pipeline: read the mosaic once (4 B) and write each
+# of the four materialised BGR stage outputs (4 x 12 B); `skip` aliases its input (0 B).  SURVEY 8d's
+# stage-by-stage figure (88 B/pix) also counts the three intermediate re-reads the fused launch avoids.
+BYTES_PER_PIX_FUSED = 4 + 4 * 12
+BYTES_PER_PIX_UNFUSED = 88
+FLOP_PER_PIX_CNN = 239680      # 223488 (Path14lBayer) + 16192 (SRCNNDemosaic)
+
+
+def build_pipeline(arch, device):
+    from reconfigisp_amd.codes.models import networks
+    opt = {'network_G': {'which_model_G': 'IspUniversal', 'architecture': arch, 'module_path': None,
+                         'individual_module_paths': [None] * 8}}
+    torch.manual_seed(10)
+    net = networks.define_G(opt).to(device)
+    net.eval()
+    return net
+
+
+def timed(fn, steps, warmup, device, world):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = t.item()
+    return wall, dev_ms / steps
+
+
+def kernel_time_ms(net, bay, reps, device):
+    """Average launch duration of the dominant kernel (the fused chain), measured live with a HIP
+    event pair on the launch stream around `reps` back-to-back launches issued straight through the
+    C ABI (one ctypes call each, so the stream never drains and the figure is kernel + the ~1.5 us
+    same-stream launch boundary, not host time)."""
+    import reconfigisp_amd.functional as F
+    n = bay.shape[0]
+    pars = net._stage_params(n)
+    plan = F.ChainPlan(bay, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], pars[1:])
+    for _ in range(5):
+        plan.launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record()
+    for _ in range(reps):
+        plan.launch()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_baseline(bay, arch, budget_s=15.0):
+    """The CPU oracle (restatement of the reference's torch-CPU path) on a bounded sample of the same
+    batch.  The thread count is the best of a short sweep (torch's default of one thread per core
+    oversubscribes these small element-wise ops on a 256-core host)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import isp_oracle as O
+    cores = os.cpu_count() or 1
+    names = O.parse_architecture(arch)
+    raw = [torch.tensor(O.PARAM_INIT[k]) for k in names]
+    n = min(16, bay.shape[0])
+    sample = bay[:n].cpu()
+    run = lambda: O.fixed_pipeline(sample, names, raw, [None] * len(names))
+
+    def rate(threads, seconds, max_reps):
+        torch.set_num_threads(threads)
+        run()
+        reps, t0 = 0, time.perf_counter()
+        while reps < 2 or (time.perf_counter() - t0 < seconds and reps < max_reps):
+            run()
+            reps += 1
+        return reps, time.perf_counter() - t0
+
+    with torch.no_grad():
+        best, best_rate = 1, 0.0
+        for th in sorted({1, 8, 16, 32, 64, cores} & set(range(1, cores + 1))):
+            reps, dt = rate(th, 0.75, 50)
+            if reps / dt > best_rate:
+                best, best_rate = th, reps / dt
+        reps, dt = rate(best, budget_s, 2000)
+    mpix = n * bay.shape[2] * bay.shape[3] * reps / dt / 1e6
+    return {'value': round(mpix, 2), 'unit': 'MPix/s', 'cores': best, 'kind': 'port',
+            'sample': '%d of the %d 256x256 patches x %d repetitions of %s through oracle/isp_oracle.py '
+                      '(torch CPU fp32, best of a thread sweep = %d threads on a %d-core host)'
+                      % (n, bay.shape[0], reps, arch, best, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=64, help='patches per GPU per step')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--eager', action='store_true', help='per-step Python dispatch instead of hipGraph replay')
+    ap.add_argument('--no-cnn', action='store_true', help='skip the MFMA-bound reference-YAML pipeline')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        dist.init_process_group(backend='nccl')       # RCCL on ROCm
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    from reconfigisp_amd.codes.data.synthetic_raw import make_batch
+    bay_cpu, _ = make_batch(args.batch, args.size, args.size, seed=10 + rank)
+    bay = bay_cpu.to(device)
+    pix_per_step = args.batch * args.size * args.size
+
+    from reconfigisp_amd.graphs import GraphedForward
+    net = build_pipeline(ARCH_HBM, device)
+    step = GraphedForward(net, bay) if not args.eager else (lambda: net(bay))
+    with torch.no_grad():
+        wall, dev_ms = timed(lambda: step(), args.steps, args.warmup, device, world)
+        kernel_ms = kernel_time_ms(net, bay, max(args.steps, 100), device)
+    value = world * pix_per_step * args.steps / wall / 1e6
+    achieved = BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms * 1e-3) / 1e9
+
+    extra = {'hbm_unfused_equiv_GBs': round(BYTES_PER_PIX_UNFUSED * pix_per_step / (kernel_ms * 1e-3) / 1e9, 1),
+             'kernel_ms': round(kernel_ms, 5), 'stream_ms_per_step': round(dev_ms, 5),
+             'launch': 'eager' if args.eager else 'hipGraph replay'}
+    if not args.no_cnn:
+        cnn = build_pipeline(ARCH_CNN, device)
+        steps_c = max(3, args.steps // 20)
+        cstep = GraphedForward(cnn, bay) if not args.eager else (lambda: cnn(bay))
+        with torch.no_grad():
+            wall_c, dev_ms_c = timed(lambda: cstep(), steps_c, 2, device, world)
+        extra.update(cnn_arch=ARCH_CNN, cnn_MPix_s=round(world * pix_per_step * steps_c / wall_c / 1e6, 1),
+                     cnn_ms_per_step=round(dev_ms_c, 3),
+                     cnn_mfma_TFLOPs=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12, 2),
+                     cnn_mfma_frac=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4))
+
+    if rank == 0:
+        line = {
+            'metric': 'MPix/s end-to-end 5-stage ISP forward, 256x256 Bayer', 'value': round(value, 1),
+            'unit': 'MPix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(wall / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'batch=%d %dx%d Bayer per GPU, 5-stage fixed ISP forward %s (skip, nearest '
+                                   'demosaic, WbManual, Gamma, GtmManual), all stage outputs materialised'
+                                   % (args.batch, args.size, args.size, ARCH_HBM),
+                       'global_batch': args.batch * world, 'parallelism': 'batch-sharded x%d, no collective' % world},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'kernel': 'chain_kernel<2> (risp_chain_fwd): one launch per step, %d B/pix algorithmic' % BYTES_PER_PIX_FUSED},
+            'extra': extra,
+        }
+        if not args.no_cpu and world == 1:
+            line['cpu_baseline'] = cpu_baseline(bay_cpu, ARCH_HBM)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -55,6 +55,16 @@ class _FixedPipeline(nn.Module):
         return self
 
     def _stage_params(self, n):
+        if not torch.is_grad_enabled():
+            # inference: sigmoid(p).repeat(N,1) only changes when a parameter does - keep the (N,P)
+            # blocks resident instead of re-launching 2 tiny kernels per stage per call
+            key = (n,) + tuple((p._version, p.data_ptr()) for p in self.all_params)
+            if getattr(self, '_stage_cache_key', None) != key:
+                self._stage_cache, self._stage_cache_key = self._build_stage_params(n), key
+            return self._stage_cache
+        return self._build_stage_params(n)
+
+    def _build_stage_params(self, n):
         out = []
         for p, cond in zip(self.all_params, self.is_conditional):
             if p.numel() == 0:

@@ -200,32 +200,39 @@ def attach_zero_grad(y, pars):
     return _ZeroGrad.apply(y, *pars)
 
 
+class ChainPlan:
+    """A fused element-wise segment with its output buffers and marshalled arguments prepared once;
+    ``launch()`` is a single C-ABI call (``risp_chain_fwd``).  ``outs[k]`` is stage k's output
+    (SKIP stages alias their input)."""
+
+    def __init__(self, x, ops, params):
+        x = _dev(x, 'img')
+        n, cin, h, w = x.shape
+        if h % 2 or w % 2:
+            raise ValueError('H and W must be even, got %s' % (tuple(x.shape),))
+        if cin != (1 if ops[0] == OP_DEMOSAIC_NEAREST else 3):
+            raise ValueError('chain input has %d channels' % cin)
+        self.x, self.outs, cur = x, [], x
+        for op in ops:
+            if op != OP_SKIP:
+                cur = torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
+            self.outs.append(cur)
+        self.params = [_dev(p) if p is not None else None for p in params]   # keep alive
+        self._args = (_p(x), len(ops), (C.c_int * len(ops))(*ops),
+                      L.ptr_array([p.data_ptr() if p is not None else None for p in self.params]),
+                      L.ptr_array([o.data_ptr() if op != OP_SKIP else None for o, op in zip(self.outs, ops)]),
+                      n, h, w)
+
+    def launch(self):
+        L.call('risp_chain_fwd', *self._args, _stream())
+        return self.outs
+
+
 def chain_forward(x, ops, params):
     """Fused element-wise segment: returns the list of stage outputs (SKIP aliases its input).
 
     Inference-only fast path (no autograd graph is recorded)."""
-    x = _dev(x, 'img')
-    n, cin, h, w = x.shape
-    if h % 2 or w % 2:
-        raise ValueError('H and W must be even, got %s' % (tuple(x.shape),))
-    first_dem = ops[0] == OP_DEMOSAIC_NEAREST
-    if cin != (1 if first_dem else 3):
-        raise ValueError('chain input has %d channels' % cin)
-    outs, keep = [], []
-    cur = x
-    for op, p in zip(ops, params):
-        if op == OP_SKIP:
-            outs.append(cur)
-            continue
-        cur = torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
-        outs.append(cur)
-    pts = [_dev(p) if p is not None else None for p in params]
-    keep.extend(pts)
-    L.call('risp_chain_fwd', _p(x), len(ops), (C.c_int * len(ops))(*ops),
-           L.ptr_array([p.data_ptr() if p is not None else None for p in pts]),
-           L.ptr_array([o.data_ptr() if op != OP_SKIP else None for o, op in zip(outs, ops)]),
-           n, h, w, _stream())
-    return outs
+    return ChainPlan(x, ops, params).launch()
 
 
 class _HipImpl:

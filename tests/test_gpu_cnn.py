@@ -56,22 +56,54 @@ def test_path14l_vs_reference_golden():
     _golden_case('path14l_bgr', 'path14l_bgr')
 
 
+def kink_free_weights(kind, seed, P):
+    """Weights whose hidden ReLUs are decided by a per-channel bias of +-1 (even channels live, odd
+    channels dead) with the convolution contributing only a few percent on top.  A dense input-gradient
+    can only be compared between two fp32 implementations when no pre-activation sits on the ReLU kink
+    (a 1-ulp difference would flip a mask bit); random weights at multi-tile sizes always have some.
+    The ReLU-mask / residual logic is still exercised (half the channels masked), the convolution
+    arithmetic itself is pinned by test_gpu_conv_modes.py and the golden cases."""
+    w = O.make_weights(kind, seed, P, gain=0.02)
+    keys = [k for k in w if k.endswith('.bias')]
+    last = keys[-1]
+    for k in keys:
+        if k != last:
+            sign = torch.ones_like(w[k])
+            sign[1::2] = -1.0
+            w[k] = sign
+    return w
+
+
 @pytest.mark.parametrize('kind,P,cin,hw', [('srcnn_res', 1, 3, (64, 96)), ('srcnn_demosaic', 0, 1, (64, 96)),
                                            ('path14l_bayer', 0, 1, (96, 64)), ('path14l_bgr', 0, 3, (48, 80))])
 def test_cnn_vs_oracle_multi_tile(kind, P, cin, hw):
-    """Sizes spanning several 16x32 output tiles, forward + backward, vs the CPU oracle."""
+    """Sizes spanning several 16x32 output tiles: forward with random weights, forward + backward with
+    kink-free weights, vs the CPU oracle."""
     g = np.random.Generator(np.random.PCG64(5))
     x = torch.from_numpy(g.random((2, cin) + hw).astype(np.float32))
     pv = torch.from_numpy(g.random((2, P)).astype(np.float32)) if P else None
+    TP = _modules()
+    cls = {'srcnn_res': TP.ProxyNet, 'srcnn_demosaic': TP.ProxyDemosaicNet,
+           'path14l_bayer': TP.PathRestore14lBayer, 'path14l_bgr': TP.PathRestore14lBgr}[kind]
+
+    def oracle(a, b, w):
+        return {'srcnn_res': lambda: O.srcnn_res(a, b, w), 'srcnn_demosaic': lambda: O.srcnn_demosaic(a, w),
+                'path14l_bayer': lambda: O.path14l_bayer(a, w), 'path14l_bgr': lambda: O.path14l_bgr(a, w)}[kind]()
+
     w = O.make_weights(kind, 321, P)
-    fn = {'srcnn_res': lambda a, b: O.srcnn_res(a, b, w), 'srcnn_demosaic': lambda a, b: O.srcnn_demosaic(a, w),
-          'path14l_bayer': lambda a, b: O.path14l_bayer(a, w), 'path14l_bgr': lambda a, b: O.path14l_bgr(a, w)}[kind]
+    m = cls(P, None)
+    m.load_state_dict(w)
+    m = m.cuda()
+    with torch.no_grad():
+        assert_close(m(x.cuda(), pv.cuda() if P else None), oracle(x, pv, w), what=kind + ' y (random weights)')
+
+    w = kink_free_weights(kind, 654, P)
+    m.load_state_dict(w)
     xc = x.clone().requires_grad_(True)
     pc = pv.clone().requires_grad_(True) if P else None
-    yc = fn(xc, pc)
+    yc = oracle(xc, pc, w)
     gy = torch.from_numpy(g.standard_normal(tuple(yc.shape)).astype(np.float32))
     gc = torch.autograd.grad(yc, (xc, pc) if P else (xc,), gy)
-    m = _build(kind, 321, P)
     xg = x.cuda().requires_grad_(True)
     pg = pv.cuda().requires_grad_(True) if P else None
     yg = m(xg, pg)
