@@ -1,0 +1,48 @@
+"""create_dataset / create_dataloader - mirror of the reference's data/__init__.py:9-53.
+
+Only the synthetic RAW source is built (mode 'Synthetic_RGGB2BGR'): the reference's six dataset
+classes read PNG / lmdb / memcached files through cv2 and are real-dataset I/O outside the hot path
+(SURVEY.md section 2 row 14).  The loader contract is theirs: train loaders shard ``batch_size`` over
+the ranks and drop the last batch, test loaders yield one image at a time."""
+import logging
+
+import torch
+import torch.distributed as dist
+import torch.utils.data
+from torch.utils.data.dataloader import default_collate
+
+_FILE_BACKED = ('SID_Sony_Ratio_RGGB2BGR', 'SID_Sony_Ratio_Test_RGGB2BGR', 'S7ISP_RGGB2BGR', 'S7ISP_RGGB2BGR_Test',
+                'OnePlus_Rggb2Obj', 'OnePlus_Rggb2Obj_Test')
+
+
+def create_dataloader(dataset, dataset_opt, opt=None, sampler=None, collate_fn=None):
+    phase = dataset_opt['phase']
+    if phase == 'test':
+        return torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=0, pin_memory=True)
+    if phase != 'train':
+        raise ValueError('Unknown phase: {}'.format(phase))
+    if opt['dist']:
+        world = dist.get_world_size()
+        assert dataset_opt['batch_size'] % world == 0, 'batch_size must divide over the ranks'
+        batch, workers, shuffle = dataset_opt['batch_size'] // world, dataset_opt['n_workers'], False
+    else:
+        batch = dataset_opt['batch_size']
+        workers = dataset_opt['n_workers'] * len(opt['gpu_ids'] or [0])
+        shuffle = sampler is None
+    return torch.utils.data.DataLoader(dataset, batch_size=batch, shuffle=shuffle, num_workers=workers, sampler=sampler,
+                                       drop_last=True, pin_memory=False, collate_fn=collate_fn or default_collate)
+
+
+def create_dataset(dataset_opt):
+    mode = dataset_opt['mode']
+    if mode == 'Synthetic_RGGB2BGR':
+        from .synthetic_raw import SyntheticRawDataset as D
+    elif mode in _FILE_BACKED:
+        raise NotImplementedError(
+            'Dataset [{:s}] reads image files through cv2/lmdb and is outside the scope of this build; use mode '
+            'Synthetic_RGGB2BGR (same tensor contract: noisy (1,H,W) in [0,1], gt (3,H,W)).'.format(mode))
+    else:
+        raise NotImplementedError('Dataset [{:s}] is not recognized.'.format(mode))
+    dataset = D(dataset_opt)
+    logging.getLogger('base').info('Dataset {:s} is created.'.format(mode))
+    return dataset

@@ -77,7 +77,7 @@ class _FixedPipeline(nn.Module):
 
     def forward(self, x):
         pars = self._stage_params(x.size(0))
-        if not wants_grad(x, self.all_params):
+        if x.is_cuda and not wants_grad(x, self.all_params):
             with torch.no_grad():
                 x, self.intermediate_results = fused_forward(self.all_modules, pars, x)
             return x

@@ -7,12 +7,16 @@ detached sum -> weighted sum, 'dummy gradient' for pruned parametrised ops), pro
 state-dict keys (alpha_bayer, alpha_demosaic, alpha_step<k>, param_step<k>_<name>).
 The weighted sum of a slot is one fused kernel (risp_mix_fwd/bwd) instead of K multiply-adds.
 """
+import logging
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
 from .... import functional as F
+from ....isp_kernels import demosaic as _dm
 from . import registry as R
+from . import tools_origin as T
 
 
 class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
@@ -67,10 +71,29 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                     p.data = fn(p.data)
         return self
 
+    def _unavailable(self, mods):
+        """Ops that cannot run in this build (DemosaicNet without a registered implementation): they are
+        left out of the softmax - probability exactly 0, zero alpha-gradient - instead of crashing the
+        search.  With an implementation registered (isp_kernels.demosaic.register_demosaicnet) the
+        reference behaviour applies unchanged."""
+        if _dm.demosaicnet_available():
+            return None
+        mask = [isinstance(m, T.DemosaicNet) for m in mods]
+        if not any(mask):
+            return None
+        if not getattr(self, '_warned_unavailable', False):
+            logging.getLogger('base').warning('DemosaicNet has no implementation in this build; its mixing '
+                                              'probability is fixed to 0')
+            self._warned_unavailable = True
+        return mask
+
     def forward(self, x):
         n = x.size(0)
         self.middle_results = []
         for slot, (mods, pars, alpha) in enumerate(zip(self.all_modules, self.all_params, self.all_alphas)):
+            missing = self._unavailable(mods)
+            if missing is not None:
+                alpha = alpha.masked_fill(torch.tensor(missing, device=alpha.device), float('-inf'))
             probs = TF.softmax(alpha, dim=0)
             keep_below = probs.detach() < self.threshold * probs.detach().max()
             post = probs.clone()

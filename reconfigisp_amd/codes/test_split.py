@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Full-frame tiled inference (reference test_split.py:57-142): ``python test_split.py --opt X.yml``
+with datasets.test.patch_size / patch_stride.  The frame is cut into overlapped tiles, every tile goes
+through the pipeline, and the last stage's outputs are blended back with the linear edge-ramp mask.
+
+Unlike the reference's one-tile-at-a-time host loop (numpy crop -> H2D -> forward -> D2H per tile), the
+frame stays in HBM: one gather kernel makes the (T,C,h,w) tile batch, the pipeline runs on tile
+batches, one blend kernel writes the frame."""
+import argparse
+import logging
+import os
+import os.path as osp
+import random
+import sys
+
+if __package__ in (None, ''):
+    sys.path.insert(0, osp.abspath(osp.join(osp.dirname(__file__), os.pardir, os.pardir)))
+    __package__ = 'reconfigisp_amd.codes'
+
+import numpy as np
+import torch
+
+from .data import create_dataloader, create_dataset
+from .models import create_model
+from .options import options as option
+from .test import as_three, write_ppm
+from .utils import util
+from .utils.util_path_restore import blend_tiles, gather_tiles, tile_grid
+
+
+def run_frame(model, frame, size, stride, tile_batch=16):
+    """frame: (1,C,H,W) tensor.  Returns the blended (1,3,H,W) output of the last pipeline stage."""
+    dev = model.device
+    img = frame[0].to(dev)
+    _, H, W = img.shape
+    positions = tile_grid(H, W, size, stride)
+    tiles = gather_tiles(img, positions, size)
+    print('Split into {} patches'.format(len(positions)))
+    outs = []
+    for at in range(0, len(positions), tile_batch):
+        chunk = tiles[at: at + tile_batch]
+        model.feed_data((chunk, chunk))            # dummy ground truth, as in the reference (:93)
+        _, mids = model.test()
+        outs.append(mids[-1])
+    return blend_tiles(torch.cat(outs, dim=0), positions, (H, W), stride).unsqueeze(0)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--opt', type=str, help='Path to option YAML file.')
+    ap.add_argument('--tile_batch', type=int, default=16, help='tiles per forward (the reference uses 1)')
+    args = ap.parse_args(argv)
+    opt = option.parse(args.opt, is_train=False)
+    util.mkdirs(p for k, p in opt['path'].items()
+                if p and k not in ('experiments_root', 'strict_load', 'root') and 'pretrain_model' not in k
+                and 'resume' not in k)
+    util.setup_logger('base', opt['path']['log'], 'test_' + opt['name'], level=logging.INFO, screen=True, tofile=True)
+    logger = logging.getLogger('base')
+    logger.info(option.dict2str(opt))
+
+    loaders = []
+    for _, dopt in sorted(opt['datasets'].items()):
+        loaders.append(create_dataloader(create_dataset(dopt), dopt))
+    model = create_model(opt)
+    seed = opt.get('test_seed')
+    util.set_random_seed(random.randint(1, 10000) if seed is None else seed)
+    size = (opt['datasets']['test']['patch_size'],) * 2
+    stride = (opt['datasets']['test']['patch_stride'],) * 2
+
+    for loader in loaders:
+        name = loader.dataset.opt['mode']
+        out_dir = osp.join(opt['path']['results_root'], name)
+        util.mkdir(out_dir)
+        psnr_in, psnr_out = [], []
+        for idx, data in enumerate(loader):
+            print('Image No. {}'.format(idx + 1))
+            merged = run_frame(model, data['noisy'], size, stride, args.tile_batch)
+            out_u8 = (np.clip(merged[0].permute(1, 2, 0).cpu().numpy(), 0, 1) * 255.).astype(np.uint8)
+            img_in, img_gt = as_three(util.tensor2bgr(data['noisy'])), util.tensor2bgr(data['gt'])
+            psnr_in.append(util.psnr(img_in, img_gt))
+            psnr_out.append(util.psnr(out_u8, img_gt))
+            write_ppm(osp.join(out_dir, str(data['name'][0]) + '_out.ppm'), np.concatenate([img_in, out_u8, img_gt], axis=1))
+        for tag, v in (('in', np.asarray(psnr_in)), ('out', np.asarray(psnr_out))):
+            print('PSNR {}: min {}, max {}, mean {}, std {}'.format(tag, v.min(), v.max(), v.mean(), v.std()))
+
+
+if __name__ == '__main__':
+    main()

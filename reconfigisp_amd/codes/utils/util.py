@@ -103,7 +103,7 @@ def psnr(img1, img2):
             return a.astype(np.float32) / 255.
         return a
     mse = ((unit(img1) - unit(img2)) ** 2).mean()
-    return 10 * math.log10(1. / mse)
+    return float('inf') if mse == 0 else 10 * math.log10(1. / mse)
 
 
 def psnr_tensors(a, b):
@@ -116,4 +116,5 @@ def psnr_tensors(a, b):
         raise ValueError('shape mismatch %s vs %s' % (tuple(a.shape), tuple(b.shape)))
     sse = torch.empty(1, device=a.device, dtype=torch.float64)
     L.call('risp_sse_uint8', F._p(a), F._p(b), C.c_void_p(sse.data_ptr()), a.numel(), F._stream())
-    return 10 * math.log10(1. / (sse.item() / a.numel()))
+    mse = sse.item() / a.numel()
+    return float('inf') if mse == 0 else 10 * math.log10(1. / mse)   # identical images: inf, like numpy's 1./0.

@@ -4,6 +4,20 @@ from .. import functional as F
 from ._layout import to_nchw, to_nhwc
 
 
+_DEMOSAICNET = None
+
+
+def register_demosaicnet(fn):
+    """Plug a user-supplied differentiable DemosaicNet: fn((N,1,H,W) RGGB in [0,1]) -> (N,3,H,W) BGR.
+    The original lives only in the private ISP_Kernels package and is not reproducible."""
+    global _DEMOSAICNET
+    _DEMOSAICNET = fn
+
+
+def demosaicnet_available():
+    return _DEMOSAICNET is not None
+
+
 class Demosaic:
     def run(self, img, option, params):
         fmt_in = params.get('input', {}).get('format', 'RGGB')
@@ -14,6 +28,8 @@ class Demosaic:
         if option in ('bilinear', 'laplacian'):
             return to_nhwc(F.origin_demosaic(to_nchw(img), option))
         if option == 'demosaicnet':
+            if _DEMOSAICNET is not None:
+                return _DEMOSAICNET(img)
             raise NotImplementedError(
                 "Demosaic 'demosaicnet': the Gharbi-style network and its weights live only in the private "
                 'ISP_Kernels package and cannot be reproduced (SURVEY.md section 2); the registry slot is kept')

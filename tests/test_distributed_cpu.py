@@ -1,0 +1,94 @@
+"""N>1 path on CPU: 2 gloo ranks, each with half of the batch, must reproduce the single-process
+step on the whole batch (weight gradients AND architecture gradients are averaged over the ranks by
+DartsModel._allreduce_mean).  Operator seam bound to the CPU oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_model(dist_on):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import reconfigisp_amd.functional as F
+    from oracle_backend import OracleImpl
+    F._IMPL = OracleImpl
+    from test_host_logic import darts_opt, seed_darts
+    from reconfigisp_amd.codes.models import create_model
+    opt = darts_opt(torch.device('cpu'))
+    opt['dist'] = dist_on
+    opt['network_G']['n_step'] = 1
+    torch.manual_seed(0)
+    model = create_model(opt)
+    seed_darts(model)
+    return model
+
+
+def _data():
+    g = np.random.Generator(np.random.PCG64(77))
+    f = lambda *s: torch.from_numpy(g.random(s).astype(np.float32))
+    return f(4, 1, 8, 8), f(4, 3, 8, 8), f(4, 1, 8, 8), f(4, 3, 8, 8)
+
+
+def _step(model, data):
+    model.feed_data(data)
+    model.update_learning_rate(0, warmup_iter=-1)
+    model.optimize_alphas()
+    model.optimize_parameters()
+    return {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        model = _make_model(True)
+        shard = tuple(t[rank::world] for t in _data())
+        state = _step(model, shard)
+        if rank == 0:
+            torch.save(state, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.filterwarnings('ignore')
+def test_two_ranks_equal_one_rank_with_double_batch(tmp_path):
+    torch.set_num_threads(4)
+    ref = _step(_make_model(False), _data())
+    out = str(tmp_path / 'rank0.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert set(got) == set(ref)
+    for k in ref:
+        np.testing.assert_allclose(got[k].numpy(), ref[k].numpy(), rtol=2e-4, atol=1e-6, err_msg=k)
+
+
+def test_samplers_split_and_shard():
+    from reconfigisp_amd.codes.data.data_sampler import DistIterTrainSampler, DistIterValSampler
+    ds = list(range(10))
+    tr = [list(DistIterTrainSampler(ds, 2, r, ratio=4)) for r in range(2)]
+    va = [list(DistIterValSampler(ds, 2, r, ratio=4)) for r in range(2)]
+    assert all(i < 5 for part in tr for i in part) and all(5 <= i < 10 for part in va for i in part)
+    assert len(tr[0]) == len(tr[1]) == 10                      # ceil(5*4/2)
+    s = DistIterTrainSampler(ds, 2, 0, ratio=4)
+    a = list(s)
+    s.set_epoch(1)
+    assert list(s) != a                                        # reshuffled per epoch, deterministic by seed
+    s.set_epoch(0)
+    assert list(s) == a
