@@ -97,6 +97,19 @@ def kernel_time_ms(net, bay, reps, device):
     return e0.elapsed_time(e1) / reps
 
 
+def measured_traffic(pix_per_step):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only when
+    they were taken on this very workload; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            t = json.load(f)
+        if t.get('algorithmic_bytes_per_launch') == BYTES_PER_PIX_FUSED * pix_per_step:
+            return t['traffic_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(bay, arch, budget_s=15.0):
     """The CPU oracle (restatement of the reference's torch-CPU path) on a bounded sample of the same
     batch.  The thread count is the best of a short sweep (torch's default of one thread per core
@@ -193,7 +206,7 @@ def main():
                                    % (args.batch, args.size, args.size, ARCH_HBM),
                        'global_batch': args.batch * world, 'parallelism': 'batch-sharded x%d, no collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': measured_traffic(pix_per_step),
                          'kernel': 'chain_kernel<2> (risp_chain_fwd): one launch per step, %d B/pix algorithmic' % BYTES_PER_PIX_FUSED},
             'extra': extra,
         }
