@@ -30,7 +30,8 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 
-ARCH_HBM = 'Bayer_02_Demosaic_01_sRGB_11_01_14'
+ARCH_HBM = 'Bayer_02_Demosaic_01_sRGB_11_01_14'           # element-wise only: one fused launch
+ARCH_DENOISE = 'Demosaic_01_sRGB_07_11_01_14'             # nearest demosaic, bilateral, WbManual, Gamma, GtmManual
 ARCH_CNN = 'Bayer_01_Demosaic_03_sRGB_01_13_11'
 # algorithmic HBM bytes per pixel of the fused hbm pipeline: read the mosaic once (4 B) and write each
 # of the four materialised BGR stage outputs (4 x 12 B); `skip` aliases its input (0 B).  SURVEY 8d's
@@ -83,7 +84,8 @@ def kernel_time_ms(net, bay, reps, device):
     same-stream launch boundary, not host time)."""
     import reconfigisp_amd.functional as F
     n = bay.shape[0]
-    pars = net._stage_params(n)
+    pars = list(net._stage_params(n))
+    pars[2] = pars[2] * 5        # WbManual: the kernel takes the gain (params * 5)
     plan = F.ChainPlan(bay, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], pars[1:])
     for _ in range(5):
         plan.launch()

@@ -46,7 +46,8 @@ const char *risp_last_error(void);
 int risp_demosaic_nearest_fwd(const float *bayer, float *bgr, int N, int H, int W, void *stream);
 int risp_demosaic_nearest_bwd(const float *g_bgr, float *g_bayer, int N, int H, int W, void *stream);
 
-/* whitebalance.WhiteBalance().run(img,'manual',{'gain':5p}) - tools_origin.py:211-221. P=3 */
+/* whitebalance.WhiteBalance().run(img,'manual',{'gain'}) - tools_origin.py:211-221.  p = the gain
+ * itself, (N,3) in [0,5] (the wrapper's params * 5, :214); y_c = x_c * gain_c, no clipping. */
 int risp_wb_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
 int risp_wb_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
                        int N, int HW, void *stream);
@@ -185,6 +186,45 @@ int risp_tile_gather(const float *img, float *patches, const int32_t *pos_dev, i
                      int H, int W, int h, int w, void *stream);
 int risp_tile_blend(const float *patches, float *img, const int32_t *pos_dev, int T, int C,
                     int H, int W, int h, int w, int eh, int ew, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Classical, non-differentiable "Origin" kernels of OriginUniversal (tools_origin.py:445-804).
+ * Build-defined OPSPEC (parity unpinned), see oracle/isp_oracle.py origin_*.  Images are NCHW fp32
+ * scaled to 0..255; outputs are clipped and rounded to 8-bit codes; reflect-101 borders.
+ * in_scale / out_div: every input sample is multiplied by in_scale first and every output code is
+ * multiplied by the fp32 reciprocal of out_div last (how PyTorch divides a GPU tensor by a scalar) - (1,1) for the plugin boundary, which receives x255 images and divides the
+ * result itself (tools_origin.py:455,471), (255,255) when the fused pipeline works on [0,1] tensors
+ * directly (bit-identical: the same fp32 multiply and divide, minus two passes over the image).
+ * ------------------------------------------------------------------------- */
+/* demosaic 'bilinear' (laplacian=0) / 'laplacian' (Malvar-He-Cutler, laplacian=1) - :457-468, :491-502 */
+int risp_origin_demosaic(const float *bayer, float *bgr, int laplacian, int N, int H, int W, float in_scale,
+                         float out_div, void *stream);
+/* spatialnoisereduction 'bilateral' - :686-710.  window (N) odd <= 15, sigmas (N) in 0..255 units */
+int risp_origin_bilateral(const float *x, float *y, const int32_t *window, const float *sigma_color,
+                          const float *sigma_space, int max_window, int N, int H, int W, float in_scale,
+                          float out_div, void *stream);
+/* 'median' - :734-751; one odd size <= 15 for the whole batch; works on 8-bit codes */
+int risp_origin_median(const float *x, float *y, int size, int N, int H, int W, float in_scale, float out_div,
+                       void *stream);
+/* 'fastnlm' - :775-797; block_size / search_block (N) odd, decay (N) */
+int risp_origin_fastnlm(const float *x, float *y, const int32_t *block_size, const int32_t *search_block,
+                        const float *decay, int max_block, int max_search, int N, int H, int W, float in_scale,
+                        float out_div, void *stream);
+/* globaltonemapping 'reinhard' (mode 0: a=white_point, b=middle_grey), 'crysisengine' (1: a=lum_adapted),
+ * 'filmic' (2: a=white_point, b=exposure_bias) - :526-543, :566-581, :604-623; whitebalance
+ * 'whiteworld' (3: a=white_point_ratio, stats from risp_channel_stats) - :647-662.
+ * a, b: (N) device arrays; scratch: 5*N floats. */
+int risp_origin_tonemap(const float *x, float *y, int mode, const float *a, const float *b, const float *stats,
+                        float *scratch, int N, int HW, float in_scale, float out_div, void *stream);
+
+/* Fused stencil segment (inference): [nearest demosaic ->] bilateral -> element-wise chain in one launch;
+ * the BGR halo tile is staged in LDS (straight from the mosaic when from_bayer), every stage output is
+ * written ([0,1] domain; the bilateral works on x255 values and returns codes/255 like the reference
+ * wrapper, tools_origin.py:690,716).  ops/params/outs as in risp_chain_fwd (no demosaic op). W % 4 == 0. */
+int risp_bilateral_chain_fwd(const float *in, int from_bayer, float *out_demosaic, float *out_bilateral,
+                             const int32_t *window, const float *sigma_color, const float *sigma_space,
+                             int max_window, int n_ops, const int *ops, const float *const *params,
+                             float *const *outs, int N, int H, int W, void *stream);
 
 /* tensor2bgr + psnr on device (utils/util.py:118-154): truncating uint8 conversion of
  * both images, squared error accumulated in fp64 into sse[0] (zeroed by the call). */

@@ -1,0 +1,204 @@
+// Fused stencil segment of a fixed pipeline (inference):
+//
+//     [nearest demosaic] -> bilateral denoise -> element-wise chain (WB / gamma / tone curve ...)
+//
+// in ONE launch that reads the segment input once and still writes every stage output
+// (intermediate_results is API: test.py:74 consumes every stage).  This is the literal ISP ordering
+// of the headline benchmark (demosaic -> denoise -> white balance -> gamma -> tone map).
+//
+// Per workgroup (256 threads): a 64 x 16 output tile.  The BGR halo tile (reflect-101, radius = window/2)
+// is staged in LDS - straight from the Bayer mosaic when the segment starts with the nearest-neighbour
+// demosaic (index map only) - scaled to the 0..255 domain the classical bilateral is defined in.  Each
+// thread then owns 4 consecutive pixels: bilateral from LDS, 8-bit rounding, back to [0,1], the
+// element-wise stages in registers, and 16-byte stores of every stage's planes.
+//
+// Arithmetic: oracle/isp_oracle.py origin_denoise('bilateral') (build-defined OPSPEC, parity unpinned;
+// call site tools_origin.py:686-710) and the element-wise contexts of risp_ops.h.
+#include "risp_common.h"
+#include "risp_ops.h"
+
+namespace {
+
+using namespace risp_ops;
+
+constexpr int FX = 64, FY = 16, PXT = 4;   // tile and pixels per thread (FX/PXT * FY = 256 threads)
+
+struct FusedArgs {
+    const float *in;            // (N,1,H,W) mosaic if from_bayer else (N,3,H,W)
+    float *out_dem;             // (N,3,H,W) demosaic output (from_bayer only)
+    float *out_bil;             // (N,3,H,W) bilateral output
+    const int *win;             // (N) odd window per image
+    const float *sig_c, *sig_s; // (N)
+    int n_ops, N, H, W, R;
+    int ops[RISP_MAX_CHAIN];
+    const float *params[RISP_MAX_CHAIN];
+    float *outs[RISP_MAX_CHAIN];
+};
+
+__device__ __forceinline__ int refl(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+__device__ __forceinline__ float q8f(float v) {
+    v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+    return floorf(v + 0.5f);
+}
+
+// RT: compile-time halo radius (1 = the 3x3 window every reference configuration produces, because
+// `.int()` precedes `*7` at tools_origin.py:698); 0 = run-time radius a.R.
+template <bool FROM_BAYER, int RT>
+__global__ __launch_bounds__(256) void bilateral_chain_kernel(const FusedArgs a) {
+    extern __shared__ float lds[];
+    const int R = RT > 0 ? RT : a.R, H = a.H, W = a.W;
+    const int tw = FX + 2 * R, th = FY + 2 * R, per = tw * th;
+    const int n = blockIdx.z, x0 = blockIdx.x * FX, y0 = blockIdx.y * FY;
+    const size_t plane = (size_t)H * W;
+
+    // ---- stage the BGR halo tile, in 8-bit units
+    if (FROM_BAYER) {
+        const float *bay = a.in + (size_t)n * plane;
+        for (int idx = threadIdx.x; idx < per; idx += 256) {
+            const int ty = idx / tw, tx = idx - ty * tw;
+            const int gy = refl(y0 + ty - R, H), gx = refl(x0 + tx - R, W);
+            const int qy = gy & ~1, qx = gx & ~1;                       // quad origin
+            const float r = bay[(size_t)qy * W + qx];
+            const float g = bay[(size_t)(qy + (gy & 1)) * W + qx + 1 - (gy & 1)];   // G1 on even rows, G2 on odd rows
+            const float b = bay[(size_t)(qy + 1) * W + qx + 1];
+            lds[idx] = b * 255.f;
+            lds[per + idx] = g * 255.f;
+            lds[2 * per + idx] = r * 255.f;
+        }
+    } else {
+        const float *img = a.in + (size_t)n * 3 * plane;
+        for (int idx = threadIdx.x; idx < 3 * per; idx += 256) {
+            const int c = idx / per, rem = idx - c * per;
+            const int ty = rem / tw, tx = rem - ty * tw;
+            lds[idx] = img[(size_t)c * plane + (size_t)refl(y0 + ty - R, H) * W + refl(x0 + tx - R, W)] * 255.f;
+        }
+    }
+    __syncthreads();
+
+    const int lx = (threadIdx.x & 15) * PXT, ly = threadIdx.x >> 4;
+    const int px = x0 + lx, py = y0 + ly;
+    if (px >= W || py >= H) return;                     // W % 4 == 0: the 4 pixels are in or out together
+    const size_t o = (size_t)n * 3 * plane + (size_t)py * W + px;
+    const float *ctr = lds + (ly + R) * tw + lx + R;
+
+    if (FROM_BAYER) {                                   // the demosaic stage output ([0,1] domain: the staged values / 255)
+        float4 vb, vg, vr;
+        float *eb = reinterpret_cast<float *>(&vb), *eg = reinterpret_cast<float *>(&vg), *er = reinterpret_cast<float *>(&vr);
+        const float *bay = a.in + (size_t)n * plane;
+#pragma unroll
+        for (int i = 0; i < PXT; ++i) {                 // exact copy of the mosaic samples (bit-exact index map)
+            const int gx = px + i, qy = py & ~1, qx = gx & ~1;
+            er[i] = bay[(size_t)qy * W + qx];
+            eg[i] = bay[(size_t)(qy + (py & 1)) * W + qx + 1 - (py & 1)];
+            eb[i] = bay[(size_t)(qy + 1) * W + qx + 1];
+        }
+        *reinterpret_cast<float4 *>(a.out_dem + o) = vb;
+        *reinterpret_cast<float4 *>(a.out_dem + o + plane) = vg;
+        *reinterpret_cast<float4 *>(a.out_dem + o + 2 * plane) = vr;
+    }
+
+    // ---- bilateral on 4 pixels
+    int r = a.win[n] / 2;
+    r = r < 0 ? 0 : (r > R ? R : r);                   // never walk outside the staged halo
+    const bool full = RT > 0 && r == RT;               // wave-uniform: unrolled window, LDS reads shared by the 4 pixels
+    const float ks = -1.f / (2.f * a.sig_s[n] * a.sig_s[n]), kc = -1.f / (2.f * a.sig_c[n] * a.sig_c[n]);
+    f3 pix[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) {
+        const float *c0 = ctr + i;
+        const float cb = c0[0], cg = c0[per], cr = c0[2 * per];
+        float nb = 0.f, ng = 0.f, nr = 0.f, den = 0.f;
+        auto tap = [&](int dy, int dx) {
+            const float *q = c0 + dy * tw + dx;
+            const float qb = q[0], qg = q[per], qr = q[2 * per];
+            const float dist = fabsf(qb - cb) + fabsf(qg - cg) + fabsf(qr - cr);
+            const float wgt = __expf((float)(dy * dy + dx * dx) * ks + dist * dist * kc);
+            nb += wgt * qb; ng += wgt * qg; nr += wgt * qr; den += wgt;
+        };
+        if (full) {
+#pragma unroll
+            for (int dy = -RT; dy <= RT; ++dy)
+#pragma unroll
+                for (int dx = -RT; dx <= RT; ++dx) tap(dy, dx);
+        } else {
+            for (int dy = -r; dy <= r; ++dy)
+                for (int dx = -r; dx <= r; ++dx) tap(dy, dx);
+        }
+        // x (1/255): what `output.float() / 255.` (tools_origin.py:716) evaluates to on the GPU (PyTorch divides by a
+        // host scalar through its fp32 reciprocal)
+        const float inv255 = 1.f / 255.f;
+        pix[i] = {q8f(nb / den) * inv255, q8f(ng / den) * inv255, q8f(nr / den) * inv255};
+    }
+    auto store = [&](float *dst) {
+        *reinterpret_cast<float4 *>(dst + o) = make_float4(pix[0].b, pix[1].b, pix[2].b, pix[3].b);
+        *reinterpret_cast<float4 *>(dst + o + plane) = make_float4(pix[0].g, pix[1].g, pix[2].g, pix[3].g);
+        *reinterpret_cast<float4 *>(dst + o + 2 * plane) = make_float4(pix[0].r, pix[1].r, pix[2].r, pix[3].r);
+    };
+    store(a.out_bil);
+
+    // ---- element-wise stages
+    for (int k = 0; k < a.n_ops; ++k) {
+        apply_op<PXT>(a.ops[k], a.params[k], n, pix);
+        if (a.outs[k]) store(a.outs[k]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int risp_bilateral_chain_fwd(const float *in, int from_bayer, float *out_demosaic, float *out_bilateral,
+                             const int32_t *window, const float *sigma_color, const float *sigma_space, int max_window,
+                             int n_ops, const int *ops, const float *const *params, float *const *outs, int N, int H,
+                             int W, void *stream) {
+    RISP_CHECK_ARG(in && out_bilateral && window && sigma_color && sigma_space, "risp_bilateral_chain_fwd: null argument");
+    RISP_CHECK_ARG(!from_bayer || out_demosaic, "risp_bilateral_chain_fwd: demosaic output buffer missing");
+    RISP_CHECK_ARG(n_ops >= 0 && n_ops <= RISP_MAX_CHAIN && (n_ops == 0 || (ops && params && outs)),
+                   "risp_bilateral_chain_fwd: bad op list");
+    RISP_CHECK_ARG(max_window >= 1 && max_window <= 15 && (max_window & 1), "risp_bilateral_chain_fwd: window %d", max_window);
+    RISP_CHECK_ARG(N > 0 && N <= 65535 && H % 2 == 0 && W % 4 == 0 && H > max_window / 2 && W > max_window / 2,
+                   "risp_bilateral_chain_fwd: bad shape N=%d H=%d W=%d (W must be a multiple of 4)", N, H, W);
+    FusedArgs a;
+    a.in = in;
+    a.out_dem = out_demosaic;
+    a.out_bil = out_bilateral;
+    a.win = window;
+    a.sig_c = sigma_color;
+    a.sig_s = sigma_space;
+    a.n_ops = n_ops;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.R = max_window / 2;
+    for (int k = 0; k < RISP_MAX_CHAIN; ++k) {
+        a.ops[k] = RISP_OP_SKIP;
+        a.params[k] = nullptr;
+        a.outs[k] = nullptr;
+    }
+    for (int k = 0; k < n_ops; ++k) {
+        RISP_CHECK_ARG(ops[k] == RISP_OP_SKIP || (ops[k] >= RISP_OP_WB_MANUAL && ops[k] <= RISP_OP_GAIN3),
+                       "risp_bilateral_chain_fwd: op %d not allowed after the stencil", ops[k]);
+        RISP_CHECK_ARG(ops[k] == RISP_OP_SKIP || (params[k] && outs[k]), "risp_bilateral_chain_fwd: stage %d incomplete", k);
+        a.ops[k] = ops[k];
+        a.params[k] = params[k];
+        a.outs[k] = ops[k] == RISP_OP_SKIP ? nullptr : outs[k];
+    }
+    const size_t lds = sizeof(float) * 3 * (FX + 2 * a.R) * (FY + 2 * a.R);
+    dim3 grid((W + FX - 1) / FX, (H + FY - 1) / FY, N);
+    hipStream_t s = (hipStream_t)stream;
+    if (a.R == 1) {
+        if (from_bayer) hipLaunchKernelGGL((bilateral_chain_kernel<true, 1>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((bilateral_chain_kernel<false, 1>), grid, dim3(256), lds, s, a);
+    } else {
+        if (from_bayer) hipLaunchKernelGGL((bilateral_chain_kernel<true, 0>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((bilateral_chain_kernel<false, 0>), grid, dim3(256), lds, s, a);
+    }
+    RISP_LAUNCH_CHECK("risp_bilateral_chain_fwd");
+    return 0;
+}
+
+}  // extern "C"

@@ -9,175 +9,11 @@
 // GtmManual :414-440; plugin-backed ops follow the build-defined OPSPEC restated in
 // oracle/isp_oracle.py (gamma_manual, wb_manual, demosaic_nearest).
 #include "risp_common.h"
+#include "risp_ops.h"
 
 namespace {
 
-constexpr float kToe = 1.0f / 1024.0f;      // OPSPEC gamma toe (10 bits)
-constexpr float kLog2Toe = -10.0f;          // log2(kToe)
-constexpr float kLn2 = 0.6931471805599453f;
-
-// ---------------------------------------------------------------- per-image op contexts
-struct WbManualCtx {
-    static constexpr int NP = 3;
-    float k[3];
-    __device__ WbManualCtx(const float *p, int n) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) k[c] = p[n * 3 + c] * 5.f;
-    }
-    __device__ f3 fwd(f3 v) const { return {v.b * k[0], v.g * k[1], v.r * k[2]}; }
-    __device__ f3 bwd(f3 x, f3 g, float *acc) const {
-        acc[0] += g.b * x.b;
-        acc[1] += g.g * x.g;
-        acc[2] += g.r * x.r;
-        return {g.b * k[0], g.g * k[1], g.r * k[2]};
-    }
-    __device__ static float pscale(int) { return 5.f; }
-    __device__ static int prow(int n) { return n; }
-};
-
-struct GammaCtx {
-    static constexpr int NP = 1;
-    float g, toe;  // toe = T^(g-1): slope of the linear segment below T
-    __device__ GammaCtx(const float *p, int n) {
-        g = p[n];
-        toe = __builtin_amdgcn_exp2f((g - 1.f) * kLog2Toe);
-    }
-    __device__ float f(float x) const {
-        return x >= kToe ? __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(x)) : x * toe;
-    }
-    __device__ f3 fwd(f3 v) const { return {f(v.b), f(v.g), f(v.r)}; }
-    __device__ float b1(float x, float gy, float *acc) const {
-        if (x >= kToe) {
-            float l2 = __builtin_amdgcn_logf(x);
-            float y = __builtin_amdgcn_exp2f(g * l2);
-            acc[0] += gy * y * (l2 * kLn2);
-            return gy * g * y / x;
-        }
-        acc[0] += gy * x * toe * (kLog2Toe * kLn2);
-        return gy * toe;
-    }
-    __device__ f3 bwd(f3 x, f3 gy, float *acc) const {
-        return {b1(x.b, gy.b, acc), b1(x.g, gy.g, acc), b1(x.r, gy.r, acc)};
-    }
-    __device__ static float pscale(int) { return 1.f; }
-    __device__ static int prow(int n) { return n; }
-};
-
-struct GtmCtx {  // 4 segments; knots from row 0 of p only (tools_origin.py:423)
-    static constexpr int NP = 3;
-    float ys[4], sl[4];
-    __device__ GtmCtx(const float *p, int) {
-        float k[5] = {0.f, p[0], p[1], p[2], 1.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            ys[s] = k[s];
-            sl[s] = (k[s + 1] - k[s]) / 0.25f;
-        }
-    }
-    __device__ float pre(float x, int &seg, float &slope) const {
-        // half-open segments [k/4,(k+1)/4); anything else (x<0, x>=1, NaN) passes through
-        seg = -1;
-        slope = 1.f;
-        float o = x;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float xs = 0.25f * s, xe = 0.25f * (s + 1);
-            if (x >= xs && x < xe) {
-                o = (x - xs) * sl[s] + ys[s];
-                seg = s;
-                slope = sl[s];
-            }
-        }
-        return o;
-    }
-    __device__ float f(float x) const {
-        int s;
-        float m;
-        return clamp01(pre(x, s, m));
-    }
-    __device__ f3 fwd(f3 v) const { return {f(v.b), f(v.g), f(v.r)}; }
-    __device__ float b1(float x, float gy, float *acc) const {
-        int s;
-        float m;
-        float o = pre(x, s, m);
-        float g = gy * gate01(o);
-        float t = (x - 0.25f * s) * 4.f;  // d out / d y_end ; (1-t) = d out / d y_start
-#pragma unroll
-        for (int j = 0; j < 3; ++j)     // knot j is the end of segment j and the start of segment j+1
-            acc[j] += (s == j ? g * t : 0.f) + (s == j + 1 ? g * (1.f - t) : 0.f);
-        return g * m;
-    }
-    __device__ f3 bwd(f3 x, f3 gy, float *acc) const {
-        return {b1(x.b, gy.b, acc), b1(x.g, gy.g, acc), b1(x.r, gy.r, acc)};
-    }
-    __device__ static float pscale(int) { return 1.f; }
-    __device__ static int prow(int) { return 0; }
-};
-
-struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR B G R 1
-    static constexpr int NP = 30;
-    float c[3][10];
-    __device__ WbqCtx(const float *p, int n) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-            for (int j = 0; j < 10; ++j) c[ch][j] = p[n * 30 + ch * 10 + j] * 10.f - 5.f;
-    }
-    __device__ float pre(const float *f, int ch) const {
-        float s = f[0] * c[ch][0];
-#pragma unroll
-        for (int j = 1; j < 10; ++j) s += f[j] * c[ch][j];
-        return s;
-    }
-    __device__ static void feats(f3 v, float *f) {
-        f[0] = v.b * v.b; f[1] = v.g * v.g; f[2] = v.r * v.r;
-        f[3] = v.b * v.g; f[4] = v.b * v.r; f[5] = v.g * v.r;
-        f[6] = v.b; f[7] = v.g; f[8] = v.r; f[9] = 1.f;
-    }
-    __device__ f3 fwd(f3 v) const {
-        float f[10];
-        feats(v, f);
-        return {clamp01(pre(f, 0)), clamp01(pre(f, 1)), clamp01(pre(f, 2))};
-    }
-    __device__ f3 bwd(f3 x, f3 gy, float *acc) const {
-        float f[10];
-        feats(x, f);
-        float g[3] = {gy.b * gate01(pre(f, 0)), gy.g * gate01(pre(f, 1)), gy.r * gate01(pre(f, 2))};
-        f3 o = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-#pragma unroll
-            for (int j = 0; j < 10; ++j) acc[ch * 10 + j] += g[ch] * f[j];
-            o.b += g[ch] * (2.f * x.b * c[ch][0] + x.g * c[ch][3] + x.r * c[ch][4] + c[ch][6]);
-            o.g += g[ch] * (2.f * x.g * c[ch][1] + x.b * c[ch][3] + x.r * c[ch][5] + c[ch][7]);
-            o.r += g[ch] * (2.f * x.r * c[ch][2] + x.b * c[ch][4] + x.g * c[ch][5] + c[ch][8]);
-        }
-        return o;
-    }
-    __device__ static float pscale(int) { return 10.f; }
-    __device__ static int prow(int n) { return n; }
-};
-
-struct Gain3Ctx {  // y_c = clamp(x_c * p[n,c]) : gray-world apply with precomputed gains
-    static constexpr int NP = 3;
-    float k[3];
-    __device__ Gain3Ctx(const float *p, int n) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) k[c] = p[n * 3 + c];
-    }
-    __device__ f3 fwd(f3 v) const { return {clamp01(v.b * k[0]), clamp01(v.g * k[1]), clamp01(v.r * k[2])}; }
-    __device__ f3 bwd(f3 x, f3 g, float *acc) const {
-        g.b *= gate01(x.b * k[0]);
-        g.g *= gate01(x.g * k[1]);
-        g.r *= gate01(x.r * k[2]);
-        acc[0] += g.b * x.b;
-        acc[1] += g.g * x.g;
-        acc[2] += g.r * x.r;
-        return {g.b * k[0], g.g * k[1], g.r * k[2]};
-    }
-    __device__ static float pscale(int) { return 1.f; }
-    __device__ static int prow(int n) { return n; }
-};
+using namespace risp_ops;
 
 // ---------------------------------------------------------------- planar BGR kernels
 // grid = (blocks per image, N); each thread walks float4 slots of one image.
@@ -330,13 +166,6 @@ struct ChainArgs {
     float *outs[RISP_MAX_CHAIN];
 };
 
-template <class Ctx, int NPX>
-__device__ __forceinline__ void apply_all(const float *p, int n, f3 *px) {
-    const Ctx ctx(p, n);
-#pragma unroll
-    for (int i = 0; i < NPX; ++i) px[i] = ctx.fwd(px[i]);
-}
-
 template <int QW>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     const int n = blockIdx.y, W = a.W, H = a.H, wq = W / (2 * QW);
@@ -366,15 +195,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     for (int k = k0; k < a.n_ops; ++k) {
         const int op = a.ops[k];
         const float *p = a.params[k];
-        f3 *flat = &px[0][0];
-        switch (op) {
-            case RISP_OP_WB_MANUAL: apply_all<WbManualCtx, 4 * QW>(p, n, flat); break;
-            case RISP_OP_GAMMA: apply_all<GammaCtx, 4 * QW>(p, n, flat); break;
-            case RISP_OP_GTM_MANUAL: apply_all<GtmCtx, 4 * QW>(p, n, flat); break;
-            case RISP_OP_WB_QUADRATIC: apply_all<WbqCtx, 4 * QW>(p, n, flat); break;
-            case RISP_OP_GAIN3: apply_all<Gain3Ctx, 4 * QW>(p, n, flat); break;
-            default: break;  // SKIP, DEMOSAIC_NEAREST (already applied)
-        }
+        apply_op<4 * QW>(op, p, n, &px[0][0]);
         float *o = a.outs[k];
         if (o == nullptr) continue;
 #pragma unroll

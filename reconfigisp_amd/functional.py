@@ -235,6 +235,42 @@ def chain_forward(x, ops, params):
     return ChainPlan(x, ops, params).launch()
 
 
+class BilateralChainPlan:
+    """[nearest demosaic ->] bilateral -> element-wise chain as ONE launch (risp_bilateral_chain_fwd).
+    ``outs`` lists the stage outputs in pipeline order: [demosaic,] bilateral, chain stages..."""
+
+    def __init__(self, x, from_bayer, window, sigma_color, sigma_space, max_window, ops, params):
+        x = _dev(x, 'img')
+        n, cin, h, w = x.shape
+        if cin != (1 if from_bayer else 3) or h % 2 or w % 4:
+            raise ValueError('fused stencil segment: unsupported input %s' % (tuple(x.shape),))
+        new = lambda: torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
+        self.x = x
+        self.dem = new() if from_bayer else None
+        self.bil = new()
+        self.outs = ([self.dem] if from_bayer else []) + [self.bil]
+        cur, chain_outs = self.bil, []
+        for op in ops:
+            if op != OP_SKIP:
+                cur = new()
+            chain_outs.append(cur)
+        self.outs += chain_outs
+        if window.dtype != torch.int32 or not window.is_cuda:
+            raise ValueError('window must be an int32 device tensor')
+        self.keep = [window.contiguous(), _dev(sigma_color), _dev(sigma_space)] + \
+                    [_dev(p) if p is not None else None for p in params]
+        win, sc, ss = self.keep[:3]
+        self._args = (_p(x), int(from_bayer), _p(self.dem), _p(self.bil), _p(win), _p(sc), _p(ss), int(max_window),
+                      len(ops), (C.c_int * max(1, len(ops)))(*ops),
+                      L.ptr_array([p.data_ptr() if p is not None else None for p in self.keep[3:]] or [None]),
+                      L.ptr_array([o.data_ptr() if op != OP_SKIP else None for o, op in zip(chain_outs, ops)] or [None]),
+                      n, h, w)
+
+    def launch(self):
+        L.call('risp_bilateral_chain_fwd', *self._args, _stream())
+        return self.outs
+
+
 class _HipImpl:
     """The product implementation: every op runs in libreconfigisp_hip.so."""
 
@@ -363,23 +399,89 @@ def path14l_bgr(x, module):
     return _IMPL.path14l_bgr(x, module)
 
 
-def _tier2(name):
-    raise NotImplementedError(
-        "reconfigisp_amd: the classical %s kernels of OriginUniversal (tools_origin.py:445-804) are "
-        'SURVEY.md section 8f row 1 ("next") and are not built yet' % name)
+# ---------------------------------------------------------------------------
+# classical "Origin" kernels (0..255 domain, non-differentiable)
+# ---------------------------------------------------------------------------
+def _vec(v, n, device, dtype=torch.float32):
+    """per-image plugin parameter (numpy array / tensor / scalar) -> contiguous (N,) device tensor"""
+    t = torch.as_tensor(v).detach().to(device=device, dtype=dtype).reshape(-1)
+    if t.numel() == 1 and n > 1:
+        t = t.repeat(n)
+    if t.numel() != n:
+        raise ValueError('expected %d per-image values, got %d' % (n, t.numel()))
+    return t.contiguous()
 
 
-def origin_whiteworld(x, ratio):
-    _tier2('white-world')
+def _check_odd(name, v):
+    v = int(v)
+    if v < 1 or v > 15 or v % 2 == 0:
+        raise ValueError('%s must be an odd size in 1..15, got %d' % (name, v))
+    return v
 
 
-def origin_demosaic(x, option):
-    _tier2(option + ' demosaic')
+def origin_demosaic(x, option, scales=(1.0, 1.0)):
+    x = _dev(x.detach(), 'img')
+    if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 2 or x.shape[3] % 2:
+        raise ValueError('expected a (N,1,H,W) RGGB mosaic with even H, W; got %s' % (tuple(x.shape),))
+    n, _, h, w = x.shape
+    y = torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
+    L.call('risp_origin_demosaic', _p(x), _p(y), int(option == 'laplacian'), n, h, w, scales[0], scales[1], _stream())
+    return y
 
 
-def origin_tonemap(x, option, params):
-    _tier2(option + ' tone-mapping')
+_TONEMAP = {'reinhard': (0, 'white_point', 'middle_grey'), 'crysisengine': (1, 'lum_adapted', None),
+            'filmic': (2, 'white_point', 'exposure_bias')}
 
 
-def origin_denoise(x, option, params):
-    _tier2(option + ' denoise')
+def origin_tonemap(x, option, params, scales=(1.0, 1.0)):
+    x = _dev(x.detach(), 'img')
+    _check_bgr(x)
+    n, hw = x.shape[0], x.shape[2] * x.shape[3]
+    mode, ka, kb = _TONEMAP[option]
+    a = _vec(params[ka], n, x.device)
+    b = _vec(params[kb], n, x.device) if kb else None
+    y = torch.empty_like(x)
+    ws = torch.empty(5 * n, device=x.device, dtype=torch.float32)
+    L.call('risp_origin_tonemap', _p(x), _p(y), mode, _p(a), _p(b), None, _p(ws), n, hw, scales[0], scales[1],
+           _stream())
+    return y
+
+
+def origin_whiteworld(x, ratio, scales=(1.0, 1.0)):
+    x = _dev(x.detach(), 'img')
+    _check_bgr(x)
+    n, hw = x.shape[0], x.shape[2] * x.shape[3]
+    stats, _ = channel_stats(x, want_arg=False)
+    y = torch.empty_like(x)
+    ws = torch.empty(5 * n, device=x.device, dtype=torch.float32)
+    r = _vec(ratio, n, x.device)          # keep every operand alive until the launch is enqueued
+    L.call('risp_origin_tonemap', _p(x), _p(y), 3, _p(r), None, _p(stats), _p(ws), n, hw, scales[0], scales[1],
+           _stream())
+    return y
+
+
+def origin_denoise(x, option, params, scales=(1.0, 1.0)):
+    x = _dev(x.detach(), 'img')
+    _check_bgr(x)
+    n, _, h, w = x.shape
+    y = torch.empty_like(x)
+    if option == 'median':
+        L.call('risp_origin_median', _p(x), _p(y), _check_odd('median size', params['size']), n, h, w, scales[0],
+               scales[1], _stream())
+    elif option == 'bilateral':
+        win = _vec(params['window_length'], n, x.device, torch.int32)
+        sc, ss = _vec(params['sigma_color'], n, x.device), _vec(params['sigma_space'], n, x.device)
+        wmax = _check_odd('window_length', params.get('max_window') or win.max().item())
+        L.call('risp_origin_bilateral', _p(x), _p(y), _p(win), _p(sc), _p(ss), wmax, n, h, w, scales[0], scales[1],
+               _stream())
+    elif option == 'fastnlm':
+        blk = _vec(params['block_size'], n, x.device, torch.int32)
+        srch = _vec(params['search_block'], n, x.device, torch.int32)
+        dec = _vec(params['decay_factor'], n, x.device)
+        bmax = _check_odd('block_size', params.get('max_block') or blk.max().item())
+        smax = _check_odd('search_block', params.get('max_search') or srch.max().item())
+        L.call('risp_origin_fastnlm', _p(x), _p(y), _p(blk), _p(srch), _p(dec), bmax, smax, n, h, w, scales[0],
+               scales[1], _stream())
+    else:
+        raise ValueError('unknown denoiser %r' % (option,))
+    return y

@@ -10,8 +10,7 @@ class WhiteBalance:
     def run(self, img, option, params):
         x = to_nchw(img)
         if option == 'manual':
-            # gain (N,3) in [0,5], BGR order; the HIP kernel takes the [0,1] parameter and scales by 5
-            y = F.wb_manual(x, params['gain'] / 5.0)
+            y = F.wb_manual(x, params['gain'])     # gain (N,3) in [0,5], BGR order
         elif option == 'grayworld':
             y = F.grayworld(x)
         elif option == 'whiteworld':

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libreconfigisp_hip.so')
 _f = C.c_void_p        # device float*
 _i = C.c_int
 _z = C.c_size_t
+_fl = C.c_float
 _s = C.c_void_p        # hipStream_t
 _pp = C.POINTER(C.c_void_p)
 
@@ -57,6 +58,12 @@ SIGNATURES = {
     'risp_plane_sums': (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
     'risp_tile_gather': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
     'risp_tile_blend': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
+    'risp_origin_demosaic': (_i, [_f, _f, _i, _i, _i, _i, _fl, _fl, _s]),
+    'risp_origin_bilateral': (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _fl, _s]),
+    'risp_origin_median': (_i, [_f, _f, _i, _i, _i, _i, _fl, _fl, _s]),
+    'risp_origin_fastnlm': (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _s]),
+    'risp_origin_tonemap': (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _fl, _fl, _s]),
+    'risp_bilateral_chain_fwd': (_i, [_f, _i, _f, _f, _f, _f, _f, _i, _i, C.POINTER(_i), _pp, _pp, _i, _i, _i, _s]),
     'risp_sse_uint8': (_i, [_f, _f, _f, _z, _s]),
 }
 

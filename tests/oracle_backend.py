@@ -13,7 +13,7 @@ def _sd(module):
 
 class OracleImpl:
     skip = staticmethod(lambda x, p=None: x)
-    wb_manual = staticmethod(O.wb_manual)
+    wb_manual = staticmethod(lambda x, gain: x * gain.view(-1, 3, 1, 1))     # the seam takes the gain (= 5p)
     gamma = staticmethod(O.gamma_manual)
     gtm_manual = staticmethod(O.gtm_manual)
     wb_quadratic = staticmethod(O.wb_quadratic)
@@ -35,3 +35,8 @@ class OracleImpl:
     srcnn_demosaic = staticmethod(lambda x, m: O.srcnn_demosaic(x, _sd(m)))
     path14l_bayer = staticmethod(lambda x, m: O.path14l_bayer(x, _sd(m)))
     path14l_bgr = staticmethod(lambda x, m: O.path14l_bgr(x, _sd(m)))
+
+    origin_demosaic = staticmethod(O.origin_demosaic)
+    origin_tonemap = staticmethod(O.origin_tonemap)
+    origin_whiteworld = staticmethod(O.origin_whiteworld)
+    origin_denoise = staticmethod(O.origin_denoise)

@@ -1,0 +1,145 @@
+"""GPU: the classical "Origin" stencil / tone kernels vs the CPU oracle's OPSPEC (build-defined, parity
+unpinned against the absent plugin), through the plugin-shaped modules and OriginUniversal.
+
+Outputs are 8-bit codes: a last-ulp difference in an exp() or a division can move a value across a
+rounding boundary, so the bar is: no code differs by more than 1, and at most 0.2 % of the codes differ
+at all (index maps / medians are exact)."""
+import numpy as np
+import pytest
+import torch
+
+import isp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.random(shape).astype(np.float32))
+
+
+def codes_close(got, ref, what, exact=False):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    assert got.shape == ref.shape, what
+    assert torch.equal(got, got.round()) and got.min() >= 0 and got.max() <= 255, what + ': not 8-bit codes'
+    d = (got - ref).abs()
+    frac = (d > 0).float().mean().item()
+    assert d.max().item() <= (0 if exact else 1), '%s: max code difference %g' % (what, d.max().item())
+    assert frac <= (0 if exact else 2e-3), '%s: %.4f%% of the codes differ' % (what, 100 * frac)
+
+
+@pytest.mark.parametrize('hw', [(8, 8), (34, 50), (256, 256)])
+@pytest.mark.parametrize('option', ['bilinear', 'laplacian'])
+def test_origin_demosaic(option, hw):
+    import reconfigisp_amd.functional as F
+    x = torch.floor(rnd(2, 1, *hw, seed=1) * 1023) / 1023 * 255          # 10-bit codes scaled to 0..255
+    codes_close(F.origin_demosaic(x.cuda(), option), O.origin_demosaic(x, option), option)
+    flat = torch.full((1, 1, 8, 8), 77.0)
+    assert F.origin_demosaic(flat.cuda(), option).unique().tolist() == [77.0]   # constant in -> constant out
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (33 * 2, 45 * 2)])
+def test_origin_tonemaps_and_whiteworld(hw):
+    import reconfigisp_amd.functional as F
+    x = rnd(3, 3, *hw, seed=2) * 255
+    p = {'white_point': np.array([0.5, 0.9, 0.1], np.float32), 'middle_grey': np.array([0.5, 0.2, 0.8], np.float32),
+         'lum_adapted': np.array([0.5, 0.05, 0.95], np.float32), 'exposure_bias': np.array([5.5, 1.0, 10.0], np.float32)}
+    for option in ('reinhard', 'crysisengine', 'filmic'):
+        codes_close(F.origin_tonemap(x.cuda(), option, p), O.origin_tonemap(x, option, p), option)
+    ratio = np.array([0.5, 0.0, 1.0], np.float32)
+    codes_close(F.origin_whiteworld(x.cuda(), ratio), O.origin_whiteworld(x, ratio), 'whiteworld')
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (40, 70)])
+def test_origin_denoisers(hw):
+    import reconfigisp_amd.functional as F
+    x = rnd(2, 3, *hw, seed=3) * 255
+    for size in (3, 9):
+        codes_close(F.origin_denoise(x.cuda(), 'median', {'size': size}), O.origin_denoise(x, 'median', {'size': size}),
+                    'median %d' % size, exact=True)
+    bp = {'window_length': torch.tensor([3, 5]), 'sigma_color': torch.tensor([50.5, 12.0]),
+          'sigma_space': torch.tensor([50.5, 1.5])}
+    codes_close(F.origin_denoise(x.cuda(), 'bilateral', bp), O.origin_denoise(x, 'bilateral', bp), 'bilateral')
+    npar = {'block_size': torch.tensor([3, 3]), 'search_block': torch.tensor([3, 5]),
+            'decay_factor': torch.tensor([50.5, 8.0])}
+    codes_close(F.origin_denoise(x.cuda(), 'fastnlm', npar), O.origin_denoise(x, 'fastnlm', npar), 'fastnlm')
+    with pytest.raises(ValueError, match='odd size'):
+        F.origin_denoise(x.cuda(), 'median', {'size': 4})
+
+
+def test_origin_universal_test_yaml_pipeline():
+    """The shipped test YAMLs select OriginUniversal (options/test/SID_test.yml:28:
+    Bayer_01_Demosaic_03_sRGB_01_13_11); here with every classical op in one pipeline, through the
+    reference-shaped wrappers (x255 / detach / plugin.run / /255), vs the oracle's restatement."""
+    from reconfigisp_amd.codes.models.modules.origin_universal import OriginUniversal
+    arch = 'Bayer_02_Demosaic_03_sRGB_07_06_11_01_02_08_09_04_03_14'
+    net = OriginUniversal(module_path=None, architecture=arch).cuda().eval()
+    bay, _ = O.synthetic_raw(2, 32, 48, seed=5)
+    with torch.no_grad():
+        y = net(bay.cuda())
+    names = O.parse_architecture(arch)
+    assert names == ['skip', 'laplacian', 'bilateral', 'whiteworld', 'wbmanual', 'gamma', 'reinhard', 'median',
+                     'fastnlm', 'filmic', 'crysisengine', 'gtmmanual']
+    sig = lambda k: torch.sigmoid(torch.tensor(O.PARAM_INIT[k])).repeat(2, 1)
+    x = bay
+    for k, got in zip(names, net.intermediate_results):
+        p = sig(k) if O.PARAM_INIT[k] else None
+        if k == 'skip':
+            ref = x
+        elif k == 'laplacian':
+            ref = O.origin_demosaic(x * 255, 'laplacian') / 255
+        elif k == 'bilateral':   # window: .int() before *7 -> always 3 (tools_origin.py:698)
+            ref = O.origin_denoise(x * 255, 'bilateral', {'window_length': (p[:, 0].int() * 7) * 2 + 3,
+                                                           'sigma_color': p[:, 1] * 99 + 1, 'sigma_space': p[:, 2] * 99 + 1}) / 255
+        elif k == 'whiteworld':
+            ref = O.origin_whiteworld(x * 255, p[:, 0].numpy()) / 255
+        elif k == 'reinhard':
+            ref = O.origin_tonemap(x * 255, 'reinhard', {'white_point': p[:, 0].numpy(), 'middle_grey': p[:, 1].numpy()}) / 255
+        elif k == 'median':
+            ref = O.origin_denoise(x * 255, 'median', {'size': 2 * int(p[0, 0].item() * 7) + 3}) / 255
+        elif k == 'fastnlm':
+            ref = O.origin_denoise(x * 255, 'fastnlm', {'block_size': (p[:, 0].int() * 7) * 2 + 3,
+                                                         'search_block': (p[:, 1].int() * 7) * 2 + 3,
+                                                         'decay_factor': p[:, 2] * 99 + 1}) / 255
+        elif k == 'filmic':
+            ref = O.origin_tonemap(x * 255, 'filmic', {'white_point': p[:, 0].numpy(),
+                                                       'exposure_bias': p[:, 1].numpy() * 9. + 1.}) / 255
+        elif k == 'crysisengine':
+            ref = O.origin_tonemap(x * 255, 'crysisengine', {'lum_adapted': p[:, 0].numpy()}) / 255
+        else:
+            ref = O.apply_op(k, x, p)
+        d = (got.cpu() - ref).abs()
+        assert d.max().item() <= 1.01 / 255 and (d > 1e-5).float().mean().item() < 5e-3, 'stage %s: %g' % (k, d.max().item())
+        x = got.cpu()            # continue from the GPU result so single-code flips do not cascade
+
+
+@pytest.mark.parametrize('arch,cls', [('Demosaic_01_sRGB_07_11_01_14', 'OriginUniversal'),
+                                      ('Bayer_02_Demosaic_01_sRGB_11_07_01_13', 'OriginUniversal'),
+                                      ('Demosaic_01_sRGB_07', 'OriginUniversal')])
+@pytest.mark.parametrize('seed', range(6))
+def test_fused_stencil_segment_equals_unfused(arch, cls, seed):
+    """risp_bilateral_chain_fwd ([demosaic ->] bilateral -> element-wise tail, one launch) must reproduce
+    the stage-by-stage path (reference-shaped wrappers: x255, plugin.run, /255) bit for bit."""
+    from reconfigisp_amd.codes.models import networks
+    opt = {'network_G': {'which_model_G': cls, 'architecture': arch, 'module_path': None}}
+    net = networks.define_G(opt).cuda().eval()
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for p in net.all_params:
+            if p.numel():
+                p.add_(torch.randn_like(p) * 0.3)
+    bay, _ = O.synthetic_raw(3, 48, 80, seed=6 + seed)
+    x = bay.cuda()
+    with torch.no_grad():
+        y_fused = net(x).clone()
+        fused = [m.clone() for m in net.intermediate_results]
+    pars = net._build_stage_params(3)
+    cur, unfused = x, []
+    with torch.no_grad():
+        for op, par in zip(net.all_modules, pars):
+            cur = op(cur, par)
+            unfused.append(cur)
+    assert len(fused) == len(unfused)
+    for k, (a, b) in enumerate(zip(fused, unfused)):
+        assert torch.equal(a, b), 'stage %d (%s): max diff %g' % (k, net.step_names[k], (a - b).abs().max().item())
+    assert torch.equal(y_fused, unfused[-1])

@@ -45,7 +45,7 @@ def test_pointwise_vs_oracle(F, shape):
     n = shape[0]
     x = rnd(*shape, seed=1, lo=-0.15, hi=1.2)
     gy = rnd(*shape, seed=2, lo=-0.5, hi=0.5)
-    _fwd_bwd(F.wb_manual, O.wb_manual, x, rnd(n, 3, seed=3), gy, 'wb_manual')
+    _fwd_bwd(lambda a, p: F.wb_manual(a, p * 5), O.wb_manual, x, rnd(n, 3, seed=3), gy, 'wb_manual')
     _fwd_bwd(F.gamma, O.gamma_manual, x, rnd(n, 1, seed=4, lo=0.2, hi=0.9), gy, 'gamma')
     _fwd_bwd(F.gtm_manual, O.gtm_manual, x, rnd(n, 3, seed=5), gy, 'gtm')
     _fwd_bwd(F.wb_quadratic, O.wb_quadratic, x, rnd(n, 30, seed=6, lo=0.4, hi=0.6), gy, 'wbq')
@@ -99,7 +99,7 @@ def test_chain_matches_per_op_and_oracle(F):
     pq = rnd(n, 30, seed=13, lo=0.45, hi=0.55)
     ops = [F.OP_SKIP, F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL, F.OP_WB_QUADRATIC]
     # SKIP before the demosaic is resolved by the host; the chain itself starts at the demosaic
-    outs = F.chain_forward(bay.cuda(), ops[1:], [None, pw.cuda(), pg.cuda(), pt.cuda(), pq.cuda()])
+    outs = F.chain_forward(bay.cuda(), ops[1:], [None, (pw * 5).cuda(), pg.cuda(), pt.cuda(), pq.cuda()])
     ref = O.demosaic_nearest(bay)
     assert torch.equal(outs[0].cpu(), ref)
     for o, fn, p in zip(outs[1:], (O.wb_manual, O.gamma_manual, O.gtm_manual, O.wb_quadratic), (pw, pg, pt, pq)):
@@ -111,7 +111,7 @@ def test_chain_matches_per_op_and_oracle(F):
     assert_close(o2[1], O.gamma_manual(O.demosaic_nearest(bay2), torch.full((1, 1), 0.5)))
     # BGR-input chain with a leading skip aliasing its input
     xb = rnd(2, 3, 8, 8, seed=15).cuda()
-    o3 = F.chain_forward(xb, [F.OP_SKIP, F.OP_WB_MANUAL], [None, sig(O.PARAM_INIT['wbmanual'])[:2].cuda()])
+    o3 = F.chain_forward(xb, [F.OP_SKIP, F.OP_WB_MANUAL], [None, (sig(O.PARAM_INIT['wbmanual'])[:2] * 5).cuda()])
     assert o3[0].data_ptr() == xb.data_ptr()
     assert_close(o3[1], O.wb_manual(xb.cpu(), sig(O.PARAM_INIT['wbmanual'])[:2]))
 
