@@ -8,8 +8,12 @@ data-path collective: every image is independent).
 
 A step = one forward of the pipeline over one batch of 64 synthetic 256x256 RGGB patches that is
 already resident in HBM.  Workloads (SURVEY.md section 8d / BASELINE.md):
-  hbm (headline `value`)  Bayer_02_Demosaic_01_sRGB_11_01_14 = skip -> nearest demosaic -> WbManual
-                          -> Gamma -> GtmManual, every stage output materialised; HBM roofline
+  isp (headline `value`)  Demosaic_01_sRGB_07_11_01_14 = nearest demosaic -> bilateral denoise ->
+                          WbManual -> Gamma -> GtmManual (OriginUniversal; the literal demosaic / denoise /
+                          white-balance / gamma / tone-map ordering), every stage output materialised,
+                          ONE fused launch (risp_bilateral_chain_fwd); HBM roofline
+  pointwise (`extra.pointwise_*`)  Bayer_02_Demosaic_01_sRGB_11_01_14 = skip -> nearest demosaic ->
+                          WbManual -> Gamma -> GtmManual (no neighbourhood stage), one risp_chain_fwd launch
   cnn (`extra.cnn_*`)     Bayer_01_Demosaic_03_sRGB_01_13_11 (options/train/SID_isp.yml:28) =
                           Path-Restore-Bayer -> proxy demosaic -> Gamma -> WbQuadratic -> WbManual;
                           fp32-MFMA roofline
@@ -33,17 +37,18 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 pea
 ARCH_HBM = 'Bayer_02_Demosaic_01_sRGB_11_01_14'           # element-wise only: one fused launch
 ARCH_DENOISE = 'Demosaic_01_sRGB_07_11_01_14'             # nearest demosaic, bilateral, WbManual, Gamma, GtmManual
 ARCH_CNN = 'Bayer_01_Demosaic_03_sRGB_01_13_11'
-# algorithmic HBM bytes per pixel of the fused hbm pipeline: read the mosaic once (4 B) and write each
-# of the four materialised BGR stage outputs (4 x 12 B); `skip` aliases its input (0 B).  SURVEY 8d's
-# stage-by-stage figure (88 B/pix) also counts the three intermediate re-reads the fused launch avoids.
-BYTES_PER_PIX_FUSED = 4 + 4 * 12
+# algorithmic HBM bytes per pixel of a fused launch: read the mosaic once (4 B) and write each materialised
+# BGR stage output (12 B each); `skip` aliases its input (0 B).  SURVEY 8d's stage-by-stage figures
+# (112 / 88 B/pix) also count the intermediate re-reads that the fused launches avoid.
+BYTES_PER_PIX_ISP = 4 + 5 * 12          # demosaic, bilateral, wb, gamma, tone curve outputs
+BYTES_PER_PIX_FUSED = 4 + 4 * 12        # point-wise pipeline: demosaic, wb, gamma, tone curve outputs
 BYTES_PER_PIX_UNFUSED = 88
 FLOP_PER_PIX_CNN = 239680      # 223488 (Path14lBayer) + 16192 (SRCNNDemosaic)
 
 
-def build_pipeline(arch, device):
+def build_pipeline(arch, device, which='IspUniversal'):
     from reconfigisp_amd.codes.models import networks
-    opt = {'network_G': {'which_model_G': 'IspUniversal', 'architecture': arch, 'module_path': None,
+    opt = {'network_G': {'which_model_G': which, 'architecture': arch, 'module_path': None,
                          'individual_module_paths': [None] * 8}}
     torch.manual_seed(10)
     net = networks.define_G(opt).to(device)
@@ -77,16 +82,23 @@ def timed(fn, steps, warmup, device, world):
     return wall, dev_ms / steps
 
 
-def kernel_time_ms(net, bay, reps, device):
-    """Average launch duration of the dominant kernel (the fused chain), measured live with a HIP
-    event pair on the launch stream around `reps` back-to-back launches issued straight through the
-    C ABI (one ctypes call each, so the stream never drains and the figure is kernel + the ~1.5 us
-    same-stream launch boundary, not host time)."""
+def kernel_time_ms(net, bay, reps, device, isp):
+    """Average launch duration of the dominant kernel (the one fused launch a step consists of), measured
+    live with a HIP event pair on the launch stream around `reps` back-to-back launches issued straight
+    through the C ABI (one ctypes call each, so the stream never drains and the figure is kernel + the
+    ~1.5 us same-stream launch boundary, not host time)."""
     import reconfigisp_amd.functional as F
     n = bay.shape[0]
-    pars = list(net._stage_params(n))
-    pars[2] = pars[2] * 5        # WbManual: the kernel takes the gain (params * 5)
-    plan = F.ChainPlan(bay, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], pars[1:])
+    with torch.no_grad():
+        pars = list(net._stage_params(n))
+    if isp:     # demosaic | bilateral | wbmanual, gamma, gtmmanual
+        d = net.all_modules[1]._params(pars[1].detach(), {})
+        plan = F.BilateralChainPlan(bay, True, d['window_length'].to(torch.int32), d['sigma_color'], d['sigma_space'],
+                                    int(d['window_length'].max().item()),
+                                    [F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], [pars[2] * 5, pars[3], pars[4]])
+    else:       # skip | demosaic, wbmanual, gamma, gtmmanual (the kernel takes the gain = params * 5)
+        plan = F.ChainPlan(bay, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL],
+                           [None, pars[2] * 5, pars[3], pars[4]])
     for _ in range(5):
         plan.launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -99,20 +111,20 @@ def kernel_time_ms(net, bay, reps, device):
     return e0.elapsed_time(e1) / reps
 
 
-def measured_traffic(pix_per_step):
+def measured_traffic(algorithmic_bytes):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only when
     they were taken on this very workload; otherwise null."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             t = json.load(f)
-        if t.get('algorithmic_bytes_per_launch') == BYTES_PER_PIX_FUSED * pix_per_step:
+        if t.get('algorithmic_bytes_per_launch') == algorithmic_bytes:
             return t['traffic_bytes_per_launch']
     except (OSError, ValueError, KeyError):
         pass
     return None
 
 
-def cpu_baseline(bay, arch, budget_s=15.0):
+def cpu_baseline(bay, arch, budget_s=10.0):
     """The CPU oracle (restatement of the reference's torch-CPU path) on a bounded sample of the same
     batch.  The thread count is the best of a short sweep (torch's default of one thread per core
     oversubscribes these small element-wise ops on a 256-core host)."""
@@ -121,23 +133,23 @@ def cpu_baseline(bay, arch, budget_s=15.0):
     cores = os.cpu_count() or 1
     names = O.parse_architecture(arch)
     raw = [torch.tensor(O.PARAM_INIT[k]) for k in names]
-    n = min(16, bay.shape[0])
+    n = min(4, bay.shape[0])
     sample = bay[:n].cpu()
-    run = lambda: O.fixed_pipeline(sample, names, raw, [None] * len(names))
+    run = lambda: O.fixed_pipeline(sample, names, raw, [None] * len(names), origin=True)
 
     def rate(threads, seconds, max_reps):
         torch.set_num_threads(threads)
         run()
         reps, t0 = 0, time.perf_counter()
-        while reps < 2 or (time.perf_counter() - t0 < seconds and reps < max_reps):
+        while reps < 1 or (time.perf_counter() - t0 < seconds and reps < max_reps):
             run()
             reps += 1
         return reps, time.perf_counter() - t0
 
     with torch.no_grad():
         best, best_rate = 1, 0.0
-        for th in sorted({1, 8, 16, 32, 64, cores} & set(range(1, cores + 1))):
-            reps, dt = rate(th, 0.75, 50)
+        for th in sorted({8, 16, 32, 64} & set(range(1, cores + 1))) or [cores]:
+            reps, dt = rate(th, 0.5, 20)
             if reps / dt > best_rate:
                 best, best_rate = th, reps / dt
         reps, dt = rate(best, budget_s, 2000)
@@ -175,17 +187,26 @@ def main():
     pix_per_step = args.batch * args.size * args.size
 
     from reconfigisp_amd.graphs import GraphedForward
-    net = build_pipeline(ARCH_HBM, device)
+    net = build_pipeline(ARCH_DENOISE, device, 'OriginUniversal')
     step = GraphedForward(net, bay) if not args.eager else (lambda: net(bay))
     with torch.no_grad():
         wall, dev_ms = timed(lambda: step(), args.steps, args.warmup, device, world)
-        kernel_ms = kernel_time_ms(net, bay, max(args.steps, 100), device)
+        kernel_ms = kernel_time_ms(net, bay, max(args.steps, 100), device, True)
     value = world * pix_per_step * args.steps / wall / 1e6
-    achieved = BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms * 1e-3) / 1e9
+    achieved = BYTES_PER_PIX_ISP * pix_per_step / (kernel_ms * 1e-3) / 1e9
 
-    extra = {'hbm_unfused_equiv_GBs': round(BYTES_PER_PIX_UNFUSED * pix_per_step / (kernel_ms * 1e-3) / 1e9, 1),
-             'kernel_ms': round(kernel_ms, 5), 'stream_ms_per_step': round(dev_ms, 5),
-             'launch': 'eager' if args.eager else 'hipGraph replay'}
+    pw = build_pipeline(ARCH_HBM, device)
+    pstep = GraphedForward(pw, bay) if not args.eager else (lambda: pw(bay))
+    with torch.no_grad():
+        wall_p, dev_ms_p = timed(lambda: pstep(), args.steps, args.warmup, device, world)
+        kernel_ms_p = kernel_time_ms(pw, bay, max(args.steps, 100), device, False)
+    extra = {'kernel_ms': round(kernel_ms, 5), 'stream_ms_per_step': round(dev_ms, 5),
+             'launch': 'eager' if args.eager else 'hipGraph replay',
+             'pointwise_arch': ARCH_HBM,
+             'pointwise_MPix_s': round(world * pix_per_step * args.steps / wall_p / 1e6, 1),
+             'pointwise_kernel_ms': round(kernel_ms_p, 5),
+             'pointwise_hbm_GBs': round(BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms_p * 1e-3) / 1e9, 1),
+             'pointwise_hbm_frac': round(BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if not args.no_cnn:
         cnn = build_pipeline(ARCH_CNN, device)
         steps_c = max(3, args.steps // 20)
@@ -203,17 +224,18 @@ def main():
             'unit': 'MPix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(wall / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'batch=%d %dx%d Bayer per GPU, 5-stage fixed ISP forward %s (skip, nearest '
-                                   'demosaic, WbManual, Gamma, GtmManual), all stage outputs materialised'
-                                   % (args.batch, args.size, args.size, ARCH_HBM),
+            'config': {'workload': 'batch=%d %dx%d Bayer per GPU, 5-stage fixed ISP forward %s (nearest demosaic, '
+                                   'bilateral denoise, WbManual, Gamma, GtmManual; OriginUniversal), all stage '
+                                   'outputs materialised' % (args.batch, args.size, args.size, ARCH_DENOISE),
                        'global_batch': args.batch * world, 'parallelism': 'batch-sharded x%d, no collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': measured_traffic(pix_per_step),
-                         'kernel': 'chain_kernel<2> (risp_chain_fwd): one launch per step, %d B/pix algorithmic' % BYTES_PER_PIX_FUSED},
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': measured_traffic(BYTES_PER_PIX_ISP * pix_per_step),
+                         'kernel': 'bilateral_chain_kernel<true,1> (risp_bilateral_chain_fwd): one launch per step, '
+                                   '%d B/pix algorithmic' % BYTES_PER_PIX_ISP},
             'extra': extra,
         }
         if not args.no_cpu and world == 1:
-            line['cpu_baseline'] = cpu_baseline(bay_cpu, ARCH_HBM)
+            line['cpu_baseline'] = cpu_baseline(bay_cpu, ARCH_DENOISE)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -55,26 +55,67 @@ __global__ __launch_bounds__(256) void bilateral_chain_kernel(const FusedArgs a)
     const int n = blockIdx.z, x0 = blockIdx.x * FX, y0 = blockIdx.y * FY;
     const size_t plane = (size_t)H * W;
 
-    // ---- stage the BGR halo tile, in 8-bit units
+    // ---- stage the BGR halo tile, in 8-bit units.  With a compile-time radius all global loads of the
+    // thread are issued before the first LDS write (one memory round trip per block, not one per element).
     if (FROM_BAYER) {
         const float *bay = a.in + (size_t)n * plane;
-        for (int idx = threadIdx.x; idx < per; idx += 256) {
+        auto fetch = [&](int idx, float &b, float &g, float &r) {
             const int ty = idx / tw, tx = idx - ty * tw;
             const int gy = refl(y0 + ty - R, H), gx = refl(x0 + tx - R, W);
             const int qy = gy & ~1, qx = gx & ~1;                       // quad origin
-            const float r = bay[(size_t)qy * W + qx];
-            const float g = bay[(size_t)(qy + (gy & 1)) * W + qx + 1 - (gy & 1)];   // G1 on even rows, G2 on odd rows
-            const float b = bay[(size_t)(qy + 1) * W + qx + 1];
-            lds[idx] = b * 255.f;
-            lds[per + idx] = g * 255.f;
-            lds[2 * per + idx] = r * 255.f;
+            r = bay[(size_t)qy * W + qx];
+            g = bay[(size_t)(qy + (gy & 1)) * W + qx + 1 - (gy & 1)];   // G1 on even rows, G2 on odd rows
+            b = bay[(size_t)(qy + 1) * W + qx + 1];
+        };
+        if (RT > 0) {
+            constexpr int PER = (FX + 2 * RT) * (FY + 2 * RT), NIT = (PER + 255) / 256;
+            float vb[NIT], vg[NIT], vr[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                vb[i] = vg[i] = vr[i] = 0.f;
+                if (idx < PER) fetch(idx, vb[i], vg[i], vr[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                if (idx < PER) {
+                    lds[idx] = vb[i] * 255.f;
+                    lds[PER + idx] = vg[i] * 255.f;
+                    lds[2 * PER + idx] = vr[i] * 255.f;
+                }
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < per; idx += 256) {
+                float b, g, r;
+                fetch(idx, b, g, r);
+                lds[idx] = b * 255.f;
+                lds[per + idx] = g * 255.f;
+                lds[2 * per + idx] = r * 255.f;
+            }
         }
     } else {
         const float *img = a.in + (size_t)n * 3 * plane;
-        for (int idx = threadIdx.x; idx < 3 * per; idx += 256) {
+        auto fetch1 = [&](int idx) {
             const int c = idx / per, rem = idx - c * per;
             const int ty = rem / tw, tx = rem - ty * tw;
-            lds[idx] = img[(size_t)c * plane + (size_t)refl(y0 + ty - R, H) * W + refl(x0 + tx - R, W)] * 255.f;
+            return img[(size_t)c * plane + (size_t)refl(y0 + ty - R, H) * W + refl(x0 + tx - R, W)];
+        };
+        if (RT > 0) {
+            constexpr int PER3 = 3 * (FX + 2 * RT) * (FY + 2 * RT), NIT = (PER3 + 255) / 256;
+            float v[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                v[i] = idx < PER3 ? fetch1(idx) : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                if (idx < PER3) lds[idx] = v[i] * 255.f;
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < 3 * per; idx += 256) lds[idx] = fetch1(idx) * 255.f;
         }
     }
     __syncthreads();
