@@ -1,21 +1,19 @@
-"""create_model(opt) - mirror of the reference's models/__init__.py:5-22."""
+"""Model factory - the ``opt['model']`` names of the reference (models/__init__.py:5-22)."""
+import importlib
 import logging
 
-logger = logging.getLogger('base')
+_BUILT = {'darts': ('.darts_model', 'DartsModel'), 'isp': ('.isp_model', 'IspModel')}
+_OUT_OF_SCOPE = {'darts_yolo': 'YOLOv3 task loss', 'isp_yolo': 'YOLOv3 task loss', 'darts_ft': 'online proxy fine-tuning'}
 
 
 def create_model(opt):
-    kind = opt['model']
-    if kind == 'darts':
-        from .darts_model import DartsModel as M
-    elif kind == 'isp':
-        from .isp_model import IspModel as M
-    elif kind in ('darts_yolo', 'isp_yolo', 'darts_ft'):
-        raise NotImplementedError(
-            'Model [{:s}] is outside the hot-path scope of this build (YOLO task loss / proxy fine-tuning, '
-            'SURVEY.md section 2 rows 16-17).'.format(kind))
-    else:
-        raise NotImplementedError('Model [{:s}] not recognized.'.format(kind))
-    m = M(opt)
-    logger.info('Model [{:s}] is created.'.format(kind))
-    return m
+    name = opt['model']
+    if name in _OUT_OF_SCOPE:
+        raise NotImplementedError('Model [{:s}] ({}) is outside the hot-path scope of this build '
+                                  '(SURVEY.md section 2 rows 16-17).'.format(name, _OUT_OF_SCOPE[name]))
+    if name not in _BUILT:
+        raise NotImplementedError('Model [{:s}] not recognized.'.format(name))
+    module, cls = _BUILT[name]
+    model = getattr(importlib.import_module(module, __name__), cls)(opt)
+    logging.getLogger('base').info('Model [{:s}] is created.'.format(name))
+    return model

@@ -1,5 +1,6 @@
-"""BaseModel - LR warm-up, save / load / resume plumbing shared by the model wrappers
-(mirror of models/base_model.py:8-119; same method names and checkpoint formats)."""
+"""Shared behaviour of the model wrappers: learning-rate warm-up, checkpoint and training-state files
+(same method names and on-disk formats as the reference's models/base_model.py:8-119, so checkpoints
+written by either side load in the other)."""
 import os
 from collections import OrderedDict
 
@@ -7,81 +8,72 @@ import torch
 import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel
 
+_WRAPPERS = (nn.DataParallel, DistributedDataParallel)
 
-def _unwrap(net):
-    return net.module if isinstance(net, (nn.DataParallel, DistributedDataParallel)) else net
+
+def _bare(network):
+    return network.module if isinstance(network, _WRAPPERS) else network
+
+
+def _strip_module_prefix(state):
+    return OrderedDict((key[len('module.'):] if key.startswith('module.') else key, value) for key, value in state.items())
 
 
 class BaseModel(object):
     def __init__(self, opt):
-        self.opt = opt
-        self.device = torch.device('cuda' if opt['gpu_ids'] is not None else 'cpu')
-        self.is_train = opt['is_train']
-        self.schedulers = []
-        self.optimizers = []
+        self.opt, self.is_train = opt, opt['is_train']
+        self.device = torch.device('cpu' if opt['gpu_ids'] is None else 'cuda')
+        self.optimizers, self.schedulers = [], []
 
-    def feed_data(self, data):
-        pass
+    # interface filled in by the subclasses
+    def feed_data(self, data): pass
+    def optimize_parameters(self): pass
+    def get_current_visuals(self): pass
+    def get_current_losses(self): pass
+    def print_network(self): pass
+    def save(self, label): pass
+    def load(self): pass
 
-    def optimize_parameters(self):
-        pass
-
-    def get_current_visuals(self):
-        pass
-
-    def get_current_losses(self):
-        pass
-
-    def print_network(self):
-        pass
-
-    def save(self, label):
-        pass
-
-    def load(self):
-        pass
+    # ---- learning rate
+    def _get_init_lr(self):
+        return [[group['initial_lr'] for group in opt.param_groups] for opt in self.optimizers]
 
     def _set_lr(self, lr_groups_l):
-        for optimizer, lr_groups in zip(self.optimizers, lr_groups_l):
-            for group, lr in zip(optimizer.param_groups, lr_groups):
+        for opt, lrs in zip(self.optimizers, lr_groups_l):
+            for group, lr in zip(opt.param_groups, lrs):
                 group['lr'] = lr
 
-    def _get_init_lr(self):
-        return [[g['initial_lr'] for g in o.param_groups] for o in self.optimizers]
-
     def update_learning_rate(self, cur_iter, warmup_iter=-1):
-        for s in self.schedulers:
-            s.step()
-        if cur_iter < warmup_iter:      # linear warm-up from 0 to the scheduler's initial lr
-            self._set_lr([[v / warmup_iter * cur_iter for v in grp] for grp in self._get_init_lr()])
+        for sched in self.schedulers:
+            sched.step()
+        if cur_iter < warmup_iter:                      # linear ramp towards the scheduler's initial value
+            scale = cur_iter / warmup_iter
+            self._set_lr([[lr * scale for lr in lrs] for lrs in self._get_init_lr()])
 
     def get_current_learning_rate(self):
         return self.optimizers[0].param_groups[0]['lr']
 
+    # ---- networks on disk: '<iter>_<label>.pth' holds a CPU state dict
     def get_network_description(self, network):
-        network = _unwrap(network)
-        return str(network), sum(p.numel() for p in network.parameters())
+        net = _bare(network)
+        return str(net), sum(p.numel() for p in net.parameters())
 
     def save_network(self, network, network_label, iter_label):
-        path = os.path.join(self.opt['path']['models'], '{}_{}.pth'.format(iter_label, network_label))
-        state = OrderedDict((k, v.cpu()) for k, v in _unwrap(network).state_dict().items())
-        torch.save(state, path)
+        target = os.path.join(self.opt['path']['models'], '{}_{}.pth'.format(iter_label, network_label))
+        torch.save(OrderedDict((k, v.cpu()) for k, v in _bare(network).state_dict().items()), target)
 
     def load_network(self, load_path, network, strict=True):
-        state = torch.load(load_path, map_location='cpu')
-        clean = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in state.items())
-        _unwrap(network).load_state_dict(clean, strict=strict)
+        _bare(network).load_state_dict(_strip_module_prefix(torch.load(load_path, map_location='cpu')), strict=strict)
 
+    # ---- optimiser / scheduler state: '<iter>.state'
     def save_training_state(self, epoch, iter_step):
-        state = {'epoch': epoch, 'iter': iter_step,
-                 'schedulers': [s.state_dict() for s in self.schedulers],
-                 'optimizers': [o.state_dict() for o in self.optimizers]}
-        torch.save(state, os.path.join(self.opt['path']['training_state'], '{}.state'.format(iter_step)))
+        blob = dict(epoch=epoch, iter=iter_step, schedulers=[s.state_dict() for s in self.schedulers],
+                    optimizers=[o.state_dict() for o in self.optimizers])
+        torch.save(blob, os.path.join(self.opt['path']['training_state'], '{}.state'.format(iter_step)))
 
     def resume_training(self, resume_state):
-        assert len(resume_state['optimizers']) == len(self.optimizers), 'Wrong lengths of optimizers'
-        assert len(resume_state['schedulers']) == len(self.schedulers), 'Wrong lengths of schedulers'
-        for o, s in zip(self.optimizers, resume_state['optimizers']):
-            o.load_state_dict(s)
-        for sch, s in zip(self.schedulers, resume_state['schedulers']):
-            sch.load_state_dict(s)
+        for kind, mine in (('optimizers', self.optimizers), ('schedulers', self.schedulers)):
+            saved = resume_state[kind]
+            assert len(saved) == len(mine), 'Wrong lengths of ' + kind
+            for obj, state in zip(mine, saved):
+                obj.load_state_dict(state)
