@@ -41,8 +41,7 @@ __device__ __forceinline__ int refl(int i, int n) {
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 __device__ __forceinline__ float q8f(float v) {
-    v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
-    return floorf(v + 0.5f);
+    return floorf(__builtin_amdgcn_fmed3f(v, 0.f, 255.f) + 0.5f);   // clamp in one instruction (v is never NaN here)
 }
 
 // RT: compile-time halo radius (1 = the 3x3 window every reference configuration produces, because
@@ -55,44 +54,68 @@ __global__ __launch_bounds__(256) void bilateral_chain_kernel(const FusedArgs a)
     const int n = blockIdx.z, x0 = blockIdx.x * FX, y0 = blockIdx.y * FY;
     const size_t plane = (size_t)H * W;
 
-    // ---- stage the BGR halo tile, in 8-bit units.  With a compile-time radius all global loads of the
-    // thread are issued before the first LDS write (one memory round trip per block, not one per element).
-    if (FROM_BAYER) {
+    // ---- stage the BGR halo tile (raw [0,1] samples; the x255 of the bilateral's domain is applied on read).
+    const int lx = (threadIdx.x & 15) * PXT, ly = threadIdx.x >> 4;
+    const int px = x0 + lx, py = y0 + ly;
+    if (FROM_BAYER && RT == 1) {
+        // Quad staging: one 2x2 mosaic quad (two 8-byte loads) yields the BGR values of its four pixels -
+        // R and B shared, G per row - so the index arithmetic is paid once per four tile entries.  Only quads
+        // inside the image are loaded; the one-pixel ring outside the image is filled by reflection afterwards.
+        constexpr int TWc = FX + 2, THc = FY + 2, PERc = TWc * THc, QW = FX / 2 + 2, QH = FY / 2 + 2;
         const float *bay = a.in + (size_t)n * plane;
-        auto fetch = [&](int idx, float &b, float &g, float &r) {
+        float2 top[2], bot[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = threadIdx.x + 256 * it;
+            const int j = q / QW, i = q - j * QW;
+            const int Y = y0 - 2 + 2 * j, X = x0 - 2 + 2 * i;
+            const bool ok = q < QW * QH && Y >= 0 && Y < H && X >= 0 && X < W;
+            top[it] = ok ? *reinterpret_cast<const float2 *>(bay + (size_t)Y * W + X) : make_float2(0.f, 0.f);
+            bot[it] = ok ? *reinterpret_cast<const float2 *>(bay + (size_t)(Y + 1) * W + X) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = threadIdx.x + 256 * it;
+            const int j = q / QW, i = q - j * QW;
+            const int Y = y0 - 2 + 2 * j, X = x0 - 2 + 2 * i;
+            if (!(q < QW * QH && Y >= 0 && Y < H && X >= 0 && X < W)) continue;
+            const float R_ = top[it].x, G1 = top[it].y, G2 = bot[it].x, B_ = bot[it].y;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int ty = 2 * j - 1 + dy, tx = 2 * i - 1 + dx;
+                    if (ty >= 0 && ty < THc && tx >= 0 && tx < TWc) {
+                        const int idx = ty * TWc + tx;
+                        lds[idx] = B_;
+                        lds[PERc + idx] = dy ? G2 : G1;
+                        lds[2 * PERc + idx] = R_;
+                    }
+                }
+        }
+        if (x0 == 0 || y0 == 0 || x0 + FX >= W || y0 + FY >= H) {        // block-uniform: tile touches the image border
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < PERc; idx += 256) {
+                const int ty = idx / TWc, tx = idx - ty * TWc;
+                const int gy = y0 - 1 + ty, gx = x0 - 1 + tx;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) continue;
+                const int sy = refl(gy, H) - (y0 - 1), sx = refl(gx, W) - (x0 - 1);
+                if (sy < 0 || sy >= THc || sx < 0 || sx >= TWc) continue;      // feeds only outputs outside the image
+                const int src = sy * TWc + sx;
+                lds[idx] = lds[src];
+                lds[PERc + idx] = lds[PERc + src];
+                lds[2 * PERc + idx] = lds[2 * PERc + src];
+            }
+        }
+    } else if (FROM_BAYER) {
+        const float *bay = a.in + (size_t)n * plane;
+        for (int idx = threadIdx.x; idx < per; idx += 256) {
             const int ty = idx / tw, tx = idx - ty * tw;
             const int gy = refl(y0 + ty - R, H), gx = refl(x0 + tx - R, W);
             const int qy = gy & ~1, qx = gx & ~1;                       // quad origin
-            r = bay[(size_t)qy * W + qx];
-            g = bay[(size_t)(qy + (gy & 1)) * W + qx + 1 - (gy & 1)];   // G1 on even rows, G2 on odd rows
-            b = bay[(size_t)(qy + 1) * W + qx + 1];
-        };
-        if (RT > 0) {
-            constexpr int PER = (FX + 2 * RT) * (FY + 2 * RT), NIT = (PER + 255) / 256;
-            float vb[NIT], vg[NIT], vr[NIT];
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int idx = threadIdx.x + 256 * i;
-                vb[i] = vg[i] = vr[i] = 0.f;
-                if (idx < PER) fetch(idx, vb[i], vg[i], vr[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int idx = threadIdx.x + 256 * i;
-                if (idx < PER) {
-                    lds[idx] = vb[i] * 255.f;
-                    lds[PER + idx] = vg[i] * 255.f;
-                    lds[2 * PER + idx] = vr[i] * 255.f;
-                }
-            }
-        } else {
-            for (int idx = threadIdx.x; idx < per; idx += 256) {
-                float b, g, r;
-                fetch(idx, b, g, r);
-                lds[idx] = b * 255.f;
-                lds[per + idx] = g * 255.f;
-                lds[2 * per + idx] = r * 255.f;
-            }
+            lds[2 * per + idx] = bay[(size_t)qy * W + qx];
+            lds[per + idx] = bay[(size_t)(qy + (gy & 1)) * W + qx + 1 - (gy & 1)];   // G1 on even rows, G2 on odd rows
+            lds[idx] = bay[(size_t)(qy + 1) * W + qx + 1];
         }
     } else {
         const float *img = a.in + (size_t)n * 3 * plane;
@@ -112,30 +135,26 @@ __global__ __launch_bounds__(256) void bilateral_chain_kernel(const FusedArgs a)
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int idx = threadIdx.x + 256 * i;
-                if (idx < PER3) lds[idx] = v[i] * 255.f;
+                if (idx < PER3) lds[idx] = v[i];
             }
         } else {
-            for (int idx = threadIdx.x; idx < 3 * per; idx += 256) lds[idx] = fetch1(idx) * 255.f;
+            for (int idx = threadIdx.x; idx < 3 * per; idx += 256) lds[idx] = fetch1(idx);
         }
     }
     __syncthreads();
 
-    const int lx = (threadIdx.x & 15) * PXT, ly = threadIdx.x >> 4;
-    const int px = x0 + lx, py = y0 + ly;
     if (px >= W || py >= H) return;                     // W % 4 == 0: the 4 pixels are in or out together
     const size_t o = (size_t)n * 3 * plane + (size_t)py * W + px;
     const float *ctr = lds + (ly + R) * tw + lx + R;
 
-    if (FROM_BAYER) {                                   // the demosaic stage output ([0,1] domain: the staged values / 255)
+    if (FROM_BAYER) {                                   // the demosaic stage output: the staged samples themselves
         float4 vb, vg, vr;
         float *eb = reinterpret_cast<float *>(&vb), *eg = reinterpret_cast<float *>(&vg), *er = reinterpret_cast<float *>(&vr);
-        const float *bay = a.in + (size_t)n * plane;
 #pragma unroll
-        for (int i = 0; i < PXT; ++i) {                 // exact copy of the mosaic samples (bit-exact index map)
-            const int gx = px + i, qy = py & ~1, qx = gx & ~1;
-            er[i] = bay[(size_t)qy * W + qx];
-            eg[i] = bay[(size_t)(qy + (py & 1)) * W + qx + 1 - (py & 1)];
-            eb[i] = bay[(size_t)(qy + 1) * W + qx + 1];
+        for (int i = 0; i < PXT; ++i) {
+            eb[i] = ctr[i];
+            eg[i] = ctr[per + i];
+            er[i] = ctr[2 * per + i];
         }
         *reinterpret_cast<float4 *>(a.out_dem + o) = vb;
         *reinterpret_cast<float4 *>(a.out_dem + o + plane) = vg;
@@ -151,11 +170,16 @@ __global__ __launch_bounds__(256) void bilateral_chain_kernel(const FusedArgs a)
 #pragma unroll
     for (int i = 0; i < PXT; ++i) {
         const float *c0 = ctr + i;
-        const float cb = c0[0], cg = c0[per], cr = c0[2 * per];
+        const float cb = c0[0] * 255.f, cg = c0[per] * 255.f, cr = c0[2 * per] * 255.f;
+        // the centre tap has weight exp(0) = 1 exactly: start from it instead of evaluating it
         float nb = 0.f, ng = 0.f, nr = 0.f, den = 0.f;
         auto tap = [&](int dy, int dx) {
+            if (dy == 0 && dx == 0) {
+                nb += cb; ng += cg; nr += cr; den += 1.f;
+                return;
+            }
             const float *q = c0 + dy * tw + dx;
-            const float qb = q[0], qg = q[per], qr = q[2 * per];
+            const float qb = q[0] * 255.f, qg = q[per] * 255.f, qr = q[2 * per] * 255.f;
             const float dist = fabsf(qb - cb) + fabsf(qg - cg) + fabsf(qr - cr);
             const float wgt = __expf((float)(dy * dy + dx * dx) * ks + dist * dist * kc);
             nb += wgt * qb; ng += wgt * qg; nr += wgt * qr; den += wgt;

@@ -15,8 +15,7 @@ namespace {
 constexpr int TX = 32, TY = 8;   // output pixels per 256-thread block
 
 __device__ __forceinline__ float q8(float v) {
-    v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
-    return floorf(v + 0.5f);
+    return floorf(__builtin_amdgcn_fmed3f(v, 0.f, 255.f) + 0.5f);   // clamp in one instruction (v is never NaN here)
 }
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (i < 0) i = -i;
@@ -104,6 +103,10 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
         for (int dx = -r; dx <= r; ++dx) {
             const float *q = ctr + dy * tw + dx;
             const float qb = q[0], qg = q[per], qr = q[2 * per];
+            if (dy == 0 && dx == 0) {                  // weight exp(0) = 1 exactly
+                nb += qb; ng += qg; nr += qr; den += 1.f;
+                continue;
+            }
             const float dist = fabsf(qb - cb) + fabsf(qg - cg) + fabsf(qr - cr);
             const float wgt = __expf((float)(dy * dy + dx * dx) * ks + dist * dist * kc);
             nb += wgt * qb; ng += wgt * qg; nr += wgt * qr; den += wgt;
