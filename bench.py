@@ -176,8 +176,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
-        dist.init_process_group(backend='nccl')       # RCCL on ROCm
+        # RCCL on ROCm.  RISP_BENCH_BACKEND=gloo + RISP_BENCH_ONE_DEVICE=1 is a dry-run mode for boxes with a
+        # single GPU (every rank on device 0) used only to exercise this code path.
+        dist.init_process_group(backend=os.environ.get('RISP_BENCH_BACKEND', 'nccl'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if os.environ.get('RISP_BENCH_ONE_DEVICE') == '1':
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 

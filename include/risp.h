@@ -174,6 +174,13 @@ int risp_conv_pack_weights(const float *w, int cin, int cout, int ksize, int tra
                            void *stream);
 int risp_conv2d(const risp_conv_desc *d, void *stream);
 
+/* Backward-weight of the same layer: dw (cout,cin,k,k) = sum_{n,y,x} gy[n,co,y,x] * load(x)[n,ci,y+ky-p,x+kx-p]
+ * (fully written).  Uses d->x, load_mode (PLAIN / CONSTCH), cin_img, cvals, N, H, W, cin, cout, ksize; gy is
+ * (N,cout,H,W).  scratch: risp_conv_wgrad_scratch_floats(ksize) floats.  Only the proxy fine-tuning path
+ * (darts_ft_model.py:206-246) needs weight gradients.  Float atomics: the last bits vary run to run. */
+size_t risp_conv_wgrad_scratch_floats(int ksize);
+int risp_conv2d_wgrad(const risp_conv_desc *d, const float *gy, float *dw, float *scratch, void *stream);
+
 /* sum over H,W of channels [c0, c0+nc) of an (N,C,H,W) tensor -> out (N,nc) (SRCNNRes
  * gradient of the broadcast parameter planes). */
 int risp_plane_sums(const float *x, float *out, int N, int C, int c0, int nc, int HW, void *stream);

@@ -17,7 +17,8 @@ def install_aliases():
         sys.modules.setdefault(name, module)
     # submodules that the reference imports by dotted path
     for dotted in ('models.networks', 'models.base_model', 'models.isp_model', 'models.darts_model',
-                   'models.lr_scheduler', 'models.modules', 'models.modules.tools_origin',
+                   'models.darts_ft_model', 'models.lr_scheduler', 'models.modules',
+                   'models.modules.super_prune_fifteen_demos_four_bayer_two_ft', 'models.modules.tools_origin',
                    'models.modules.tools_proxy', 'models.modules.srcnn_res_arch',
                    'models.modules.srcnn_demosaic_arch', 'models.modules.path_14l_bayer_arch',
                    'models.modules.path_14l_bgr_arch', 'models.modules.isp_universal',

@@ -2,8 +2,9 @@
 import importlib
 import logging
 
-_BUILT = {'darts': ('.darts_model', 'DartsModel'), 'isp': ('.isp_model', 'IspModel')}
-_OUT_OF_SCOPE = {'darts_yolo': 'YOLOv3 task loss', 'isp_yolo': 'YOLOv3 task loss', 'darts_ft': 'online proxy fine-tuning'}
+_BUILT = {'darts': ('.darts_model', 'DartsModel'), 'isp': ('.isp_model', 'IspModel'),
+          'darts_ft': ('.darts_ft_model', 'DartsFtModel')}
+_OUT_OF_SCOPE = {'darts_yolo': 'YOLOv3 task loss', 'isp_yolo': 'YOLOv3 task loss'}
 
 
 def create_model(opt):

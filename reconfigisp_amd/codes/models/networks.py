@@ -20,8 +20,10 @@ def define_G(opt):
         return SuperPruneFifteenDemosFourBayerTwo(n_step=opt_net['n_step'], threshold=opt_net['prune_threshold'],
                                                   module_path=module_path)
     if which == 'SuperPruneFifteenDemosFourBayerTwoFt':
-        raise NotImplementedError('Generator model [{:s}]: online proxy fine-tuning is SURVEY.md section 8f row 2 '
-                                  '("next"), not built yet'.format(which))
+        from .modules.super_prune_fifteen_demos_four_bayer_two_ft import SuperPruneFifteenDemosFourBayerTwoFt
+        opt_net['n_modules']
+        return SuperPruneFifteenDemosFourBayerTwoFt(n_step=opt_net['n_step'], threshold=opt_net['prune_threshold'],
+                                                    module_path=module_path)
     if which == 'IspUniversal':
         from .modules.isp_universal import IspUniversal
         cond = opt_net['conditional_modules'] if 'conditional_modules' in opt_net else {}

@@ -118,7 +118,11 @@ def main(argv=None):
                 break
             model.feed_data(batch_tuple(opt, trn, val))
             model.update_learning_rate(step, warmup_iter=opt['train']['warmup_iter'])
-            if kind == 'darts':
+            if kind == 'darts_ft' and step % opt['proxy_ft_params']['ft_interval'] == 0:
+                model.finetune_proxies()
+                if rank <= 0:
+                    print('proxy nets fine-tuned!')
+            if kind in ('darts', 'darts_ft'):
                 model.optimize_alphas()
             model.optimize_parameters()
 
@@ -126,7 +130,7 @@ def main(argv=None):
                 print('Average time per iter: {:.6f}'.format((time.time() - tick) / print_freq))
                 msg = '<epoch:{:3d}, iter:{:8,d}, lr:{:.3e}> '.format(epoch, step, model.get_current_learning_rate())
                 msg += ' '.join('{:s}: {:.4e}'.format(k, v) for k, v in model.get_current_log().items())
-                if kind == 'darts':
+                if kind in ('darts', 'darts_ft'):
                     print('train_val_loss: {}'.format(model.val_loss.item()))
                     print('Pruned paths: {}'.format(model.netG_attr.pruned_paths))
                 logger.info(msg)

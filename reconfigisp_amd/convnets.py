@@ -51,6 +51,19 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     return out
 
 
+def conv_wgrad(x, gy, cin, cout, k, n, h, w, load=LOAD_PLAIN, cin_img=0, cvals=None):
+    """(dW (cout,cin,k,k), db (cout,)) of one layer from its input x and the gradient gy at its output."""
+    gy = _dev(gy, 'grad')
+    dw = torch.empty((cout, cin, k, k), device=gy.device, dtype=torch.float32)
+    ws = torch.empty(L.load().risp_conv_wgrad_scratch_floats(k), device=gy.device, dtype=torch.float32)
+    d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=load, cin_img=cin_img, epilogue=0, add_c=0,
+                   x=_p(x), wpack=None, bias=None, cvals=_p(cvals), add=None, mask=None, y=None)
+    L.call('risp_conv2d_wgrad', C.byref(d), _p(gy), _p(dw), _p(ws), _stream())
+    sums = torch.empty((n, cout), device=gy.device, dtype=torch.float32)
+    L.call('risp_plane_sums', _p(gy), _p(sums), n, cout, 0, cout, h * w, _stream())
+    return dw, sums.sum(dim=0)
+
+
 class PackCache:
     """Re-pack a module's conv weights only when a parameter changed (version counter / storage)."""
 
@@ -160,7 +173,60 @@ class _SrcnnRes(torch.autograd.Function):
         return gx, sums[3], None
 
 
-def srcnn_res(x, pv, packs):
+class _SrcnnResTrain(torch.autograd.Function):
+    """SRCNNRes whose six conv tensors are autograd inputs: backward also returns their gradients
+    (risp_conv2d_wgrad).  Used only while a proxy is being fine-tuned against its classical teacher."""
+
+    @staticmethod
+    def forward(ctx, x, pv, packs, w1, b1, w2, b2, w3, b3):
+        x = _dev(x, 'img')
+        n, _, h, w = x.shape
+        c1, c2, c3 = packs
+        P = c1.cin - 12
+        pv = _dev(pv, 'params') if P else None
+        stats, arg = channel_stats(x)
+        cvals = torch.empty((n, 9 + P), device=x.device, dtype=torch.float32)
+        L.call('risp_srcnn_cvals', _p(stats), _p(pv), _p(cvals), n, P, h * w, _stream())
+        t1 = conv(x, c1, n, h, w, load=LOAD_CONSTCH, cin_img=3, cvals=cvals, epi=EPI_RELU)
+        t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
+        y = conv(t2, c3, n, h, w, epi=EPI_ADD, add=x, add_c=3)
+        ctx.save_for_backward(x, cvals, t1, t2, arg)
+        ctx.packs, ctx.dims = packs, (n, h, w, P)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, cvals, t1, t2, arg = ctx.saved_tensors
+        c1, c2, c3 = ctx.packs
+        n, h, w, P = ctx.dims
+        gy = _dev(gy, 'grad')
+        g2 = conv(gy, c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2)
+        g1 = conv(g2, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1)
+        dw3, db3 = conv_wgrad(t2, gy, c3.cin, c3.cout, c3.k, n, h, w)
+        dw2, db2 = conv_wgrad(t1, g2, c2.cin, c2.cout, c2.k, n, h, w)
+        dw1, db1 = conv_wgrad(x, g1, c1.cin, c1.cout, c1.k, n, h, w, load=LOAD_CONSTCH, cin_img=3, cvals=cvals)
+        gx = gpv = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gf = conv(g1, c1, n, h, w, transpose=True, epi=EPI_ADD, add=gy, add_c=3)
+            sums = []
+            for c0, nc in ((3, 3), (6, 3), (9, 3), (12, P)):
+                if nc == 0:
+                    sums.append(None)
+                    continue
+                s_ = torch.empty((n, nc), device=gy.device, dtype=torch.float32)
+                L.call('risp_plane_sums', _p(gf), _p(s_), n, 12 + P, c0, nc, h * w, _stream())
+                sums.append(s_)
+            gx = gf[:, :3].contiguous()
+            L.call('risp_stats_bwd', _p(gx), _p(sums[0]), _p(sums[1]), _p(sums[2]), _p(arg), n * 3, h * w, _stream())
+            gpv = sums[3]
+        return gx, gpv, None, dw1, db1, dw2, db2, dw3, db3
+
+
+def srcnn_res(x, pv, packs, train_module=None):
+    if train_module is not None:
+        seq = train_module.srcnn
+        return _SrcnnResTrain.apply(x, pv, packs, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias,
+                                    seq[4].weight, seq[4].bias)
     return _SrcnnRes.apply(x, pv, packs)
 
 

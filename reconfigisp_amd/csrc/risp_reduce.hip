@@ -247,6 +247,17 @@ __global__ __launch_bounds__(256) void plane_sums_kernel(const float *__restrict
     if (threadIdx.x == 0) atomicAdd(&out[n * nc + c], acc[0]);
 }
 
+__global__ __launch_bounds__(256) void plane_sums_scalar_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                                int C, int c0, int nc, int hw) {
+    __shared__ float red[4];
+    const int n = blockIdx.y / nc, c = blockIdx.y % nc;
+    const float *xb = x + ((size_t)n * C + c0 + c) * hw;
+    float acc[1] = {0.f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) acc[0] += xb[i];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&out[n * nc + c], acc[0]);
+}
+
 // ---- truncating uint8 conversion + squared error (utils/util.py:130-131,141-154)
 __device__ __forceinline__ float to_u8(float v) {
     float t = v * 255.f;
@@ -380,16 +391,20 @@ int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *g
 }
 
 int risp_plane_sums(const float *x, float *out, int N, int C, int c0, int nc, int HW, void *stream) {
-    RISP_CHECK_ARG(x && out && N > 0 && C > 0 && c0 >= 0 && nc > 0 && c0 + nc <= C && HW % 4 == 0 && N * nc <= 65535,
+    RISP_CHECK_ARG(x && out && N > 0 && C > 0 && c0 >= 0 && nc > 0 && c0 + nc <= C && HW > 0 && N * nc <= 65535,
                    "risp_plane_sums: bad arguments");
     if (hipMemsetAsync(out, 0, sizeof(float) * N * nc, (hipStream_t)stream) != hipSuccess) {
         risp_set_error("risp_plane_sums: memset failed");
         return 2;
     }
     int bx = (HW / 4 + 2047) / 2048;
-    if (bx > 32) bx = 32;
-    hipLaunchKernelGGL(plane_sums_kernel, dim3(bx, N * nc), dim3(256), 0, (hipStream_t)stream, x, out, C, c0, nc,
-                       HW / 4);
+    bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
+    if (HW % 4 == 0)
+        hipLaunchKernelGGL(plane_sums_kernel, dim3(bx, N * nc), dim3(256), 0, (hipStream_t)stream, x, out, C, c0, nc,
+                           HW / 4);
+    else
+        hipLaunchKernelGGL(plane_sums_scalar_kernel, dim3(bx, N * nc), dim3(256), 0, (hipStream_t)stream, x, out, C, c0,
+                           nc, HW);
     RISP_LAUNCH_CHECK("risp_plane_sums");
     return 0;
 }

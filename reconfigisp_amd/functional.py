@@ -310,12 +310,31 @@ class _HipImpl:
     def histc01(x, bins):
         return histc01(x, bins)
 
+    @staticmethod
+    def origin_demosaic(x, option, scales=(1.0, 1.0)):
+        return _hip_origin_demosaic(x, option, scales)
+
+    @staticmethod
+    def origin_tonemap(x, option, params, scales=(1.0, 1.0)):
+        return _hip_origin_tonemap(x, option, params, scales)
+
+    @staticmethod
+    def origin_whiteworld(x, ratio, scales=(1.0, 1.0)):
+        return _hip_origin_whiteworld(x, ratio, scales)
+
+    @staticmethod
+    def origin_denoise(x, option, params, scales=(1.0, 1.0)):
+        return _hip_origin_denoise(x, option, params, scales)
+
     # CNN families: `module` is the nn.Module that owns the reference-shaped parameters
     @staticmethod
     def srcnn_res(x, pv, module):
         from . import convnets as CN
         packs = _packs(module, lambda: CN.build_srcnn_packs(module.srcnn))
-        return CN.srcnn_res(x, pv, packs)
+        # weight gradients only on request (proxy fine-tuning sets module.train_weights); the search itself never
+        # uses them, although the proxies' tensors nominally require grad
+        training = getattr(module, 'train_weights', False) and torch.is_grad_enabled()
+        return CN.srcnn_res(x, pv, packs, module if training else None)
 
     @staticmethod
     def srcnn_demosaic(x, module):
@@ -419,7 +438,7 @@ def _check_odd(name, v):
     return v
 
 
-def origin_demosaic(x, option, scales=(1.0, 1.0)):
+def _hip_origin_demosaic(x, option, scales=(1.0, 1.0)):
     x = _dev(x.detach(), 'img')
     if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 2 or x.shape[3] % 2:
         raise ValueError('expected a (N,1,H,W) RGGB mosaic with even H, W; got %s' % (tuple(x.shape),))
@@ -433,7 +452,7 @@ _TONEMAP = {'reinhard': (0, 'white_point', 'middle_grey'), 'crysisengine': (1, '
             'filmic': (2, 'white_point', 'exposure_bias')}
 
 
-def origin_tonemap(x, option, params, scales=(1.0, 1.0)):
+def _hip_origin_tonemap(x, option, params, scales=(1.0, 1.0)):
     x = _dev(x.detach(), 'img')
     _check_bgr(x)
     n, hw = x.shape[0], x.shape[2] * x.shape[3]
@@ -447,7 +466,7 @@ def origin_tonemap(x, option, params, scales=(1.0, 1.0)):
     return y
 
 
-def origin_whiteworld(x, ratio, scales=(1.0, 1.0)):
+def _hip_origin_whiteworld(x, ratio, scales=(1.0, 1.0)):
     x = _dev(x.detach(), 'img')
     _check_bgr(x)
     n, hw = x.shape[0], x.shape[2] * x.shape[3]
@@ -460,7 +479,7 @@ def origin_whiteworld(x, ratio, scales=(1.0, 1.0)):
     return y
 
 
-def origin_denoise(x, option, params, scales=(1.0, 1.0)):
+def _hip_origin_denoise(x, option, params, scales=(1.0, 1.0)):
     x = _dev(x.detach(), 'img')
     _check_bgr(x)
     n, _, h, w = x.shape
@@ -485,3 +504,19 @@ def origin_denoise(x, option, params, scales=(1.0, 1.0)):
     else:
         raise ValueError('unknown denoiser %r' % (option,))
     return y
+
+
+def origin_demosaic(x, option, scales=(1.0, 1.0)):
+    return _IMPL.origin_demosaic(x, option, scales)
+
+
+def origin_tonemap(x, option, params, scales=(1.0, 1.0)):
+    return _IMPL.origin_tonemap(x, option, params, scales)
+
+
+def origin_whiteworld(x, ratio, scales=(1.0, 1.0)):
+    return _IMPL.origin_whiteworld(x, ratio, scales)
+
+
+def origin_denoise(x, option, params, scales=(1.0, 1.0)):
+    return _IMPL.origin_denoise(x, option, params, scales)

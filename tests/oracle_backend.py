@@ -31,12 +31,25 @@ class OracleImpl:
     def histc01(x, bins):
         return torch.stack([torch.cat([torch.histc(ch.detach(), bins=bins, min=0, max=1) for ch in im]) for im in x])
 
-    srcnn_res = staticmethod(lambda x, pv, m: O.srcnn_res(x, pv, _sd(m)))
+    # weights stay attached to the graph while a proxy is being fine-tuned (module.train_weights)
+    srcnn_res = staticmethod(lambda x, pv, m: O.srcnn_res(
+        x, pv, dict(m.named_parameters()) if getattr(m, 'train_weights', False) else _sd(m)))
     srcnn_demosaic = staticmethod(lambda x, m: O.srcnn_demosaic(x, _sd(m)))
     path14l_bayer = staticmethod(lambda x, m: O.path14l_bayer(x, _sd(m)))
     path14l_bgr = staticmethod(lambda x, m: O.path14l_bgr(x, _sd(m)))
 
-    origin_demosaic = staticmethod(O.origin_demosaic)
-    origin_tonemap = staticmethod(O.origin_tonemap)
-    origin_whiteworld = staticmethod(O.origin_whiteworld)
-    origin_denoise = staticmethod(O.origin_denoise)
+    # classical kernels: the plugin boundary hands over x255 images (scales = (1, 1))
+    origin_demosaic = staticmethod(lambda x, option, scales=(1.0, 1.0): O.origin_demosaic(x, option))
+    origin_whiteworld = staticmethod(lambda x, ratio, scales=(1.0, 1.0): O.origin_whiteworld(x, _np(ratio)))
+
+    @staticmethod
+    def origin_tonemap(x, option, params, scales=(1.0, 1.0)):
+        return O.origin_tonemap(x, option, {k: _np(v) for k, v in params.items() if k not in ('input', 'output')})
+
+    @staticmethod
+    def origin_denoise(x, option, params, scales=(1.0, 1.0)):
+        return O.origin_denoise(x, option, params)
+
+
+def _np(v):
+    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v

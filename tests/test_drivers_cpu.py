@@ -15,7 +15,7 @@ def test_option_files_parse(tmp_path):
     from reconfigisp_amd.codes.options import options as option
     for f in sorted(glob.glob(os.path.join(CODES, 'options', '*', '*.yml'))):
         opt = option.parse(f, is_train='train' in f)
-        assert opt['network_G']['which_model_G'] and opt['model'] in ('darts', 'isp')
+        assert opt['network_G']['which_model_G'] and opt['model'] in ('darts', 'darts_ft', 'isp')
         assert opt['datasets'][list(opt['datasets'])[0]]['phase'] in ('train', 'test')
     text = option.dict2str({'a': 1, 'b': {'c': 2}})
     assert 'b:[' in text and 'c: 2' in text

@@ -87,3 +87,48 @@ def test_const_channel_load():
     full = torch.cat([x, cv[:, :, None, None].expand(-1, -1, h, w)], dim=1)
     assert_close(CN.conv(x, pc, n, h, w, load=CN.LOAD_CONSTCH, cin_img=3, cvals=cv), TF.conv2d(full, wt, b, padding=4),
                  what='const channels')
+
+
+@pytest.mark.parametrize('cin,cout,k,hw', [(32, 3, 5, (16, 16)), (64, 32, 5, (24, 40)), (17, 64, 9, (20, 36)),
+                                           (64, 64, 3, (33, 30)), (3, 64, 3, (8, 8))])
+def test_backward_weight(cin, cout, k, hw):
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n = 3
+    wt = (rnd(cout, cin, k, k, seed=21) * 0.1).requires_grad_(True)
+    b = (rnd(cout, seed=22) * 0.1).requires_grad_(True)
+    x, gy = rnd(n, cin, h, w, seed=23), rnd(n, cout, h, w, seed=24)
+    ref = TF.conv2d(x, wt, b, padding=k // 2)
+    gw_ref, gb_ref = torch.autograd.grad(ref, (wt, b), gy)
+    gw, gb = CN.conv_wgrad(x, gy, cin, cout, k, n, h, w)
+    assert_close(gw, gw_ref, what='dW')
+    assert_close(gb, gb_ref, what='db')
+
+
+def test_srcnn_res_weight_gradients_vs_oracle():
+    """Proxy fine-tuning path: gradients of an MSE-like loss w.r.t. all six SRCNNRes tensors vs CPU autograd."""
+    import isp_oracle as O
+    from reconfigisp_amd.codes.models.modules.tools_proxy import ProxyNet
+    P, n, h, w = 3, 2, 24, 40
+    wts = O.make_weights('srcnn_res', 55, P)
+    for k in list(wts):                                   # kink-free (see test_gpu_cnn.kink_free_weights)
+        if k.endswith('.bias') and not k.startswith('srcnn.4'):
+            s = torch.ones_like(wts[k]); s[1::2] = -1.0; wts[k] = s
+        elif k.endswith('.weight'):
+            wts[k] = wts[k] * 0.02
+    x, pv = rnd(n, 3, h, w, seed=25).cpu().abs().clamp(0, 1), rnd(n, P, seed=26).cpu().abs().clamp(0, 1)
+    gy = rnd(n, 3, h, w, seed=27).cpu()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in wts.items()}
+    yc = O.srcnn_res(x, pv, leaf)
+    keys = sorted(leaf)
+    gref = torch.autograd.grad(yc, [leaf[k] for k in keys], gy)
+    m = ProxyNet(P, None)
+    m.load_state_dict(wts)
+    m = m.cuda()
+    m.train_weights = True
+    yg = m(x.cuda(), pv.cuda())
+    assert_close(yg, yc, what='y')
+    params = dict(m.named_parameters())
+    ggot = torch.autograd.grad(yg, [params[k] for k in keys], gy.cuda())
+    for k, a, b in zip(keys, ggot, gref):
+        assert_close(a, b, rtol=2e-4, what='grad ' + k)

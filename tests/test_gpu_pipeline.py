@@ -166,3 +166,27 @@ def test_train_driver_two_iterations(tmp_path, monkeypatch):
     assert saved
     state = torch.load(saved[0])
     assert sorted(state)[:3] == ['alpha_bayer', 'alpha_demosaic', 'alpha_step1'] and len(state) == 3 + 12
+
+
+def test_train_ft_driver_with_finetuning(tmp_path, monkeypatch, capsys):
+    """train_ft path on the GPU: darts_ft + SuperPrune...Ft, proxies fine-tuned against the HIP stencil teachers."""
+    from reconfigisp_amd.codes import train
+    from reconfigisp_amd.codes.options import options as option
+    real = option.parse
+
+    def parse(path, is_train=True):
+        opt = real(path, is_train)
+        opt['train']['niter'] = 4
+        opt['network_G']['n_step'] = 1
+        opt['proxy_ft_params'].update(ft_interval=2, ft_steps=2, memory_size=4)
+        opt['datasets']['train'].update(data_size=32, n_images=16, batch_size=2)
+        for k in ('experiments_root', 'models', 'training_state', 'log', 'val_images'):
+            opt['path'][k] = str(tmp_path / 'exp' / ('' if k in ('experiments_root', 'log') else k))
+        opt['logger'].update(print_freq=1, save_checkpoint_freq=4)
+        return opt
+    monkeypatch.setattr(option, 'parse', parse)
+    train.main(['--opt', os.path.join(CODES, 'options', 'train', 'synthetic_search_ft.yml')])
+    out = capsys.readouterr().out
+    assert out.count('proxy nets fine-tuned!') == 2
+    saved = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / 'exp' / 'models' / '4_*.pth')))
+    assert saved == ['4_G.pth', '4_bilateral.pth', '4_crysisengine.pth', '4_fastnlm.pth', '4_median.pth', '4_whiteworld.pth']
