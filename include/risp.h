@@ -233,6 +233,23 @@ int risp_bilateral_chain_fwd(const float *in, int from_bayer, float *out_demosai
                              int max_window, int n_ops, const int *ops, const float *const *params,
                              float *const *outs, int N, int H, int W, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Input side on the device (what the reference's dataset classes do with numpy / cv2 on the host).
+ * sel is a device (N,3) int32 array {frame, row, col}; rows / cols even keep the RGGB phase.
+ * ------------------------------------------------------------------------- */
+/* uint16 RGGB frames (F,H0,W0) -> (N,1,h,w) fp32 = sample / divisor (1023 / 16383:
+ * data/oneplus_rggb2obj_dataset.py:201, data/sid_sony_ratio_rggb2bgr_dataset.py:121-134) */
+int risp_raw_crop(const uint16_t *frames, float *out, const int32_t *sel, int N, int H0, int W0, int h, int w,
+                  float divisor, void *stream);
+/* uint8 HWC BGR ground truth (F,H0,W0,3) -> (N,3,h,w) fp32 / 255 */
+int risp_gt_crop(const uint8_t *frames, float *out, const int32_t *sel, int N, int H0, int W0, int h, int w,
+                 void *stream);
+/* OnePlus "resize by quad" (data/util.py:37-64, oneplus_rggb2obj_dataset.py:109-145): each colour plane of
+ * src (H0,W0) is resized to (resized_h/2, W/2) by nearest neighbour and placed pad_top rows down in the
+ * zero-filled dst (H,W). */
+int risp_resize_rggb(const uint16_t *src, uint16_t *dst, int H0, int W0, int H, int W, int resized_h, int pad_top,
+                     void *stream);
+
 /* tensor2bgr + psnr on device (utils/util.py:118-154): truncating uint8 conversion of
  * both images, squared error accumulated in fp64 into sse[0] (zeroed by the call). */
 int risp_sse_uint8(const float *a, const float *b, double *sse, size_t numel, void *stream);

@@ -66,6 +66,9 @@ SIGNATURES = {
     'risp_origin_fastnlm': (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _s]),
     'risp_origin_tonemap': (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _fl, _fl, _s]),
     'risp_bilateral_chain_fwd': (_i, [_f, _i, _f, _f, _f, _f, _f, _i, _i, C.POINTER(_i), _pp, _pp, _i, _i, _i, _s]),
+    'risp_raw_crop': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _fl, _s]),
+    'risp_gt_crop': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _s]),
+    'risp_resize_rggb': (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _s]),
     'risp_sse_uint8': (_i, [_f, _f, _f, _z, _s]),
 }
 
