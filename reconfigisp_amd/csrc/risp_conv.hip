@@ -286,7 +286,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     tile[(c * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * 32 + l31] = acc[r][c][e];
-            __syncthreads();
+            // the tile is private to this wave and a wave's LDS operations execute in order: no workgroup
+            // barrier, only keep the compiler from moving the reads above the writes
+            __builtin_amdgcn_wave_barrier();
             const bool row_ok = oy < d.H && x0 + q4 < d.W;
             float4 v[NV], av[NV], mv[NV];
 #pragma unroll
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
                 if (row_ok && co < d.cout)
                     *reinterpret_cast<float4 *>(py + ((size_t)n * d.cout + co) * plane + (size_t)oy * d.W + x0 + q4) = o;
             }
-            __syncthreads();                             // tile is rewritten by the next row
+            __builtin_amdgcn_wave_barrier();            // tile is rewritten by the next row (same wave, in order)
         }
 #ifdef RISP_CONV_STAMPS
         if (lane == 0 && d.mask && !(d.epilogue & RISP_EPI_MASK)) {

@@ -47,7 +47,10 @@ __device__ __forceinline__ float q8f(float v) {
 // RT: compile-time halo radius (1 = the 3x3 window every reference configuration produces, because
 // `.int()` precedes `*7` at tools_origin.py:698); 0 = run-time radius a.R.
 template <bool FROM_BAYER, int RT>
-__global__ __launch_bounds__(256) void bilateral_chain_kernel(const FusedArgs a) {
+#ifndef RISP_FUSED_WAVES
+#define RISP_FUSED_WAVES 1
+#endif
+__global__ __launch_bounds__(256, RISP_FUSED_WAVES) void bilateral_chain_kernel(const FusedArgs a) {
     extern __shared__ float lds[];
     const int R = RT > 0 ? RT : a.R, H = a.H, W = a.W;
     const int tw = FX + 2 * R, th = FY + 2 * R, per = tw * th;
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256) void bilateral_chain_kernel(const FusedArgs a)
         }
         // x (1/255): what `output.float() / 255.` (tools_origin.py:716) evaluates to on the GPU (PyTorch divides by a
         // host scalar through its fp32 reciprocal)
-        const float inv255 = 1.f / 255.f;
-        pix[i] = {q8f(nb / den) * inv255, q8f(ng / den) * inv255, q8f(nr / den) * inv255};
+        const float inv255 = 1.f / 255.f, rden = 1.f / den;     // OPSPEC: normalise by one reciprocal, not three divisions
+        pix[i] = {q8f(nb * rden) * inv255, q8f(ng * rden) * inv255, q8f(nr * rden) * inv255};
     }
     auto store = [&](float *dst) {
         *reinterpret_cast<float4 *>(dst + o) = make_float4(pix[0].b, pix[1].b, pix[2].b, pix[3].b);

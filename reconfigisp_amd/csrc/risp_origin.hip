@@ -112,9 +112,10 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
             nb += wgt * qb; ng += wgt * qg; nr += wgt * qr; den += wgt;
         }
     const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)py * W + px;
-    y[o] = q8(nb / den) * (1.f / so);
-    y[o + plane] = q8(ng / den) * (1.f / so);
-    y[o + 2 * plane] = q8(nr / den) * (1.f / so);
+    const float rden = 1.f / den;                       // OPSPEC: normalise by one reciprocal, not three divisions
+    y[o] = q8(nb * rden) * (1.f / so);
+    y[o + plane] = q8(ng * rden) * (1.f / so);
+    y[o + 2 * plane] = q8(nr * rden) * (1.f / so);
 }
 
 // ---------------------------------------------------------------- median on 8-bit codes (bisection on the code)
@@ -177,9 +178,10 @@ __global__ __launch_bounds__(256) void fastnlm_kernel(const float *__restrict__ 
             nb += wgt * q[0]; ng += wgt * q[per]; nr += wgt * q[2 * per]; den += wgt;
         }
     const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)py * W + px;
-    y[o] = q8(nb / den) * (1.f / so);
-    y[o + plane] = q8(ng / den) * (1.f / so);
-    y[o + 2 * plane] = q8(nr / den) * (1.f / so);
+    const float rden = 1.f / den;                       // OPSPEC: normalise by one reciprocal, not three divisions
+    y[o] = q8(nb * rden) * (1.f / so);
+    y[o + plane] = q8(ng * rden) * (1.f / so);
+    y[o + 2 * plane] = q8(nr * rden) * (1.f / so);
 }
 
 // ---------------------------------------------------------------- global tone curves / white-world (plane streams)
