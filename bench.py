@@ -82,30 +82,34 @@ def timed(fn, steps, warmup, device, world):
     return wall, dev_ms / steps
 
 
-def kernel_time_ms(net, bay, reps, device, isp):
+def kernel_time_ms(net, batches, reps, device, isp):
     """Average launch duration of the dominant kernel (the one fused launch a step consists of), measured
     live with a HIP event pair on the launch stream around `reps` back-to-back launches issued straight
     through the C ABI (one ctypes call each, so the stream never drains and the figure is kernel + the
-    ~1.5 us same-stream launch boundary, not host time)."""
+    ~1.5 us same-stream launch boundary, not host time).  The launches rotate over `batches` (each with its own
+    output buffers): with one batch the 285 MB working set is largely served by the 256 MiB Infinity Cache,
+    with several it streams from / to HBM."""
     import reconfigisp_amd.functional as F
-    n = bay.shape[0]
+    n = batches[0].shape[0]
     with torch.no_grad():
         pars = list(net._stage_params(n))
-    if isp:     # demosaic | bilateral | wbmanual, gamma, gtmmanual
-        d = net.all_modules[1]._params(pars[1].detach(), {})
-        plan = F.BilateralChainPlan(bay, True, d['window_length'].to(torch.int32), d['sigma_color'], d['sigma_space'],
-                                    int(d['window_length'].max().item()),
-                                    [F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], [pars[2] * 5, pars[3], pars[4]])
-    else:       # skip | demosaic, wbmanual, gamma, gtmmanual (the kernel takes the gain = params * 5)
-        plan = F.ChainPlan(bay, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL],
-                           [None, pars[2] * 5, pars[3], pars[4]])
-    for _ in range(5):
-        plan.launch()
+    plans = []
+    for bay in batches:
+        if isp:     # demosaic | bilateral | wbmanual, gamma, gtmmanual
+            d = net.all_modules[1]._params(pars[1].detach(), {})
+            plans.append(F.BilateralChainPlan(bay, True, d['window_length'].to(torch.int32), d['sigma_color'],
+                                              d['sigma_space'], int(d['window_length'].max().item()),
+                                              [F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], [pars[2] * 5, pars[3], pars[4]]))
+        else:       # skip | demosaic, wbmanual, gamma, gtmmanual (the kernel takes the gain = params * 5)
+            plans.append(F.ChainPlan(bay, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL],
+                                     [None, pars[2] * 5, pars[3], pars[4]]))
+    for k in range(2 * len(plans)):
+        plans[k % len(plans)].launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
     e0.record()
-    for _ in range(reps):
-        plan.launch()
+    for k in range(reps):
+        plans[k % len(plans)].launch()
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / reps
@@ -168,6 +172,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='patches per GPU per step')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--eager', action='store_true', help='per-step Python dispatch instead of hipGraph replay')
+    ap.add_argument('--queue', type=int, default=4, help='resident batches per hipGraph replay (1 = one forward per '
+                                                          'replay); a step is still ONE forward over ONE batch')
     ap.add_argument('--no-cnn', action='store_true', help='skip the MFMA-bound reference-YAML pipeline')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     args = ap.parse_args()
@@ -190,12 +196,25 @@ def main():
     bay = bay_cpu.to(device)
     pix_per_step = args.batch * args.size * args.size
 
-    from reconfigisp_amd.graphs import GraphedForward
+    from reconfigisp_amd.graphs import GraphedForward, GraphedQueue
     net = build_pipeline(ARCH_DENOISE, device, 'OriginUniversal')
-    step = GraphedForward(net, bay) if not args.eager else (lambda: net(bay))
+    queue = args.queue if (not args.eager and args.queue > 1 and args.steps % args.queue == 0
+                           and args.warmup % args.queue == 0) else 1
+    # `queue` different batches resident in HBM, each with its own stage-output buffers
+    batches = [bay] + [make_batch(args.batch, args.size, args.size, seed=100 + 10 * rank + k)[0].to(device)
+                       for k in range(1, max(queue, 1))]
+    if args.eager:
+        step = lambda: net(bay)
+    elif queue > 1:
+        # one replay = `queue` steps (forwards), each on its own resident batch
+        step = GraphedQueue(net, batches)
+    else:
+        step = GraphedForward(net, bay)
     with torch.no_grad():
-        wall, dev_ms = timed(lambda: step(), args.steps, args.warmup, device, world)
-        kernel_ms = kernel_time_ms(net, bay, max(args.steps, 100), device, True)
+        wall, dev_ms = timed(lambda: step(), args.steps // queue, args.warmup // queue, device, world)
+        dev_ms /= queue
+        kernel_ms = kernel_time_ms(net, batches[:queue], max(args.steps, 100), device, True)
+        kernel_ms_cached = kernel_time_ms(net, batches[:1], max(args.steps, 100), device, True)
     value = world * pix_per_step * args.steps / wall / 1e6
     achieved = BYTES_PER_PIX_ISP * pix_per_step / (kernel_ms * 1e-3) / 1e9
 
@@ -203,9 +222,12 @@ def main():
     pstep = GraphedForward(pw, bay) if not args.eager else (lambda: pw(bay))
     with torch.no_grad():
         wall_p, dev_ms_p = timed(lambda: pstep(), args.steps, args.warmup, device, world)
-        kernel_ms_p = kernel_time_ms(pw, bay, max(args.steps, 100), device, False)
+        kernel_ms_p = kernel_time_ms(pw, batches[:queue], max(args.steps, 100), device, False)
     extra = {'kernel_ms': round(kernel_ms, 5), 'stream_ms_per_step': round(dev_ms, 5),
-             'launch': 'eager' if args.eager else 'hipGraph replay',
+             'resident_batches': queue,
+             'kernel_ms_one_batch_cache_assisted': round(kernel_ms_cached, 5),
+             'hbm_frac_one_batch_cache_assisted': round(BYTES_PER_PIX_ISP * pix_per_step / (kernel_ms_cached * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             'launch': 'eager' if args.eager else ('hipGraph replay, %d resident batches (steps) per replay' % queue),
              'pointwise_arch': ARCH_HBM,
              'pointwise_MPix_s': round(world * pix_per_step * args.steps / wall_p / 1e6, 1),
              'pointwise_kernel_ms': round(kernel_ms_p, 5),

@@ -10,6 +10,39 @@ ROCm); the library's launches land on the capturing stream because every C-ABI c
 import torch
 
 
+class GraphedQueue:
+    """Serving form: ONE graph replay runs the network over a queue of ``len(examples)`` resident batches
+    (distinct static input slots, distinct output buffers), so the per-replay launch latency (~8 us on this
+    stack, more than 10 % of a 55 us forward) is paid once per queue, not once per batch.
+
+    ``q = GraphedQueue(net, [b0, b1, b2, b3]); outs = q()`` -> list of network outputs, ``q.stage_outputs[k]``
+    the per-stage outputs of slot k.  ``q.load(k, x)`` copies new data into slot k."""
+
+    def __init__(self, net, examples, warmup=2):
+        self.net = net
+        self.slots = [e.detach().clone() for e in examples]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(warmup):
+                net(self.slots[0])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self.outputs, self.stage_outputs = [], []
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            for slot in self.slots:
+                self.outputs.append(net(slot))
+                self.stage_outputs.append(list(getattr(net, 'intermediate_results', [])))
+
+    def load(self, k, x):
+        self.slots[k].copy_(x, non_blocking=True)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.outputs
+
+
 class GraphedForward:
     """``g = GraphedForward(net, example); y = g(x)`` - x must keep the example's shape.
 

@@ -99,6 +99,16 @@ def test_headline_config_full_size_properties():
     with torch.no_grad():
         y2 = net(x2).clone()
     assert torch.equal(g(x2), y2)                                                          # replay on new data
+    from reconfigisp_amd.graphs import GraphedQueue
+    x3 = make_batch(64, 256, 256, seed=12)[0].cuda()
+    q = GraphedQueue(net, [x, x2, x3])
+    outs = q()
+    with torch.no_grad():
+        y3 = net(x3).clone()
+    assert torch.equal(outs[0], y) and torch.equal(outs[1], y2) and torch.equal(outs[2], y3)   # one replay, three batches
+    assert torch.equal(q.stage_outputs[1][1], O.demosaic_nearest(x2.cpu()).cuda())
+    q.load(0, x3)
+    assert torch.equal(q()[0], y3)
     from reconfigisp_amd.codes.utils import util
     assert util.psnr_tensors(y[:1], ref[:1].cuda()) > 60                              # PSNR(build, oracle) >> 0.01 dB bar
 
