@@ -118,6 +118,15 @@ __device__ __forceinline__ void store_row(float *p, const float *v) {
     for (int i = 0; i < 2 * QW; ++i) s[i] = v[i];
     *reinterpret_cast<typename RowVec<QW>::T *>(p) = t;
 }
+// the same row as a streaming (non-temporal) store: for outputs no later kernel of the launch sequence re-reads
+template <int QW>
+__device__ __forceinline__ void store_row_nt(float *p, const float *v) {
+    typedef float vt __attribute__((ext_vector_type(2 * QW)));
+    vt t;
+#pragma unroll
+    for (int i = 0; i < 2 * QW; ++i) t[i] = v[i];
+    __builtin_nontemporal_store(t, reinterpret_cast<vt *>(p));
+}
 
 // Bayer rows r0 (R G1 R G1 ..), r1 (G2 B G2 B ..) -> BGR pixels px[row][col]
 template <int QW>
@@ -161,6 +170,7 @@ __global__ __launch_bounds__(256) void demosaic_nearest_bwd_kernel(const float *
 struct ChainArgs {
     const float *in;
     int n_ops, N, H, W;
+    int last_out;               // index of the last stage that stores an output
     int ops[RISP_MAX_CHAIN];
     const float *params[RISP_MAX_CHAIN];
     float *outs[RISP_MAX_CHAIN];
@@ -207,9 +217,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 vg[i] = px[r][i].g;
                 vr[i] = px[r][i].r;
             }
-            store_row<QW>(o + ((size_t)n * 3 + 0) * plane + off + (size_t)r * W, vb);
-            store_row<QW>(o + ((size_t)n * 3 + 1) * plane + off + (size_t)r * W, vg);
-            store_row<QW>(o + ((size_t)n * 3 + 2) * plane + off + (size_t)r * W, vr);
+            float *ob = o + ((size_t)n * 3 + 0) * plane + off + (size_t)r * W;
+            if (k < a.last_out) {       // an intermediate stage output: nothing downstream reads it soon - stream it
+                store_row_nt<QW>(ob, vb);
+                store_row_nt<QW>(ob + plane, vg);
+                store_row_nt<QW>(ob + 2 * plane, vr);
+            } else {                    // the segment's result feeds the next launch: default cache policy
+                store_row<QW>(ob, vb);
+                store_row<QW>(ob + plane, vg);
+                store_row<QW>(ob + 2 * plane, vr);
+            }
         }
     }
 }
@@ -272,6 +289,7 @@ int risp_chain_fwd(const float *in, int n_ops, const int *ops, const float *cons
     ChainArgs a;
     a.in = in;
     a.n_ops = n_ops;
+    a.last_out = -1;
     a.N = N;
     a.H = H;
     a.W = W;
@@ -290,7 +308,11 @@ int risp_chain_fwd(const float *in, int n_ops, const int *ops, const float *cons
         a.ops[k] = op;
         a.params[k] = params[k];
         a.outs[k] = (op == RISP_OP_SKIP) ? nullptr : outs[k];
+        if (a.outs[k]) a.last_out = k;
     }
+#ifdef RISP_NT_ALL
+    a.last_out = RISP_MAX_CHAIN;
+#endif
     return chain_launch(a, stream);
 }
 

@@ -15,10 +15,14 @@ def timeit(fn, reps=20):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 
+for gib in (1, 4, 16):
+    big = torch.empty(gib << 28, device='cuda')
+    t = timeit(lambda: big.fill_(1.0), 10); print('fill %2d GiB           : %.2f TB/s written' % (gib, big.numel() * 4 / t / 1e12))
+    del big
 big = torch.empty(1 << 28, device='cuda')            # 1 GiB fp32
 src = torch.rand(1 << 28, device='cuda')
-t = timeit(lambda: big.fill_(1.0)); print('fill 1 GiB            : %.2f TB/s written' % (big.numel() * 4 / t / 1e12))
 t = timeit(lambda: big.copy_(src)); print('copy 1 GiB -> 1 GiB   : %.2f TB/s (read+write)' % (2 * big.numel() * 4 / t / 1e12))
+del big, src
 small = torch.empty(48 << 20, device='cuda')          # 192 MiB: fits the Infinity Cache
 t = timeit(lambda: small.fill_(1.0), 50); print('fill 192 MiB (cached) : %.2f TB/s written' % (small.numel() * 4 / t / 1e12))
 
@@ -26,7 +30,7 @@ n = 64
 sig = lambda v: torch.sigmoid(torch.tensor(v)).repeat(n, 1).cuda()
 pw, pg, pt = sig([-1.38] * 3) * 5, sig([0.]), sig([-1.099, 0., 1.099])
 sc = torch.full((n,), 50.5).cuda(); ss = torch.full((n,), 50.5).cuda(); w = torch.full((n,), 3, dtype=torch.int32).cuda()
-for sets in (1, 4, 8):
+for sets in (1, 2, 4, 8, 16, 32):
     bays = [make_batch(n, 256, 256, seed=10 + k)[0].cuda() for k in range(sets)]
     fused = [F.BilateralChainPlan(b, True, w, sc, ss, 3, [F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], [pw, pg, pt]) for b in bays]
     chain = [F.ChainPlan(b, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL], [None, pw, pg, pt]) for b in bays]
