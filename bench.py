@@ -20,6 +20,7 @@ already resident in HBM.  Workloads (SURVEY.md section 8d / BASELINE.md):
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -64,16 +65,25 @@ def timed(fn, steps, warmup, device, world):
         dist.barrier()
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gc.collect()
+    gc.disable()                # as timeit does: no cyclic-GC pause (tens of ms on a torch-sized heap) inside the timed region
     t0 = time.perf_counter()
     ev0.record()
+    marks = []
     for _ in range(steps):
         fn()
+        marks.append(time.perf_counter())
     ev1.record()
+    # host time to ISSUE a step (diagnostic): mean, median and worst single step
+    gaps = sorted(b - a for a, b in zip([t0] + marks[:-1], marks))
+    timed.host_us = (marks[-1] - t0) / steps * 1e6
+    timed.host_med_us, timed.host_max_us = gaps[len(gaps) // 2] * 1e6, gaps[-1] * 1e6
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
+    gc.enable()
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([wall], device=device, dtype=torch.float64)
@@ -171,9 +181,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=64, help='patches per GPU per step')
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--eager', action='store_true', help='per-step Python dispatch instead of hipGraph replay')
-    ap.add_argument('--queue', type=int, default=4, help='resident batches per hipGraph replay (1 = one forward per '
-                                                          'replay); a step is still ONE forward over ONE batch')
+    ap.add_argument('--launch', choices=('stream', 'graph'), default='stream',
+                    help="stream: every step is a Python call of the registry forward (one C-ABI launch on the stream; "
+                         "measured faster than hipGraph on this stack, whose kernel nodes are ~9 us apart); "
+                         "graph: hipGraph replay of `--queue` forwards")
+    ap.add_argument('--eager', action='store_true', help='alias of --launch stream')
+    ap.add_argument('--queue', type=int, default=4, help='resident batches the steps rotate over, each with its own '
+                                                          'stage-output buffers; a step is ONE forward over ONE batch')
     ap.add_argument('--no-cnn', action='store_true', help='skip the MFMA-bound reference-YAML pipeline')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     args = ap.parse_args()
@@ -198,45 +212,56 @@ def main():
 
     from reconfigisp_amd.graphs import GraphedForward, GraphedQueue
     net = build_pipeline(ARCH_DENOISE, device, 'OriginUniversal')
-    queue = args.queue if (not args.eager and args.queue > 1 and args.steps % args.queue == 0
-                           and args.warmup % args.queue == 0) else 1
+    graph = args.launch == 'graph' and not args.eager
+    queue = max(1, args.queue)
+    if graph and (args.steps % queue or args.warmup % queue):
+        queue = 1
     # `queue` different batches resident in HBM, each with its own stage-output buffers
     batches = [bay] + [make_batch(args.batch, args.size, args.size, seed=100 + 10 * rank + k)[0].to(device)
-                       for k in range(1, max(queue, 1))]
-    if args.eager:
-        step = lambda: net(bay)
-    elif queue > 1:
-        # one replay = `queue` steps (forwards), each on its own resident batch
-        step = GraphedQueue(net, batches)
-    else:
-        step = GraphedForward(net, bay)
+                       for k in range(1, queue)]
+
+    def rotating(fwd):          # step k runs the registry forward on resident batch k mod queue
+        state = [0]
+        def step():
+            fwd(batches[state[0] % queue])
+            state[0] += 1
+        return step
+
     with torch.no_grad():
-        wall, dev_ms = timed(lambda: step(), args.steps // queue, args.warmup // queue, device, world)
-        dev_ms /= queue
+        if graph:               # one replay = `queue` steps (forwards), each on its own resident batch
+            gq = GraphedQueue(net, batches)
+            wall, dev_ms = timed(lambda: gq(), args.steps // queue, args.warmup // queue, device, world)
+            dev_ms /= queue
+        else:
+            wall, dev_ms = timed(rotating(net), args.steps, args.warmup, device, world)
+        host_us = timed.host_us / (queue if graph else 1)
         kernel_ms = kernel_time_ms(net, batches[:queue], max(args.steps, 100), device, True)
         kernel_ms_cached = kernel_time_ms(net, batches[:1], max(args.steps, 100), device, True)
     value = world * pix_per_step * args.steps / wall / 1e6
     achieved = BYTES_PER_PIX_ISP * pix_per_step / (kernel_ms * 1e-3) / 1e9
 
     pw = build_pipeline(ARCH_HBM, device)
-    pstep = GraphedForward(pw, bay) if not args.eager else (lambda: pw(bay))
     with torch.no_grad():
+        pstep = GraphedForward(pw, bay) if graph else rotating(pw)
         wall_p, dev_ms_p = timed(lambda: pstep(), args.steps, args.warmup, device, world)
+        host_us_p = timed.host_us
         kernel_ms_p = kernel_time_ms(pw, batches[:queue], max(args.steps, 100), device, False)
     extra = {'kernel_ms': round(kernel_ms, 5), 'stream_ms_per_step': round(dev_ms, 5),
+             'host_issue_us_per_step': round(host_us, 1),
              'resident_batches': queue,
              'kernel_ms_one_batch_cache_assisted': round(kernel_ms_cached, 5),
              'hbm_frac_one_batch_cache_assisted': round(BYTES_PER_PIX_ISP * pix_per_step / (kernel_ms_cached * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-             'launch': 'eager' if args.eager else ('hipGraph replay, %d resident batches (steps) per replay' % queue),
+             'launch': ('hipGraph replay, %d resident batches (steps) per replay' % queue) if graph else
+                       ('one Python forward() per step on the stream, rotating over %d resident batches' % queue),
              'pointwise_arch': ARCH_HBM,
              'pointwise_MPix_s': round(world * pix_per_step * args.steps / wall_p / 1e6, 1),
-             'pointwise_kernel_ms': round(kernel_ms_p, 5),
+             'pointwise_kernel_ms': round(kernel_ms_p, 5), 'pointwise_host_issue_us_per_step': round(host_us_p, 1), 'pointwise_host_issue_us_med_max': [round(timed.host_med_us, 1), round(timed.host_max_us, 1)],
              'pointwise_hbm_GBs': round(BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms_p * 1e-3) / 1e9, 1),
              'pointwise_hbm_frac': round(BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if not args.no_cnn:
         cnn = build_pipeline(ARCH_CNN, device)
         steps_c = max(3, args.steps // 20)
-        cstep = GraphedForward(cnn, bay) if not args.eager else (lambda: cnn(bay))
+        cstep = GraphedForward(cnn, bay) if graph else (lambda: cnn(bay))
         with torch.no_grad():
             wall_c, dev_ms_c = timed(lambda: cstep(), steps_c, 2, device, world)
         extra.update(cnn_arch=ARCH_CNN, cnn_MPix_s=round(world * pix_per_step * steps_c / wall_c / 1e6, 1),
