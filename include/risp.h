@@ -157,7 +157,11 @@ enum { /* epilogue flags */
     RISP_EPI_ADD = 2,        /* y[:, :add_c] += add (N,add_c,H,W), before the activation */
     RISP_EPI_MASK = 4,       /* y = (mask[n,co,h,w] > 0) ? y : 0   (backward through a ReLU) */
     RISP_EPI_SHUFFLE2 = 8,   /* store through PixelShuffle(2): (N,cout,H,W) -> (N,cout/4,2H,2W) */
-    RISP_EPI_NOBIAS = 16
+    RISP_EPI_NOBIAS = 16,
+    RISP_EPI_CASEBIAS = 32   /* y[n,co,h,w] += cvals[n,co,case(h),case(w)]: cvals is a (N,cout,k,k) table, case(v) = v
+                                for v < k/2, k/2 in the interior, k-1-(L-1-v) for the last k/2 coordinates - the
+                                contribution of spatially constant input channels (zero in the padding) folded out
+                                of the layer: SRCNNRes broadcast planes, srcnn_res_arch.py:41-46.  Needs H,W >= k-1 */
 };
 typedef struct {
     int N, H, W;             /* H,W = conv resolution (half the source for RISP_LOAD_UNSHUFFLE2) */
@@ -173,6 +177,19 @@ size_t risp_conv_wpack_floats(int cin, int cout, int ksize);
 int risp_conv_pack_weights(const float *w, int cin, int cout, int ksize, int transpose, float *wpack,
                            void *stream);
 int risp_conv2d(const risp_conv_desc *d, void *stream);
+
+/* The same operator for layers with cout <= 4 (SRCNNRes conv 5x5 32->3, srcnn_res_arch.py:22; backward-data of its
+ * 9x9 first layer :18 restricted to the 3 image channels; Path-Restore tails): a direct vector-FMA kernel - the
+ * matrix-core kernel above pads cout to 32.  wpack: [cin][k][k][4] floats (couts padded to 4 with zeros), 16-byte
+ * aligned - the layer's weights w[co][ci][ky][kx] for a forward layer, w[ci_b][co_b][k-1-ky][k-1-kx] for a
+ * backward-data layer.  load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS; ksize in {3,5,9}. */
+size_t risp_conv_small_wpack_floats(int cin, int ksize);
+int risp_conv2d_small(const risp_conv_desc *d, void *stream);
+
+/* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
+ * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
+ * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */
+int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksize, void *stream);
 
 /* Backward-weight of the same layer: dw (cout,cin,k,k) = sum_{n,y,x} gy[n,co,y,x] * load(x)[n,ci,y+ky-p,x+kx-p]
  * (fully written).  Uses d->x, load_mode (PLAIN / CONSTCH), cin_img, cvals, N, H, W, cin, cout, ksize; gy is

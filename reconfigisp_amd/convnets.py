@@ -18,7 +18,7 @@ from . import lib as L
 from .functional import _dev, _p, _stream, channel_stats
 
 LOAD_PLAIN, LOAD_UNSHUFFLE2, LOAD_CONSTCH = 0, 1, 2
-EPI_RELU, EPI_ADD, EPI_MASK, EPI_SHUFFLE2, EPI_NOBIAS = 1, 2, 4, 8, 16
+EPI_RELU, EPI_ADD, EPI_MASK, EPI_SHUFFLE2, EPI_NOBIAS, EPI_CASEBIAS = 1, 2, 4, 8, 16, 32
 
 
 class PackedConv:
@@ -33,6 +33,37 @@ class PackedConv:
         self.bwd = torch.empty(lib.risp_conv_wpack_floats(self.cout, self.cin, self.k), device=w.device)
         L.call('risp_conv_pack_weights', _p(w), self.cin, self.cout, self.k, 0, _p(self.fwd), _stream())
         L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
+
+
+class SmallConv:
+    """Weights of a layer with at most 4 output channels in the [cin][k][k][4] layout of ``risp_conv2d_small``.
+    ``weight`` is the layer's (cout,cin,k,k) tensor; ``transpose=True`` builds the backward-data layer of a
+    FORWARD weight (roles swapped, taps rotated by 180 degrees), restricted to its first ``keep`` input channels."""
+
+    def __init__(self, weight, bias=None, transpose=False, keep=None):
+        w = _dev(weight.detach(), 'weight')
+        if transpose:
+            w = w[:, :keep].flip(2, 3).permute(0, 2, 3, 1)            # [cin_b = cout_f][ky][kx][cout_b = cin_f]
+        else:
+            w = w.permute(1, 2, 3, 0)                                  # [cin][ky][kx][cout]
+        self.cin, self.k, self.cout = w.shape[0], w.shape[1], w.shape[3]
+        if self.cout > 4:
+            raise ValueError('SmallConv: %d output channels (at most 4)' % self.cout)
+        self.wpack = torch.zeros((self.cin, self.k, self.k, 4), device=w.device, dtype=torch.float32)
+        self.wpack[..., :self.cout] = w
+        self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
+
+
+def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
+    """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 4)."""
+    if sc.bias is None:
+        epi |= EPI_NOBIAS
+    out = torch.empty((n, sc.cout, h, w), device=x.device, dtype=torch.float32)
+    d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
+                   add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
+                   y=_p(out))
+    L.call('risp_conv2d_small', C.byref(d), _stream())
+    return out
 
 
 def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None, epi=0, add=None, add_c=0,
@@ -173,6 +204,81 @@ class _SrcnnRes(torch.autograd.Function):
         return gx, sums[3], None
 
 
+class SrcnnResFold:
+    """Weight-only tables that take the 9+P broadcast planes (srcnn_res_arch.py:41-46: per-image constants inside
+    the image, zero in the padding) out of the 9x9 first layer, and the small-cout forms of the 3-channel ends:
+
+      img     the layer restricted to its 3 image channels (matrix-core pack)
+      rcase   (9+P, 64*81): rcase[c, co, i, j] = sum of w[co, 3+c] over the taps inside the image for border case
+              (i, j) - forward, the constants contribute ``cvals @ rcase`` per (image, cout, case): RISP_EPI_CASEBIAS
+      wconst  (64*81, 9+P): backward, d loss / d constant = risp_rect_sums(upstream) @ wconst
+      bwd_img backward-data of the layer for the 3 image channels (direct kernel)
+      tail    the 5x5 32->3 last layer (direct kernel)
+    """
+
+    def __init__(self, conv1, conv3):
+        w1 = _dev(conv1.weight.detach(), 'weight')                    # (64, 12+P, 9, 9)
+        k, p = w1.shape[2], w1.shape[2] // 2
+        self.k = k
+        self.img = PackedConv(w1[:, :3].contiguous(), conv1.bias)
+        wc = w1[:, 3:]                                               # (64, 9+P, 9, 9)
+        cases = []
+        for i in range(k):                                           # taps lo..hi of case i survive
+            lo, hi = (p - i, k - 1) if i < p else (0, k - 1 - (i - p))
+            cases.append((lo, hi))
+        rc = torch.stack([torch.stack([wc[:, :, a:b + 1, c:d + 1].sum(dim=(2, 3)) for (c, d) in cases], dim=-1)
+                          for (a, b) in cases], dim=-2)              # (64, 9+P, k, k)
+        self.rcase = rc.permute(1, 0, 2, 3).reshape(wc.shape[1], -1).contiguous()
+        self.wconst = wc.permute(0, 2, 3, 1).reshape(-1, wc.shape[1]).contiguous()
+        self.bwd_img = SmallConv(w1, None, transpose=True, keep=3)
+        self.tail = SmallConv(conv3.weight, conv3.bias)
+
+
+def _srcnn_fold_ok(h, w, k=9):
+    return h >= k - 1 and w >= k - 1
+
+
+class _SrcnnResFolded(torch.autograd.Function):
+    """SRCNNRes with the broadcast planes folded out of the first layer (see SrcnnResFold): the 9x9 layer runs
+    over 3 channels instead of 12+P, its backward-data over 3 output channels instead of 32 padded ones."""
+
+    @staticmethod
+    def forward(ctx, x, pv, packs):
+        x = _dev(x, 'img')
+        n, _, h, w = x.shape
+        c1, c2, c3 = packs
+        fold = c1.fold
+        P = c1.cin - 12
+        pv = _dev(pv, 'params') if P else None
+        stats, arg = channel_stats(x)
+        cvals = torch.empty((n, 9 + P), device=x.device, dtype=torch.float32)
+        L.call('risp_srcnn_cvals', _p(stats), _p(pv), _p(cvals), n, P, h * w, _stream())
+        table = torch.mm(cvals, fold.rcase)                              # (N, 64*81) border-case constants
+        t1 = conv(x, fold.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table)
+        t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
+        y = conv_small(t2, fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3)
+        ctx.save_for_backward(t1, t2, arg)
+        ctx.packs, ctx.dims = packs, (n, h, w, P)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t1, t2, arg = ctx.saved_tensors
+        c1, c2, c3 = ctx.packs
+        fold = c1.fold
+        n, h, w, P = ctx.dims
+        gy = _dev(gy, 'grad')
+        g2 = conv(gy, c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2)
+        g1 = conv(g2, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1)
+        gx = conv_small(g1, fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3)     # image channels + residual path
+        rs = torch.empty((n, c1.cout * fold.k * fold.k), device=gy.device, dtype=torch.float32)
+        L.call('risp_rect_sums', _p(g1), _p(rs), n * c1.cout, h, w, fold.k, _stream())
+        gconst = torch.mm(rs, fold.wconst)                              # (N, 9+P): min, mean, max planes, then params
+        smin, smean, smax = (gconst[:, 0:3].contiguous(), gconst[:, 3:6].contiguous(), gconst[:, 6:9].contiguous())
+        L.call('risp_stats_bwd', _p(gx), _p(smin), _p(smean), _p(smax), _p(arg), n * 3, h * w, _stream())
+        return gx, (gconst[:, 9:].contiguous() if P else None), None
+
+
 class _SrcnnResTrain(torch.autograd.Function):
     """SRCNNRes whose six conv tensors are autograd inputs: backward also returns their gradients
     (risp_conv2d_wgrad).  Used only while a proxy is being fine-tuned against its classical teacher."""
@@ -227,6 +333,8 @@ def srcnn_res(x, pv, packs, train_module=None):
         seq = train_module.srcnn
         return _SrcnnResTrain.apply(x, pv, packs, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias,
                                     seq[4].weight, seq[4].bias)
+    if getattr(packs[0], 'fold', None) is not None and _srcnn_fold_ok(x.shape[2], x.shape[3]):
+        return _SrcnnResFolded.apply(x, pv, packs)
     return _SrcnnRes.apply(x, pv, packs)
 
 
@@ -260,6 +368,9 @@ def srcnn_demosaic(x, packs):
     return _SrcnnDemosaic.apply(x, packs)
 
 
-def build_srcnn_packs(seq):
-    """seq = module.srcnn (conv, ReLU, conv, ReLU, conv[, PixelShuffle])."""
-    return tuple(PackedConv(seq[i].weight, seq[i].bias) for i in (0, 2, 4))
+def build_srcnn_packs(seq, residual=False):
+    """seq = module.srcnn (conv, ReLU, conv, ReLU, conv[, PixelShuffle]).  ``residual``: the SRCNNRes form, whose
+    first layer also gets the folded tables (SrcnnResFold)."""
+    packs = tuple(PackedConv(seq[i].weight, seq[i].bias) for i in (0, 2, 4))
+    packs[0].fold = SrcnnResFold(seq[0], seq[4]) if residual and seq[4].weight.shape[0] <= 4 else None
+    return packs

@@ -59,6 +59,12 @@ ConvCfg conv_cfg(int cin, int cout, int ks) {
     return c;
 }
 
+// Which taps of a k-wide window centred on coordinate v fall inside [0, L): case P = all of them (interior),
+// case i < P = the first P - i are cut off, case P + j = the last j are cut off.  Needs L >= 2 P.
+__device__ __forceinline__ int border_case(int v, int L, int P) {
+    return v < P ? v : (v >= L - P ? 2 * P - (L - 1 - v) : P);
+}
+
 __device__ __forceinline__ float load_px(const risp_conv_desc &d, int n, int ci, int gy, int gx) {
     if (ci >= d.cin || gy < 0 || gy >= d.H || gx < 0 || gx >= d.W) return 0.f;
     if (d.load_mode == RISP_LOAD_PLAIN) return d.x[(((size_t)n * d.cin + ci) * d.H + gy) * d.W + gx];
@@ -278,6 +284,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
             bq[i] = (!(epi & RISP_EPI_NOBIAS) && co < d.cout) ? pbias[co] : 0.f;
         }
         const int q4 = 4 * (lane & 7);
+        // RISP_EPI_CASEBIAS: a (cout, KS, KS) table per image (d.cvals) indexed by how close the pixel is to the
+        // image border - the contribution of spatially constant input channels that were folded out of the layer.
+        // Interior tiles see one case only, which joins the bias.
+        const bool caseb = (epi & RISP_EPI_CASEBIAS) != 0;
+        const float *__restrict__ ctab = d.cvals + (size_t)n * d.cout * TAPS;
+        const bool case_edge = caseb && (x0 < PAD || y0 < PAD || x0 + TW > d.W - PAD || y0 + TH > d.H - PAD);
+        if (caseb && !case_edge) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int co = (lane >> 3) + 8 * i;
+                if (co < d.cout) bq[i] += ctab[co * TAPS + PAD * KS + PAD];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int oy = y0 + wrow + r;
@@ -311,6 +330,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
                 o.y = v[i].y + bq[i] + av[i].y;
                 o.z = v[i].z + bq[i] + av[i].z;
                 o.w = v[i].w + bq[i] + av[i].w;
+                if (case_edge && row_ok && co < d.cout) {
+                    const float *ct = ctab + co * TAPS + border_case(oy, d.H, PAD) * KS;
+                    const int ox4 = x0 + q4;
+                    o.x += ct[border_case(ox4, d.W, PAD)];
+                    o.y += ct[border_case(ox4 + 1, d.W, PAD)];
+                    o.z += ct[border_case(ox4 + 2, d.W, PAD)];
+                    o.w += ct[border_case(ox4 + 3, d.W, PAD)];
+                }
                 if (epi & RISP_EPI_RELU) {
                     o.x = o.x > 0.f ? o.x : 0.f;
                     o.y = o.y > 0.f ? o.y : 0.f;
@@ -374,6 +401,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
                 const int co = c * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 if (co >= d.cout) continue;
                 float v = acc[r][c][e] + bv[c][e] + av[e];
+                if (epi & RISP_EPI_CASEBIAS)
+                    v += d.cvals[((size_t)n * d.cout + co) * TAPS + border_case(oy, d.H, PAD) * KS + border_case(ox, d.W, PAD)];
                 if (epi & RISP_EPI_RELU) v = v > 0.f ? v : 0.f;
                 v = mv[e] > 0.f ? v : 0.f;
                 if (epi & RISP_EPI_SHUFFLE2) {
@@ -480,6 +509,9 @@ int risp_conv2d(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(d.load_mode != RISP_LOAD_UNSHUFFLE2 || d.cin % 4 == 0, "risp_conv2d: unshuffle load needs cin %% 4 == 0");
     RISP_CHECK_ARG(d.load_mode != RISP_LOAD_CONSTCH || (d.cvals && d.cin_img > 0 && d.cin_img <= d.cin),
                    "risp_conv2d: const-channel load needs cvals and cin_img");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_CASEBIAS) ||
+                       (d.cvals && d.load_mode != RISP_LOAD_CONSTCH && d.H >= 2 * (d.ksize / 2) && d.W >= 2 * (d.ksize / 2)),
+                   "risp_conv2d: border-case bias needs its table in cvals, a non-const-channel load and H, W >= k - 1");
     const ConvCfg c = conv_cfg(d.cin, d.cout, d.ksize);
     hipStream_t s = (hipStream_t)stream;
 #define RISP_CONV_CASE(KS, CK, CB) \

@@ -1,0 +1,250 @@
+// Direct (vector-ALU) convolution for layers with at most 4 output channels, and the rectangle sums that replace
+// a convolution over spatially constant channels.
+//
+// Why: the fp32 matrix-core kernel (risp_conv.hip) tiles the output channels in blocks of 32, so the 3-channel
+// heads and tails of the proxies issue 8-10x the useful work there:
+//   * SRCNNRes conv 5x5 32->3            (srcnn_res_arch.py:22)              forward
+//   * SRCNNRes conv 9x9 (12+P)->64       (srcnn_res_arch.py:18)              backward-data, image channels only
+// On CDNA4 the packed fp32 vector FMA has the same peak as the fp32 MFMA (157 TFLOP/s), so a direct kernel with
+// 4 output channels per pixel loses nothing to padding: weights are wave-uniform (scalar loads feed
+// v_pk_fma_f32 straight from SGPR pairs), activations come from an LDS halo tile as 3 x 128-bit reads per filter
+// row and are reused across the k taps of the row and the 4 pixels of the thread.
+//
+// The 9+P broadcast channels of SRCNNRes (srcnn_res_arch.py:41-46) are per-image constants inside the image and
+// zero in the padding.  Forward, their contribution is a per-(image, cout, border case) constant (risp_conv2d
+// RISP_EPI_CASEBIAS); backward, the gradient of constant c is sum_{co,tap} W[co][c][tap] * S[co][tap] with S the
+// sum of the upstream gradient over the pixels whose tap lands inside the image - risp_rect_sums below.
+#include "risp_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int SX = 64, SPX = 4, SPY = 2;     // tile width; SPX x SPY pixels per thread
+constexpr int SY = 16 * SPY;                 // tile height (16 x 16 threads)
+constexpr int HPAD = 4;                      // halo columns kept left and right of the tile (>= k/2, multiple of 4)
+constexpr int STW = SX + 2 * HPAD;           // LDS row stride: tile column t <-> image x0 - HPAD + t
+
+template <int KS> struct SmallCfg { static constexpr int CCH = KS == 9 ? 3 : 4; };   // input channels per LDS stage
+
+// Thread = 4 x 2 output pixels x 4 couts (16 packed accumulators).  Per input channel the thread walks the
+// KS + 1 tile rows its two output rows need: each row is 3 x 128-bit LDS reads, used by the taps of BOTH output
+// rows, and each filter row (KS x 4 wave-uniform weights, scalar loads) serves both output rows too.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d) {
+    constexpr int P = KS / 2, TH_ = SY + 2 * P, CCH = SmallCfg<KS>::CCH, ROWV = STW / 4;
+    extern __shared__ float4 lds4[];                       // [CCH][TH_][STW]
+    const int tid = threadIdx.x, n = blockIdx.z, x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
+    const int lx = (tid & 15) * SPX, ly = (tid >> 4) * SPY;
+    const int H = d.H, W = d.W, cin = d.cin;
+    const size_t plane = (size_t)H * W;
+    const float *__restrict__ xin = d.x + (size_t)n * cin * plane;
+    const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(d.wpack);      // [cin][KS][KS] x 4 couts
+    const bool vecw = (W & 3) == 0;
+
+    f32x2 acc[SPY][SPX][2];
+#pragma unroll
+    for (int r = 0; r < SPY; ++r)
+#pragma unroll
+        for (int p = 0; p < SPX; ++p) acc[r][p][0] = acc[r][p][1] = (f32x2){0.f, 0.f};
+
+    // Staging: all global loads of a stage are issued (into registers) before the first LDS write, so a stage costs
+    // one memory round trip, which the other resident workgroups of the CU cover with their FMAs.
+    constexpr int NIT = (CCH * TH_ * ROWV + 255) / 256;
+    float4 pf[NIT];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int c = idx / (TH_ * ROWV), rem = idx - c * (TH_ * ROWV);
+            const int ty = rem / ROWV, v = rem - ty * ROWV;
+            const int gy = y0 - P + ty, gx = x0 - HPAD + 4 * v, ci = c0 + c;
+            const bool row_ok = idx < CCH * TH_ * ROWV && ci < cin && gy >= 0 && gy < H;
+            const float *src = xin + (size_t)(row_ok ? ci : 0) * plane + (size_t)(row_ok ? gy : 0) * W;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vecw) {                                    // W % 4 == 0: the float4 is entirely in or out
+                if (row_ok && gx >= 0 && gx < W) q = *reinterpret_cast<const float4 *>(src + gx);
+            } else {
+                float *e = reinterpret_cast<float *>(&q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (row_ok && gx + j >= 0 && gx + j < W) e[j] = src[gx + j];
+            }
+            pf[it] = q;
+        }
+    };
+    for (int c0 = 0; c0 < cin; c0 += CCH) {
+        fetch(c0);
+        __syncthreads();                                   // the previous stage has been consumed
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            if (idx < CCH * TH_ * ROWV) lds4[idx] = pf[it];
+        }
+        __syncthreads();
+        const int cn = cin - c0 < CCH ? cin - c0 : CCH;
+        for (int c = 0; c < cn; ++c) {
+            const float4 *wch = wp + (size_t)(c0 + c) * KS * KS;                   // wave-uniform -> scalar loads
+#pragma unroll
+            for (int r = 0; r < KS + SPY - 1; ++r) {                               // tile row ly + r
+                const float4 *row = lds4 + ((c * TH_ + ly + r) * STW + lx) / 4;
+                const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+                const float a[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+                for (int o = 0; o < SPY; ++o) {                                    // output row o sees it as filter row r - o
+                    const int ky = r - o;
+                    if (ky < 0 || ky >= KS) continue;
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const float4 w = wch[ky * KS + kx];
+                        const f32x2 w01 = {w.x, w.y}, w23 = {w.z, w.w};
+#pragma unroll
+                        for (int p = 0; p < SPX; ++p) {
+                            const float av = a[HPAD - P + kx + p];
+                            const f32x2 a2 = {av, av};
+                            acc[o][p][0] = __builtin_elementwise_fma(a2, w01, acc[o][p][0]);
+                            acc[o][p][1] = __builtin_elementwise_fma(a2, w23, acc[o][p][1]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, residual add, ReLU, ReLU mask; one 16-byte store per output plane and row
+    const int ox = x0 + lx, epi = d.epilogue;
+    if (ox >= W) return;
+    const bool full = vecw || ox + SPX <= W;
+#pragma unroll
+    for (int o = 0; o < SPY; ++o) {
+        const int oy = y0 + ly + o;
+        if (oy >= H) break;
+        const size_t pix = (size_t)oy * W + ox;
+        for (int co = 0; co < d.cout; ++co) {
+            const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co];
+            float v[SPX];
+#pragma unroll
+            for (int p = 0; p < SPX; ++p) v[p] = (co & 1 ? acc[o][p][co >> 1].y : acc[o][p][co >> 1].x) + b;
+            if ((epi & RISP_EPI_ADD) && co < d.add_c) {
+                const float *ap = d.add + ((size_t)n * d.add_c + co) * plane + pix;
+#pragma unroll
+                for (int p = 0; p < SPX; ++p)
+                    if (full || ox + p < W) v[p] += ap[p];
+            }
+            if (epi & RISP_EPI_RELU) {
+#pragma unroll
+                for (int p = 0; p < SPX; ++p) v[p] = v[p] > 0.f ? v[p] : 0.f;
+            }
+            if (epi & RISP_EPI_MASK) {
+                const float *mp = d.mask + ((size_t)n * d.cout + co) * plane + pix;
+#pragma unroll
+                for (int p = 0; p < SPX; ++p)
+                    if (full || ox + p < W) v[p] = mp[p] > 0.f ? v[p] : 0.f;
+            }
+            float *yp = d.y + ((size_t)n * d.cout + co) * plane + pix;
+            if (vecw) {
+                *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < SPX; ++p)
+                    if (ox + p < W) yp[p] = v[p];
+            }
+        }
+    }
+}
+
+// S[plane][ky][kx] = sum of g over the pixels q of the plane with q + (ky - P, kx - P) inside the image.
+// One workgroup per plane; a wave takes every fourth row.
+constexpr int RK_MAX = 9;
+__global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict__ g, float *__restrict__ out, int H, int W,
+                                                        int K) {
+    const int P = K / 2;
+    const float *gp = g + (size_t)blockIdx.x * H * W;
+    __shared__ float all_rows[4][RK_MAX];                  // per wave: sum over its rows of the K column-range sums
+    __shared__ float edge_rows[2 * (RK_MAX / 2)][RK_MAX];  // column-range sums of the first P and last P rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float tot[RK_MAX];
+#pragma unroll
+    for (int j = 0; j < RK_MAX; ++j) tot[j] = 0.f;
+    for (int y = wave; y < H; y += 4) {
+        const float *row = gp + (size_t)y * W;
+        float t = 0.f;
+        for (int x = lane; x < W; x += 64) t += row[x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        // column range of tap kx (dx = kx - P): dx < 0 drops the first -dx columns, dx > 0 the last dx columns
+        float cs[RK_MAX];
+        float l = 0.f, r = 0.f;
+        cs[P] = t;
+        for (int k = 1; k <= P; ++k) {
+            l += row[k - 1];
+            r += row[W - k];
+            cs[P - k] = t - l;
+            cs[P + k] = t - r;
+        }
+        for (int j = 0; j < K; ++j) tot[j] += cs[j];
+        if (lane == 0) {
+            if (y < P)
+                for (int j = 0; j < K; ++j) edge_rows[y][j] = cs[j];
+            if (y >= H - P)
+                for (int j = 0; j < K; ++j) edge_rows[P + (H - 1 - y)][j] = cs[j];     // P + distance from the bottom
+        }
+    }
+    if (lane == 0)
+        for (int j = 0; j < K; ++j) all_rows[wave][j] = tot[j];
+    __syncthreads();
+    if (threadIdx.x < K * K) {
+        const int i = threadIdx.x / K, j = threadIdx.x - i * K, dy = i - P;
+        float s = all_rows[0][j] + all_rows[1][j] + all_rows[2][j] + all_rows[3][j];
+        for (int k = 0; k < -dy; ++k) s -= edge_rows[k][j];             // dy < 0: rows 0 .. -dy-1 have no source
+        for (int k = 0; k < dy; ++k) s -= edge_rows[P + k][j];          // dy > 0: the last dy rows
+        out[(size_t)blockIdx.x * K * K + threadIdx.x] = s;
+    }
+}
+
+template <int KS>
+int launch_small(const risp_conv_desc &d, hipStream_t s) {
+    constexpr int P = KS / 2;
+    const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (SY + 2 * P) * STW;
+    dim3 grid((d.W + SX - 1) / SX, (d.H + SY - 1) / SY, d.N);
+    hipLaunchKernelGGL(conv_small_kernel<KS>, grid, dim3(256), lds, s, d);
+    RISP_LAUNCH_CHECK("risp_conv2d_small");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t risp_conv_small_wpack_floats(int cin, int ksize) { return (size_t)cin * ksize * ksize * 4; }
+
+int risp_conv2d_small(const risp_conv_desc *dp, void *stream) {
+    RISP_CHECK_ARG(dp, "risp_conv2d_small: null descriptor");
+    const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_small: null tensor");
+    RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 4,
+                   "risp_conv2d_small: bad shape N=%d H=%d W=%d cin=%d cout=%d (cout <= 4)", d.N, d.H, d.W, d.cin, d.cout);
+    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_small: only plain loads");
+    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
+                   "risp_conv2d_small: epilogue %d not supported", d.epilogue);
+    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_small: bias missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_small: add tensor missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_small: mask tensor missing");
+    RISP_CHECK_ARG((reinterpret_cast<uintptr_t>(d.wpack) & 15) == 0, "risp_conv2d_small: wpack must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (d.ksize == 3) return launch_small<3>(d, s);
+    if (d.ksize == 5) return launch_small<5>(d, s);
+    if (d.ksize == 9) return launch_small<9>(d, s);
+    risp_set_error("risp_conv2d_small: unsupported kernel size %d", d.ksize);
+    return 1;
+}
+
+int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksize, void *stream) {
+    RISP_CHECK_ARG(g && out && planes > 0 && H > 0 && W > 0, "risp_rect_sums: bad arguments");
+    RISP_CHECK_ARG((ksize & 1) && ksize >= 1 && ksize <= RK_MAX && H >= ksize / 2 && W >= ksize / 2,
+                   "risp_rect_sums: window %d on a %dx%d plane", ksize, H, W);
+    hipLaunchKernelGGL(rect_sums_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, g, out, H, W, ksize);
+    RISP_LAUNCH_CHECK("risp_rect_sums");
+    return 0;
+}
+
+}  // extern "C"

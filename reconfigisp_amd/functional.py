@@ -341,7 +341,7 @@ class _HipImpl:
     @staticmethod
     def srcnn_res(x, pv, module):
         from . import convnets as CN
-        packs = _packs(module, lambda: CN.build_srcnn_packs(module.srcnn))
+        packs = _packs(module, lambda: CN.build_srcnn_packs(module.srcnn, residual=True))
         # weight gradients only on request (proxy fine-tuning sets module.train_weights); the search itself never
         # uses them, although the proxies' tensors nominally require grad
         training = getattr(module, 'train_weights', False) and torch.is_grad_enabled()

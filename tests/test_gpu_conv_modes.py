@@ -132,3 +132,90 @@ def test_srcnn_res_weight_gradients_vs_oracle():
     ggot = torch.autograd.grad(yg, [params[k] for k in keys], gy.cuda())
     for k, a, b in zip(keys, ggot, gref):
         assert_close(a, b, rtol=2e-4, what='grad ' + k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# direct small-cout kernel (risp_conv2d_small), rectangle sums, border-case bias
+@pytest.mark.parametrize('cin,cout,k', [(32, 3, 5), (64, 3, 9), (64, 4, 3), (5, 1, 3), (13, 2, 9), (64, 3, 3)])
+@pytest.mark.parametrize('hw', SIZES + [(9, 10), (17, 66)])
+def test_small_cout_forward_and_backward_data(cin, cout, k, hw):
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n = 2
+    wt, b = rnd(cout, cin, k, k, seed=11) * 0.1, rnd(cout, seed=12) * 0.1
+    x = rnd(n, cin, h, w, seed=13)
+    ref = TF.conv2d(x, wt, b, padding=k // 2)
+    assert_close(CN.conv_small(x, CN.SmallConv(wt, b), n, h, w), ref, what='small fwd')
+    # backward-data of a FORWARD layer (cout_f -> the first `keep` input channels)
+    wf = rnd(cin, 7, k, k, seed=14) * 0.1                     # forward layer 7 -> cin channels
+    keep = min(cout, 4)
+    xin = rnd(n, 7, h, w, seed=15).requires_grad_(True)
+    gref, = torch.autograd.grad(TF.conv2d(xin, wf, None, padding=k // 2), xin, x)
+    got = CN.conv_small(x, CN.SmallConv(wf, None, transpose=True, keep=keep), n, h, w)
+    assert_close(got, gref[:, :keep], what='small bwd-data')
+
+
+@pytest.mark.parametrize('hw', [(16, 32), (33, 30), (40, 72)])
+def test_small_cout_epilogues(hw):
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n, cin = 2, 32
+    wt, b = rnd(3, cin, 5, 5, seed=21) * 0.1, rnd(3, seed=22) * 0.1
+    sc = CN.SmallConv(wt, b)
+    x, add, mask = rnd(n, cin, h, w, seed=23), rnd(n, 3, h, w, seed=24), rnd(n, 3, h, w, seed=25)
+    lin = TF.conv2d(x, wt, b, padding=2)
+    assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_RELU), torch.relu(lin), what='relu')
+    assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=3), torch.relu(lin + add),
+                 what='add+relu')
+    assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_MASK, mask=mask), lin * (mask > 0), what='mask')
+    part = lin.clone()
+    part[:, :2] += add[:, :2]
+    assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_ADD, add=add[:, :2].contiguous(), add_c=2), part, what='partial add')
+
+
+@pytest.mark.parametrize('k', [3, 5, 9])
+@pytest.mark.parametrize('hw', [(8, 8), (9, 13), (33, 30), (64, 256)])
+def test_rect_sums_are_the_constant_channel_gradient(k, hw):
+    """risp_rect_sums(g) @ w == d/dc of sum(g * conv(c * ones)) for a spatially constant, zero-padded channel."""
+    from reconfigisp_amd import lib as L
+    from reconfigisp_amd.functional import _p, _stream
+    h, w = hw
+    n, cout, nconst = 2, 6, 4
+    g = rnd(n, cout, h, w, seed=31)
+    wt = rnd(cout, nconst, k, k, seed=32)
+    rs = torch.empty((n, cout * k * k), device='cuda')
+    L.call('risp_rect_sums', _p(g), _p(rs), n * cout, h, w, k, _stream())
+    got = rs @ wt.permute(0, 2, 3, 1).reshape(-1, nconst)
+    cv = rnd(n, nconst, seed=33).requires_grad_(True)
+    planes = cv[:, :, None, None].expand(n, nconst, h, w)
+    (TF.conv2d(planes, wt, None, padding=k // 2) * g).sum().backward()
+    assert_close(got, cv.grad, what='const-channel grad', rtol=2e-4, floor=1.0)
+
+
+@pytest.mark.parametrize('P', [1, 3, 5])
+@pytest.mark.parametrize("hw", [(8, 8), (8, 12), (20, 36), (40, 72), (34, 30)])
+def test_srcnn_res_folded_equals_unfolded(P, hw):
+    """The broadcast planes folded out of the 9x9 layer (border-case bias forward, rectangle sums backward, direct
+    kernels for the 3-channel ends) against the plain 12+P-channel convolution path: outputs, input gradient,
+    parameter gradient."""
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n = 2
+    seq = torch.nn.Sequential(torch.nn.Conv2d(12 + P, 64, 9, padding=4), torch.nn.ReLU(), torch.nn.Conv2d(64, 32, 5, padding=2),
+                              torch.nn.ReLU(), torch.nn.Conv2d(32, 3, 5, padding=2)).cuda()
+    torch.manual_seed(5)
+    for m in seq:
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.normal_(m.weight, std=0.05)
+            torch.nn.init.normal_(m.bias, std=0.1)
+    packs = CN.build_srcnn_packs(seq, residual=True)
+    assert packs[0].fold is not None
+    x0, pv0, gy = torch.rand(n, 3, h, w, device='cuda'), torch.rand(n, P, device='cuda'), rnd(n, 3, h, w, seed=41)
+    res = []
+    for fn in (CN._SrcnnResFolded, CN._SrcnnRes):
+        x, pv = x0.clone().requires_grad_(True), pv0.clone().requires_grad_(True)
+        y = fn.apply(x, pv, packs)
+        y.backward(gy)
+        res.append((y.detach(), x.grad, pv.grad))
+    for a, b, what in zip(res[0], res[1], ('output', 'input grad', 'param grad')):
+        assert_close(a, b, what=what, rtol=2e-4, floor=1.0)
