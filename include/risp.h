@@ -182,7 +182,8 @@ int risp_conv2d(const risp_conv_desc *d, void *stream);
  * 9x9 first layer :18 restricted to the 3 image channels; Path-Restore tails): a direct vector-FMA kernel - the
  * matrix-core kernel above pads cout to 32.  wpack: [cin][k][k][4] floats (couts padded to 4 with zeros), 16-byte
  * aligned - the layer's weights w[co][ci][ky][kx] for a forward layer, w[ci_b][co_b][k-1-ky][k-1-kx] for a
- * backward-data layer.  load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS; ksize in {3,5,9}. */
+ * backward-data layer.  load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout == 4;
+ * ksize in {3,5,9}. */
 size_t risp_conv_small_wpack_floats(int cin, int ksize);
 int risp_conv2d_small(const risp_conv_desc *d, void *stream);
 

@@ -58,7 +58,8 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
     """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 4)."""
     if sc.bias is None:
         epi |= EPI_NOBIAS
-    out = torch.empty((n, sc.cout, h, w), device=x.device, dtype=torch.float32)
+    shape = (n, 1, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, sc.cout, h, w)
+    out = torch.empty(shape, device=x.device, dtype=torch.float32)
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
@@ -122,7 +123,8 @@ class _Path14l(torch.autograd.Function):
             u = conv(r, c1, n, h, w, epi=EPI_RELU)
             r = conv(u, c2, n, h, w, epi=EPI_ADD | EPI_RELU, add=r, add_c=64)
             saved += [u, r]
-        y = conv(r, last, n, h, w, epi=EPI_SHUFFLE2 if bayer else 0)
+        # the 64 -> 4 / 3 tail runs on the direct small-cout kernel (the matrix-core kernel pads cout to 32)
+        y = conv_small(r, last.small, n, h, w, epi=EPI_SHUFFLE2 if bayer else 0)
         ctx.save_for_backward(*saved)
         ctx.packs, ctx.bayer, ctx.dims = packs, bayer, (n, h, w)
         return y
@@ -141,7 +143,7 @@ class _Path14l(torch.autograd.Function):
             u, r_in = saved[1 + 2 * k], saved[2 * k]
             gu = conv(g, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=u)
             g = conv(gu, c1, n, h, w, transpose=True, epi=EPI_ADD | EPI_MASK, add=g, add_c=64, mask=r_in)
-        gx = conv(g, first, n, h, w, transpose=True, epi=EPI_SHUFFLE2 if ctx.bayer else 0)
+        gx = conv_small(g, first.small_bwd, n, h, w, epi=EPI_SHUFFLE2 if ctx.bayer else 0)
         return gx, None, None
 
 
@@ -154,7 +156,10 @@ def build_path14l_packs(seq, flip_bgr):
         last_w, last_b = last_w.detach().flip(0), last_b.detach().flip(0)
     blocks = [(PackedConv(b.basic[1].weight, b.basic[1].bias), PackedConv(b.basic[3].weight, b.basic[3].bias))
               for b in seq[1]]
-    return PackedConv(first_w, first_b), blocks, PackedConv(last_w, last_b)
+    first, last = PackedConv(first_w, first_b), PackedConv(last_w, last_b)
+    first.small_bwd = SmallConv(first_w, None, transpose=True, keep=first_w.shape[1])    # 64 -> 4 / 3, backward-data
+    last.small = SmallConv(last_w, last_b)                                                # 64 -> 4 / 3
+    return first, blocks, last
 
 
 def path14l(x, packs, bayer):

@@ -114,6 +114,35 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
     const int ox = x0 + lx, epi = d.epilogue;
     if (ox >= W) return;
     const bool full = vecw || ox + SPX <= W;
+    if (epi & RISP_EPI_SHUFFLE2) {          // cout == 4 through PixelShuffle(2): (N,4,H,W) -> (N,1,2H,2W), bias only
+#pragma unroll
+        for (int o = 0; o < SPY; ++o) {
+            const int oy = y0 + ly + o;
+            if (oy >= H) break;
+            float b[4];
+#pragma unroll
+            for (int co = 0; co < 4; ++co) b[co] = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float *yp = d.y + ((size_t)n * 2 * H + 2 * oy + i) * (2 * (size_t)W) + 2 * ox;
+                float e[2 * SPX];
+#pragma unroll
+                for (int p = 0; p < SPX; ++p) {
+                    e[2 * p] = acc[o][p][i].x + b[2 * i];
+                    e[2 * p + 1] = acc[o][p][i].y + b[2 * i + 1];
+                }
+                if (vecw) {
+                    *reinterpret_cast<float4 *>(yp) = make_float4(e[0], e[1], e[2], e[3]);
+                    *reinterpret_cast<float4 *>(yp + 4) = make_float4(e[4], e[5], e[6], e[7]);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < SPX; ++p)
+                        if (ox + p < W) { yp[2 * p] = e[2 * p]; yp[2 * p + 1] = e[2 * p + 1]; }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < SPY; ++o) {
         const int oy = y0 + ly + o;
@@ -224,8 +253,11 @@ int risp_conv2d_small(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 4,
                    "risp_conv2d_small: bad shape N=%d H=%d W=%d cin=%d cout=%d (cout <= 4)", d.N, d.H, d.W, d.cin, d.cout);
     RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_small: only plain loads");
-    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
+    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS | RISP_EPI_SHUFFLE2)),
                    "risp_conv2d_small: epilogue %d not supported", d.epilogue);
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_SHUFFLE2) ||
+                       (d.cout == 4 && !(d.epilogue & (RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK))),
+                   "risp_conv2d_small: PixelShuffle store needs cout == 4 and no other epilogue");
     RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_small: bias missing");
     RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_small: add tensor missing");
     RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_small: mask tensor missing");

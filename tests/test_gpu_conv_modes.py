@@ -219,3 +219,14 @@ def test_srcnn_res_folded_equals_unfolded(P, hw):
         res.append((y.detach(), x.grad, pv.grad))
     for a, b, what in zip(res[0], res[1], ('output', 'input grad', 'param grad')):
         assert_close(a, b, what=what, rtol=2e-4, floor=1.0)
+
+
+@pytest.mark.parametrize('hw', [(8, 8), (20, 36), (33, 30)])
+def test_small_cout_pixelshuffle_store(hw):
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n, cin = 2, 64
+    wt, b = rnd(4, cin, 3, 3, seed=51) * 0.1, rnd(4, seed=52) * 0.1
+    x = rnd(n, cin, h, w, seed=53)
+    ref = TF.pixel_shuffle(TF.conv2d(x, wt, b, padding=1), 2)
+    assert_close(CN.conv_small(x, CN.SmallConv(wt, b), n, h, w, epi=CN.EPI_SHUFFLE2), ref, what='small shuffle2')
