@@ -240,7 +240,7 @@ class SrcnnResFold:
 
 
 def _srcnn_fold_ok(h, w, k=9):
-    return h >= k - 1 and w >= k - 1
+    return h >= k - 1 and k - 1 <= w <= 8192
 
 
 class _SrcnnResFolded(torch.autograd.Function):
@@ -365,7 +365,10 @@ class _SrcnnDemosaic(torch.autograd.Function):
         gy = _dev(gy, 'grad')
         g2 = conv(gy, c3, n, h, w, transpose=True, load=LOAD_UNSHUFFLE2, epi=EPI_MASK, mask=t2)
         g1 = conv(g2, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1)
-        gx = conv(g1, c1, n, h, w, transpose=True, epi=EPI_SHUFFLE2)
+        if getattr(c1, 'small_bwd', None) is not None:      # 64 -> 4 through PixelShuffle: direct small-cout kernel
+            gx = conv_small(g1, c1.small_bwd, n, h, w, epi=EPI_SHUFFLE2)
+        else:
+            gx = conv(g1, c1, n, h, w, transpose=True, epi=EPI_SHUFFLE2)
         return gx, None
 
 
@@ -378,4 +381,6 @@ def build_srcnn_packs(seq, residual=False):
     first layer also gets the folded tables (SrcnnResFold)."""
     packs = tuple(PackedConv(seq[i].weight, seq[i].bias) for i in (0, 2, 4))
     packs[0].fold = SrcnnResFold(seq[0], seq[4]) if residual and seq[4].weight.shape[0] <= 4 else None
+    if not residual and seq[0].weight.shape[1] == 4:       # SRCNNDemosaic: backward-data of the 4 -> 64 first layer
+        packs[0].small_bwd = SmallConv(seq[0].weight, None, transpose=True, keep=4)
     return packs

@@ -182,52 +182,79 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
 }
 
 // S[plane][ky][kx] = sum of g over the pixels q of the plane with q + (ky - P, kx - P) inside the image.
-// One workgroup per plane; a wave takes every fourth row.
-constexpr int RK_MAX = 9;
+// One workgroup per plane.  Pass 1 streams the plane once with 16-byte loads into per-column sums (no cross-lane
+// traffic); the K row ranges differ from "all rows" only by up to P rows at the top or bottom, the K column ranges
+// only by up to P columns at the left or right, so everything else happens on W-long vectors in LDS.
+constexpr int RK_MAX = 9, RW_MAX = 8192;
 __global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict__ g, float *__restrict__ out, int H, int W,
                                                         int K) {
     const int P = K / 2;
     const float *gp = g + (size_t)blockIdx.x * H * W;
-    __shared__ float all_rows[4][RK_MAX];                  // per wave: sum over its rows of the K column-range sums
-    __shared__ float edge_rows[2 * (RK_MAX / 2)][RK_MAX];  // column-range sums of the first P and last P rows
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float tot[RK_MAX];
-#pragma unroll
-    for (int j = 0; j < RK_MAX; ++j) tot[j] = 0.f;
-    for (int y = wave; y < H; y += 4) {
-        const float *row = gp + (size_t)y * W;
-        float t = 0.f;
-        for (int x = lane; x < W; x += 64) t += row[x];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-        // column range of tap kx (dx = kx - P): dx < 0 drops the first -dx columns, dx > 0 the last dx columns
-        float cs[RK_MAX];
-        float l = 0.f, r = 0.f;
-        cs[P] = t;
-        for (int k = 1; k <= P; ++k) {
-            l += row[k - 1];
-            r += row[W - k];
-            cs[P - k] = t - l;
-            cs[P + k] = t - r;
+    extern __shared__ float col[];                         // [phases][W] partial column sums; row 0 becomes the total
+    __shared__ float sums[RK_MAX][RK_MAX];
+    const int tid = threadIdx.x;
+    if ((W & 3) == 0) {
+        const int wq = W >> 2;                             // float4 per row
+        // thread -> (column group, row phase): consecutive threads read consecutive 16-byte pieces of a row
+        const int groups = wq < 256 ? wq : 256, phases = 256 / groups;
+        const int cg = tid % groups, ph = tid / groups;
+        if (ph < phases) {
+            for (int q = cg; q < wq; q += groups) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int y = ph; y < H; y += phases) {
+                    const float4 v = *reinterpret_cast<const float4 *>(gp + (size_t)y * W + 4 * q);
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+                *reinterpret_cast<float4 *>(col + (size_t)ph * W + 4 * q) = a;
+            }
         }
-        for (int j = 0; j < K; ++j) tot[j] += cs[j];
-        if (lane == 0) {
-            if (y < P)
-                for (int j = 0; j < K; ++j) edge_rows[y][j] = cs[j];
-            if (y >= H - P)
-                for (int j = 0; j < K; ++j) edge_rows[P + (H - 1 - y)][j] = cs[j];     // P + distance from the bottom
+        __syncthreads();
+        for (int x = tid; x < W; x += 256) {               // fixed order: the result is deterministic
+            float a = col[x];
+            for (int p2 = 1; p2 < phases; ++p2) a += col[(size_t)p2 * W + x];
+            col[x] = a;
+        }
+    } else {
+        for (int x = tid; x < W; x += 256) {
+            float a = 0.f;
+            for (int y = 0; y < H; ++y) a += gp[(size_t)y * W + x];
+            col[x] = a;
         }
     }
-    if (lane == 0)
-        for (int j = 0; j < K; ++j) all_rows[wave][j] = tot[j];
     __syncthreads();
-    if (threadIdx.x < K * K) {
-        const int i = threadIdx.x / K, j = threadIdx.x - i * K, dy = i - P;
-        float s = all_rows[0][j] + all_rows[1][j] + all_rows[2][j] + all_rows[3][j];
-        for (int k = 0; k < -dy; ++k) s -= edge_rows[k][j];             // dy < 0: rows 0 .. -dy-1 have no source
-        for (int k = 0; k < dy; ++k) s -= edge_rows[P + k][j];          // dy > 0: the last dy rows
-        out[(size_t)blockIdx.x * K * K + threadIdx.x] = s;
+    // row case i (dy = i - P): dy < 0 drops rows 0 .. -dy-1, dy > 0 drops the last dy rows.  One wave per case.
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < K; i += 4) {
+        const int dy = i - P;
+        float t = 0.f, edge[2 * (RK_MAX / 2)];             // edge[k-1]: sum of the first k columns, edge[P+k-1]: last k
+#pragma unroll
+        for (int k = 0; k < 2 * (RK_MAX / 2); ++k) edge[k] = 0.f;
+        for (int x = lane; x < W; x += 64) {
+            float v = col[x];
+            for (int k = 0; k < -dy; ++k) v -= gp[(size_t)k * W + x];
+            for (int k = 0; k < dy; ++k) v -= gp[(size_t)(H - 1 - k) * W + x];
+            t += v;
+            for (int k = 1; k <= P; ++k) {
+                if (x < k) edge[k - 1] += v;
+                if (x >= W - k) edge[P + k - 1] += v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            t += __shfl_xor(t, o);
+#pragma unroll
+            for (int k = 0; k < 2 * (RK_MAX / 2); ++k) edge[k] += __shfl_xor(edge[k], o);
+        }
+        if (lane == 0) {
+            sums[i][P] = t;
+            for (int k = 1; k <= P; ++k) {
+                sums[i][P - k] = t - edge[k - 1];          // dx = -k: the first k columns have no source
+                sums[i][P + k] = t - edge[P + k - 1];      // dx = +k: the last k columns
+            }
+        }
     }
+    __syncthreads();
+    if (tid < K * K) out[(size_t)blockIdx.x * K * K + tid] = sums[tid / K][tid % K];
 }
 
 template <int KS>
@@ -272,9 +299,11 @@ int risp_conv2d_small(const risp_conv_desc *dp, void *stream) {
 
 int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksize, void *stream) {
     RISP_CHECK_ARG(g && out && planes > 0 && H > 0 && W > 0, "risp_rect_sums: bad arguments");
-    RISP_CHECK_ARG((ksize & 1) && ksize >= 1 && ksize <= RK_MAX && H >= ksize / 2 && W >= ksize / 2,
-                   "risp_rect_sums: window %d on a %dx%d plane", ksize, H, W);
-    hipLaunchKernelGGL(rect_sums_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, g, out, H, W, ksize);
+    RISP_CHECK_ARG((ksize & 1) && ksize >= 1 && ksize <= RK_MAX && H >= ksize / 2 && W >= ksize / 2 && W <= RW_MAX,
+                   "risp_rect_sums: window %d on a %dx%d plane (W <= %d)", ksize, H, W, RW_MAX);
+    const int wq = W >> 2, groups = wq < 256 ? (wq > 0 ? wq : 1) : 256, phases = (W & 3) ? 1 : 256 / groups;
+    const size_t lds = sizeof(float) * (size_t)phases * W;
+    hipLaunchKernelGGL(rect_sums_kernel, dim3(planes), dim3(256), lds, (hipStream_t)stream, g, out, H, W, ksize);
     RISP_LAUNCH_CHECK("risp_rect_sums");
     return 0;
 }
