@@ -187,6 +187,15 @@ int risp_conv2d(const risp_conv_desc *d, void *stream);
 size_t risp_conv_small_wpack_floats(int cin, int ksize);
 int risp_conv2d_small(const risp_conv_desc *d, void *stream);
 
+/* The same operator for 3x3 layers with a one-dimensional Winograd transform F(2,3) along x (2/3 of the matrix-core
+ * work of risp_conv2d; Path-Restore's 64->64 layers, path_14l_bayer_arch.py:6-21).  wpack: [chunk of risp_conv_wino3_chunk()
+ * cin][ky][t][ci][cout padded to 32 or 64] with U_0 = g0, U_1 = (g0+g1+g2)/2, U_2 = (g0-g1+g2)/2, U_3 = g2 of filter row
+ * ky (g = w[co][ci][ky][0..2]; backward-data: the forward weight with roles swapped and taps rotated by 180
+ * degrees).  load_mode PLAIN, W % 4 == 0, 16-byte aligned tensors; epilogue RELU | ADD | MASK | NOBIAS. */
+int risp_conv_wino3_chunk(void);
+size_t risp_conv_wino3_wpack_floats(int cin, int cout);
+int risp_conv2d_wino3(const risp_conv_desc *d, void *stream);
+
 /* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */

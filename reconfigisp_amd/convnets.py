@@ -11,6 +11,7 @@ keeps them out of every optimizer).  References:
   Path14lBgr     models/modules/path_14l_bgr_arch.py:58-86
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -19,6 +20,25 @@ from .functional import _dev, _p, _stream, channel_stats
 
 LOAD_PLAIN, LOAD_UNSHUFFLE2, LOAD_CONSTCH = 0, 1, 2
 EPI_RELU, EPI_ADD, EPI_MASK, EPI_SHUFFLE2, EPI_NOBIAS, EPI_CASEBIAS = 1, 2, 4, 8, 16, 32
+
+
+# 3x3 layers run on the Winograd-x kernel (risp_conv2d_wino3) unless RISP_WINOGRAD=0 (A/B switch)
+WINOGRAD = os.environ.get('RISP_WINOGRAD', '1') != '0'
+_WINO_EPI = EPI_RELU | EPI_ADD | EPI_MASK | EPI_NOBIAS
+
+
+def _wino3_pack(w, transpose):
+    """[chunk of CK cin][ky][t][ci][cout pad] Winograd F(2,3)-along-x weights of a 3x3 layer (include/risp.h)."""
+    ck = L.load().risp_conv_wino3_chunk()
+    if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
+        w = w.flip(2, 3).transpose(0, 1)
+    g0, g1, g2 = w[..., 0], w[..., 1], w[..., 2]    # (co, ci, ky)
+    u = torch.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], dim=-1)      # (co, ci, ky, t)
+    co, ci = u.shape[0], u.shape[1]
+    cp, nch = (64 if co > 32 else 32), (ci + ck - 1) // ck
+    p = torch.zeros((nch * ck, 3, 4, cp), device=w.device, dtype=torch.float32)
+    p[:ci, :, :, :co] = u.permute(1, 2, 3, 0)
+    return p.view(nch, ck, 3, 4, cp).permute(0, 2, 3, 1, 4).contiguous()
 
 
 class PackedConv:
@@ -33,6 +53,9 @@ class PackedConv:
         self.bwd = torch.empty(lib.risp_conv_wpack_floats(self.cout, self.cin, self.k), device=w.device)
         L.call('risp_conv_pack_weights', _p(w), self.cin, self.cout, self.k, 0, _p(self.fwd), _stream())
         L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
+        self.wino_fwd = self.wino_bwd = None
+        if self.k == 3 and WINOGRAD:
+            self.wino_fwd, self.wino_bwd = _wino3_pack(w, False), _wino3_pack(w, True)
 
 
 class SmallConv:
@@ -76,10 +99,14 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     if out is None:
         shape = (n, cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, cout, h, w)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    wino = pc.wino_bwd if transpose else pc.wino_fwd
+    use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
+                (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
+                 (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
-                   epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(pc.bwd if transpose else pc.fwd),
+                   epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wino if use_wino else (pc.bwd if transpose else pc.fwd)),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
-    L.call('risp_conv2d', C.byref(d), _stream())
+    L.call('risp_conv2d_wino3' if use_wino else 'risp_conv2d', C.byref(d), _stream())
     return out
 
 

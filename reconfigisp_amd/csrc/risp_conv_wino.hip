@@ -1,0 +1,256 @@
+// 3x3 convolution layers on the fp32 matrix cores with a one-dimensional Winograd transform F(2,3) along x:
+// two horizontally adjacent outputs of a filter row cost 4 multiplications instead of 6, so the layer issues
+// 12 "taps" (3 filter rows x 4 transform points) per output PAIR where the direct kernel (risp_conv.hip) issues
+// 9 per output pixel - 2/3 of the MFMA work.  The 64 -> 64 3x3 layers of Path-Restore
+// (path_14l_bayer_arch.py:6-21, path_14l_bgr_arch.py:6-21) are 40 % of a search step and 85 % of tiled
+// full-frame inference.
+//
+//     y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3,   m_t = sum_{ky,ci} U[ky][t][co][ci] * V_t(row + ky, ci)
+//     U_0 = g0, U_1 = (g0 + g1 + g2) / 2, U_2 = (g0 - g1 + g2) / 2, U_3 = g2           (packed on the host)
+//     V_0 = d0 - d2, V_1 = d1 + d2, V_2 = d2 - d1, V_3 = d1 - d3,  d_j = x[2p - 1 + j]  (formed on the fly)
+// All arithmetic stays fp32; the transform constants are 1 and 1/2, so the result differs from the direct
+// convolution by a few ulp of the accumulated magnitude (tests: 1e-4 relative like every CNN stage).
+//
+// Per workgroup (4 waves): 4 output rows x 64 pixels x all couts.  Wave w owns row w; its MFMA column index
+// (lane & 31) is the pixel PAIR, so one v_mfma_f32_32x32x2_f32 covers 64 pixels of a row.  Accumulators
+// [4 transform points][CB cout blocks] = 128 VGPRs at 64 couts, the same budget as the direct kernel.
+// Per chunk of CK input channels the raw zero-padded halo tile (CK x 6 x 72) and the weight slab
+// [12][CK][cout] are staged in ping-pong LDS buffers; the global loads of the next chunk are issued from inside
+// the MFMA stream.  The B operands of the four transform points come from ONE pair of LDS reads (d0..d3) and
+// four vector subtractions/additions.
+#include "risp_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int WTW = 64, WTH = 4;               // output tile: 64 pixels (32 pairs) x 4 rows
+constexpr int WIH = WTH + 2, WIWP = WTW + 8;    // staged rows / row stride: column c <-> image x0 - 4 + c
+constexpr int WTAPS = 12;                       // 3 filter rows x 4 transform points
+
+template <int CK, int CB>
+__global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc d) {
+    constexpr int CP = 32 * CB;
+    constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * CP;
+    constexpr int NXV = (XN / 4 + 255) / 256, NWV = (WN / 4 + 255) / 256;
+    constexpr int NF = NXV + NWV;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sx = smem;                                  // [2][CK][WIH][WIWP]
+    float *sw = smem + 2 * XN;                         // [2][WTAPS][CK][CP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z;
+    const int nchunks = (d.cin + CK - 1) / CK;
+
+    f32x16 acc[4][CB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+    int xoff[NXV], xcl[NXV];
+    float4 xr[NXV], wr[NWV];
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+        const int v = tid + 256 * i;
+        const int cl = v / (WIH * (WIWP / 4)), rem = v - cl * (WIH * (WIWP / 4));
+        const int iy = rem / (WIWP / 4), q = rem - iy * (WIWP / 4);
+        const int gy = y0 + iy - 1, gx = x0 - 4 + 4 * q;
+        const bool ok = v < XN / 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        xcl[i] = ok ? cl : -1;                         // -1: outside the image -> zeros
+        xoff[i] = (cl * d.H + gy) * d.W + gx;
+    }
+    auto fetch_one = [&](int ch, int j) {              // j is a compile-time constant at every call site
+        if (j < NXV) {
+            const int ci = ch * CK + xcl[j];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xcl[j] >= 0 && ci < d.cin) v = *reinterpret_cast<const float4 *>(xn + (size_t)ch * CK * hw + xoff[j]);
+            xr[j] = v;
+        } else if (j < NF) {
+            const int v = tid + 256 * (j - NXV);
+            wr[j - NXV] = (v < WN / 4) ? reinterpret_cast<const float4 *>(d.wpack + (size_t)ch * WN)[v]
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto publish = [&](int buf) {
+        float *sxb = sx + buf * XN, *swb = sw + buf * WN;
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < NF; ++j) fetch_one(0, j);
+    publish(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        __syncthreads();                               // tile ch published, tile ch-1 no longer read
+        const bool more = ch + 1 < nchunks;
+        if (more) {                                    // next chunk's global loads: in flight during this chunk's MFMAs
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fetch_one(ch + 1, j);
+        }
+        // d0 of pair p sits at staged column 2p + 3 (image x0 + 2p - 1)
+        const float *bx = sx + buf * XN + (half * WIH + wave) * WIWP + 3 + 2 * l31;
+        const float *aw = sw + buf * WN + half * CP + l31;
+        // Register double-buffering of the LDS operands: group g+1 = (filter row, channel pair) is read before the
+        // 8 MFMAs of group g are issued, so LDS latency hides behind 512 cycles of matrix work.
+        constexpr int NG = 3 * (CK / 2);
+        float opa[2][4][CB], opd[2][4];
+        auto load_group = [&](int g, int slot) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+            const float *dp = bx + (2 * cp * WIH + ky) * WIWP;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) opd[slot][j] = dp[j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) opa[slot][t][c] = aw[((ky * 4 + t) * CK + 2 * cp) * CP + c * 32];
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot = g & 1;
+            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);         // keep the reads above this group's MFMAs (the scheduler sinks them)
+            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3];
+            const float bv[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int c = 0; c < CB; ++c)
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t][c], bv[t], acc[t][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) publish(buf ^ 1);
+    }
+
+    // ---- epilogue.  Lane holds m_t[cout = cb*32 + (e&3) + 8*(e>>2) + 4*half][pair = l31]; the output row of the
+    // wave (CP couts x 64 pixels) is transposed through LDS one cout block at a time so that each lane owns 4
+    // consecutive pixels of one cout plane: residual / mask loads and the stores are 16 bytes per lane.
+    const int epi = d.epilogue;
+    const float *__restrict__ pbias = d.bias;
+    const float *__restrict__ padd = d.add;
+    const float *__restrict__ pmask = d.mask;
+    float *__restrict__ py = d.y;
+    const int oy = y0 + wave;
+    __syncthreads();                                   // every wave is done with the staging tiles
+    float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
+    const int q4 = 4 * (lane & 15);                    // this lane's 4 pixels inside the row
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int col = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const float m0 = acc[0][c][e], m1 = acc[1][c][e], m2 = acc[2][c][e], m3 = acc[3][c][e];
+            float2 y2;
+            y2.x = m0 + m1 + m2;
+            y2.y = m1 - m2 - m3;
+            *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
+        }
+        __builtin_amdgcn_wave_barrier();               // private tile, in-order LDS: keep the compiler from reordering
+        const bool row_ok = oy < d.H && x0 + q4 < d.W;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                  // 32 couts x 16 float4 = 512 float4 / 64 lanes
+            const int col = (lane >> 4) + 4 * i, co = c * 32 + col;
+            float4 o = *reinterpret_cast<const float4 *>(tile + col * WTW + q4);
+            if (!(row_ok && co < d.cout)) continue;
+            const size_t off = ((size_t)n * d.cout + co) * hw + (size_t)oy * d.W + x0 + q4;
+            const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : pbias[co];
+            o.x += b; o.y += b; o.z += b; o.w += b;
+            if ((epi & RISP_EPI_ADD) && co < d.add_c) {
+                const float4 a = *reinterpret_cast<const float4 *>(padd + ((size_t)n * d.add_c + co) * hw + (size_t)oy * d.W + x0 + q4);
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            if (epi & RISP_EPI_RELU) {
+                o.x = o.x > 0.f ? o.x : 0.f;
+                o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f;
+                o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            if (epi & RISP_EPI_MASK) {
+                const float4 m = *reinterpret_cast<const float4 *>(pmask + off);
+                o.x = m.x > 0.f ? o.x : 0.f;
+                o.y = m.y > 0.f ? o.y : 0.f;
+                o.z = m.z > 0.f ? o.z : 0.f;
+                o.w = m.w > 0.f ? o.w : 0.f;
+            }
+            *reinterpret_cast<float4 *>(py + off) = o;
+        }
+        __builtin_amdgcn_wave_barrier();               // the tile is rewritten by the next cout block
+    }
+}
+
+template <int CK, int CB>
+int launch_wino(const risp_conv_desc &d, hipStream_t s) {
+    constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * 32 * CB;
+    size_t lds = sizeof(float) * 2 * (XN + WN);
+    const size_t epi = sizeof(float) * 4 * 32 * WTW;   // the epilogue's four private transposition tiles
+    if (lds < epi) lds = epi;
+    dim3 grid((d.W + WTW - 1) / WTW, (d.H + WTH - 1) / WTH, d.N);
+    if (lds > 64 * 1024) {                              // gfx950: 160 KB of LDS per CU, two workgroups share it
+        static bool raised = false;                     // benign race: the attribute is idempotent
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino3_kernel<CK, CB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                risp_set_error("risp_conv2d_wino3: cannot raise the dynamic LDS limit to %zu bytes", lds);
+                return 2;
+            }
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((conv_wino3_kernel<CK, CB>), grid, dim3(256), lds, s, d);
+    RISP_LAUNCH_CHECK("risp_conv2d_wino3");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+#ifndef RISP_WINO_CK
+#define RISP_WINO_CK 8
+#endif
+constexpr int WCK = RISP_WINO_CK;                      // input channels per LDS stage (and per weight-pack chunk)
+
+int risp_conv_wino3_chunk(void) { return WCK; }
+
+size_t risp_conv_wino3_wpack_floats(int cin, int cout) {
+    const int cb = cout > 32 ? 2 : 1;
+    return (size_t)((cin + WCK - 1) / WCK) * WTAPS * WCK * 32 * cb;
+}
+
+int risp_conv2d_wino3(const risp_conv_desc *dp, void *stream) {
+    RISP_CHECK_ARG(dp, "risp_conv2d_wino3: null descriptor");
+    const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino3: null tensor");
+    RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 &&
+                       d.ksize == 3,
+                   "risp_conv2d_wino3: needs a 3x3 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,
+                   d.W, d.cin, d.cout, d.ksize);
+    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_wino3: only plain loads");
+    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
+                   "risp_conv2d_wino3: epilogue %d not supported", d.epilogue);
+    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_wino3: bias missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_wino3: add tensor missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_wino3: mask tensor missing");
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
+                     reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
+                   "risp_conv2d_wino3: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (d.cout > 32) return launch_wino<WCK, 2>(d, s);
+    return launch_wino<WCK, 1>(d, s);
+}
+
+}  // extern "C"

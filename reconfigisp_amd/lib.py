@@ -58,6 +58,9 @@ SIGNATURES = {
     'risp_conv_small_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_small': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_rect_sums': (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    'risp_conv_wino3_chunk': (_i, []),
+    'risp_conv_wino3_wpack_floats': (_z, [_i, _i]),
+    'risp_conv2d_wino3': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wgrad_scratch_floats': (_z, [_i]),
     'risp_conv2d_wgrad': (_i, [C.POINTER(ConvDesc), _f, _f, _f, _s]),
     'risp_plane_sums': (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
