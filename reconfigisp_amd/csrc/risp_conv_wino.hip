@@ -23,6 +23,19 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Diagnostic build only (-DRISP_CONV_STAMPS, tools/conv_stamps.py wino): per-wave cycle shares written to the
+// (otherwise unused) mask buffer.  Never compiled into the product.
+#ifdef RISP_CONV_STAMPS
+#define WSTAMP(var)                                      \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        var = __builtin_amdgcn_s_memtime();              \
+        __builtin_amdgcn_s_waitcnt(0xC07F);              \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
+#else
+#define WSTAMP(var) do { } while (0)
+#endif
 constexpr int WTW = 64, WTH = 4;               // output tile: 64 pixels (32 pairs) x 4 rows
 constexpr int WIH = WTH + 2, WIWP = WTW + 8;    // staged rows / row stride: column c <-> image x0 - 4 + c
 constexpr int WTAPS = 12;                       // 3 filter rows x 4 transform points
@@ -41,6 +54,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
     const int l31 = lane & 31, half = lane >> 5;
     const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z;
     const int nchunks = (d.cin + CK - 1) / CK;
+    unsigned long long t_k0 = 0, rt_k0 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, s_bar = 0, s_cmp = 0, s_pub = 0, t_begin = 0, t_loop_end = 0;
+    (void)t_k0; (void)rt_k0; (void)t0; (void)t1; (void)t2; (void)t3; (void)s_bar; (void)s_cmp; (void)s_pub; (void)t_begin; (void)t_loop_end;
+    WSTAMP(t_k0);
+#ifdef RISP_CONV_STAMPS
+    rt_k0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     f32x16 acc[4][CB];
 #pragma unroll
@@ -90,12 +109,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
         }
     };
 
+    WSTAMP(t_begin);
 #pragma unroll
     for (int j = 0; j < NF; ++j) fetch_one(0, j);
     publish(0);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
+        WSTAMP(t0);
         __syncthreads();                               // tile ch published, tile ch-1 no longer read
+        WSTAMP(t1);
         const bool more = ch + 1 < nchunks;
         if (more) {                                    // next chunk's global loads: in flight during this chunk's MFMAs
 #pragma unroll
@@ -133,8 +155,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
                     acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t][c], bv[t], acc[t][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        WSTAMP(t2);
         if (more) publish(buf ^ 1);
+        WSTAMP(t3);
+#ifdef RISP_CONV_STAMPS
+        s_bar += t1 - t0;
+        s_cmp += t2 - t1;
+        s_pub += t3 - t2;
+#endif
     }
+    WSTAMP(t_loop_end);
 
     // ---- epilogue.  Lane holds m_t[cout = cb*32 + (e&3) + 8*(e>>2) + 4*half][pair = l31]; the output row of the
     // wave (CP couts x 64 pixels) is transposed through LDS one cout block at a time so that each lane owns 4
@@ -190,6 +220,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
         }
         __builtin_amdgcn_wave_barrier();               // the tile is rewritten by the next cout block
     }
+#ifdef RISP_CONV_STAMPS
+    if (lane == 0 && d.mask && !(d.epilogue & RISP_EPI_MASK)) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(d.mask)) +
+                                8 * ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave);
+        unsigned long long t_end;
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        WSTAMP(t_end);
+        o[0] = s_bar; o[1] = s_cmp; o[2] = s_pub;
+        o[3] = t_begin - t_k0;
+        o[4] = t_loop_end - t_begin;
+        o[5] = t_end - t_loop_end;
+        o[6] = rt_k0;
+        o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <int CK, int CB>
