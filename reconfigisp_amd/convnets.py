@@ -27,18 +27,51 @@ WINOGRAD = os.environ.get('RISP_WINOGRAD', '1') != '0'
 _WINO_EPI = EPI_RELU | EPI_ADD | EPI_MASK | EPI_NOBIAS
 
 
-def _wino3_pack(w, transpose):
-    """[chunk of CK cin][ky][t][ci][cout pad] Winograd F(2,3)-along-x weights of a 3x3 layer (include/risp.h)."""
-    ck = L.load().risp_conv_wino3_chunk()
+def wino3_weights(w, transpose, ck):
+    """[chunk of ``ck`` cin][ky][t][ci][cout pad] Winograd F(2,3)-along-x weights of a 3x3 layer (include/risp.h).
+    Pure tensor algebra on whatever device ``w`` lives on (tests/test_pack_algebra_cpu.py exercises it on the CPU)."""
     if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
         w = w.flip(2, 3).transpose(0, 1)
     g0, g1, g2 = w[..., 0], w[..., 1], w[..., 2]    # (co, ci, ky)
     u = torch.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], dim=-1)      # (co, ci, ky, t)
     co, ci = u.shape[0], u.shape[1]
     cp, nch = (64 if co > 32 else 32), (ci + ck - 1) // ck
-    p = torch.zeros((nch * ck, 3, 4, cp), device=w.device, dtype=torch.float32)
+    p = torch.zeros((nch * ck, 3, 4, cp), device=w.device, dtype=w.dtype)
     p[:ci, :, :, :co] = u.permute(1, 2, 3, 0)
     return p.view(nch, ck, 3, 4, cp).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def _wino3_pack(w, transpose):
+    return wino3_weights(w, transpose, L.load().risp_conv_wino3_chunk())
+
+
+def small_weights(w, transpose=False, keep=None):
+    """[cin][k][k][4] weights of ``risp_conv2d_small`` from a layer's (cout,cin,k,k) tensor; ``transpose``: the
+    backward-data layer of a FORWARD weight (roles swapped, taps rotated by 180 degrees) restricted to its first
+    ``keep`` input channels."""
+    if transpose:
+        w = w[:, :keep].flip(2, 3).permute(0, 2, 3, 1)                # [cin_b = cout_f][ky][kx][cout_b = cin_f]
+    else:
+        w = w.permute(1, 2, 3, 0)                                      # [cin][ky][kx][cout]
+    if w.shape[3] > 4:
+        raise ValueError('small-cout layer: %d output channels (at most 4)' % w.shape[3])
+    pack = torch.zeros((w.shape[0], w.shape[1], w.shape[2], 4), device=w.device, dtype=w.dtype)
+    pack[..., :w.shape[3]] = w
+    return pack, w.shape[3]
+
+
+def srcnn_fold_tables(w1):
+    """(rcase (9+P, cout*k*k), wconst (cout*k*k, 9+P)) of SRCNNRes' first layer w1 (cout, 12+P, k, k): see SrcnnResFold."""
+    k, p = w1.shape[2], w1.shape[2] // 2
+    wc = w1[:, 3:]
+    cases = []
+    for i in range(k):                                               # taps lo..hi of border case i survive
+        cases.append((p - i, k - 1) if i < p else (0, k - 1 - (i - p)))
+    rc = torch.stack([torch.stack([wc[:, :, a:b + 1, c:d + 1].sum(dim=(2, 3)) for (c, d) in cases], dim=-1)
+                      for (a, b) in cases], dim=-2)                  # (cout, 9+P, k, k)
+    rcase = rc.permute(1, 0, 2, 3).reshape(wc.shape[1], -1).contiguous()
+    wconst = wc.permute(0, 2, 3, 1).reshape(-1, wc.shape[1]).contiguous()
+    return rcase, wconst
 
 
 class PackedConv:
@@ -64,16 +97,8 @@ class SmallConv:
     FORWARD weight (roles swapped, taps rotated by 180 degrees), restricted to its first ``keep`` input channels."""
 
     def __init__(self, weight, bias=None, transpose=False, keep=None):
-        w = _dev(weight.detach(), 'weight')
-        if transpose:
-            w = w[:, :keep].flip(2, 3).permute(0, 2, 3, 1)            # [cin_b = cout_f][ky][kx][cout_b = cin_f]
-        else:
-            w = w.permute(1, 2, 3, 0)                                  # [cin][ky][kx][cout]
-        self.cin, self.k, self.cout = w.shape[0], w.shape[1], w.shape[3]
-        if self.cout > 4:
-            raise ValueError('SmallConv: %d output channels (at most 4)' % self.cout)
-        self.wpack = torch.zeros((self.cin, self.k, self.k, 4), device=w.device, dtype=torch.float32)
-        self.wpack[..., :self.cout] = w
+        self.wpack, self.cout = small_weights(_dev(weight.detach(), 'weight'), transpose, keep)
+        self.cin, self.k = self.wpack.shape[0], self.wpack.shape[1]
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 
@@ -250,18 +275,9 @@ class SrcnnResFold:
 
     def __init__(self, conv1, conv3):
         w1 = _dev(conv1.weight.detach(), 'weight')                    # (64, 12+P, 9, 9)
-        k, p = w1.shape[2], w1.shape[2] // 2
-        self.k = k
+        self.k = w1.shape[2]
         self.img = PackedConv(w1[:, :3].contiguous(), conv1.bias)
-        wc = w1[:, 3:]                                               # (64, 9+P, 9, 9)
-        cases = []
-        for i in range(k):                                           # taps lo..hi of case i survive
-            lo, hi = (p - i, k - 1) if i < p else (0, k - 1 - (i - p))
-            cases.append((lo, hi))
-        rc = torch.stack([torch.stack([wc[:, :, a:b + 1, c:d + 1].sum(dim=(2, 3)) for (c, d) in cases], dim=-1)
-                          for (a, b) in cases], dim=-2)              # (64, 9+P, k, k)
-        self.rcase = rc.permute(1, 0, 2, 3).reshape(wc.shape[1], -1).contiguous()
-        self.wconst = wc.permute(0, 2, 3, 1).reshape(-1, wc.shape[1]).contiguous()
+        self.rcase, self.wconst = srcnn_fold_tables(w1)
         self.bwd_img = SmallConv(w1, None, transpose=True, keep=3)
         self.tail = SmallConv(conv3.weight, conv3.bias)
 

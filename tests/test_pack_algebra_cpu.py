@@ -1,0 +1,104 @@
+"""CPU checks of the weight algebra behind three kernels (pure tensor code in reconfigisp_amd/convnets.py; the
+kernels themselves are tested on the GPU): the Winograd F(2,3) packs, the small-cout packs, and the tables that
+fold SRCNNRes' broadcast planes out of its 9x9 layer.  Each is emulated with plain torch ops in the exact way the
+kernel consumes the pack and compared with torch.nn.functional.conv2d (fp64, so only the algebra is on trial)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from reconfigisp_amd import convnets as CN
+
+
+def rnd(*shape, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.standard_normal(shape))
+
+
+def wino_emulate(x, pack, ck, cout):
+    """What conv_wino3_kernel computes from its pack: m_t = sum_{ky,ci} U[ky][t][co][ci] V_t(row+ky, ci)."""
+    n, cin, h, w = x.shape
+    xp = TF.pad(x, (1, 3, 1, 1))                               # zero 'same' padding (+2 so that odd tails exist)
+    npairs = (w + 1) // 2
+    d = torch.stack([xp[:, :, :, j:j + 2 * npairs:2] for j in range(4)], dim=-1)      # (n,ci,h+2,pairs,4): d_j = x[2p-1+j]
+    v = torch.stack([d[..., 0] - d[..., 2], d[..., 1] + d[..., 2], d[..., 2] - d[..., 1], d[..., 1] - d[..., 3]], dim=-1)
+    u = pack.permute(0, 3, 1, 2, 4).reshape(-1, 3, 4, pack.shape[-1])[:cin, :, :, :cout]   # (ci, ky, t, co)
+    m = torch.zeros(n, cout, h, npairs, 4, dtype=x.dtype)
+    for ky in range(3):
+        m += torch.einsum('nchpt,cto->nohpt', v[:, :, ky:ky + h], u[:, ky])
+    y = torch.zeros(n, cout, h, 2 * npairs, dtype=x.dtype)
+    y[..., 0::2] = m[..., 0] + m[..., 1] + m[..., 2]
+    y[..., 1::2] = m[..., 1] - m[..., 2] - m[..., 3]
+    return y[..., :w]
+
+
+@pytest.mark.parametrize('cin,cout,ck', [(64, 64, 8), (5, 3, 8), (12, 33, 4)])
+def test_winograd_pack_forward_and_backward_data(cin, cout, ck):
+    wt = rnd(cout, cin, 3, 3, seed=1)
+    x = rnd(2, cin, 6, 10, seed=2).requires_grad_(True)
+    ref = TF.conv2d(x, wt, None, padding=1)
+    got = wino_emulate(x.detach(), CN.wino3_weights(wt, False, ck), ck, cout)
+    assert torch.allclose(got, ref.detach(), rtol=1e-10, atol=1e-10)
+    gy = rnd(2, cout, 6, 10, seed=3)
+    gref, = torch.autograd.grad(ref, x, gy)
+    got = wino_emulate(gy, CN.wino3_weights(wt, True, ck), ck, cin)
+    assert torch.allclose(got, gref, rtol=1e-10, atol=1e-10)
+
+
+def small_emulate(x, pack, cout, k):
+    w = pack[..., :cout].permute(3, 0, 1, 2)                  # back to (cout, cin, k, k)
+    return TF.conv2d(x, w, None, padding=k // 2)
+
+
+@pytest.mark.parametrize('k', [3, 5, 9])
+def test_small_cout_pack_forward_and_backward_data(k):
+    wf = rnd(16, 7, k, k, seed=4)                               # forward layer 7 -> 16
+    x = rnd(2, 7, 9, 11, seed=5).requires_grad_(True)
+    ref = TF.conv2d(x, wf[:3], None, padding=k // 2)            # a 3-cout forward layer
+    pack, cout = CN.small_weights(wf[:3].float())
+    assert cout == 3 and pack.shape == (7, k, k, 4) and pack[..., 3].abs().max() == 0
+    assert torch.allclose(small_emulate(x.detach(), CN.small_weights(wf[:3])[0], 3, k), ref.detach(), rtol=1e-10, atol=1e-10)
+    gy = rnd(2, 16, 9, 11, seed=6)
+    gref, = torch.autograd.grad(TF.conv2d(x, wf, None, padding=k // 2), x, gy)
+    pack, cout = CN.small_weights(wf, transpose=True, keep=3)   # backward-data restricted to 3 input channels
+    assert torch.allclose(small_emulate(gy, pack, cout, k), gref[:, :3], rtol=1e-10, atol=1e-10)
+    with pytest.raises(ValueError):
+        CN.small_weights(wf)                                    # 16 output channels
+
+
+def border_case(v, L, p):
+    return v if v < p else (2 * p - (L - 1 - v) if v >= L - p else p)
+
+
+def rect_sums(g, k):
+    """numpy restatement of risp_rect_sums: S[n,c,ky,kx] = sum of g over q with q + (ky-p, kx-p) inside."""
+    n, c, h, w = g.shape
+    p = k // 2
+    out = torch.zeros(n, c, k, k, dtype=g.dtype)
+    for ky in range(k):
+        for kx in range(k):
+            dy, dx = ky - p, kx - p
+            out[:, :, ky, kx] = g[:, :, max(0, -dy):h - max(0, dy), max(0, -dx):w - max(0, dx)].sum(dim=(2, 3))
+    return out
+
+
+@pytest.mark.parametrize('P,hw', [(1, (8, 8)), (3, (9, 13)), (5, (12, 8))])
+def test_srcnn_broadcast_planes_fold(P, hw):
+    """conv over [image, constant planes] == conv over the image + table[case(y), case(x)], and the gradient of the
+    constants == rect_sums(upstream) @ wconst."""
+    h, w = hw
+    n, cout, k = 2, 6, 9
+    w1 = rnd(cout, 12 + P, k, k, seed=7)
+    x = rnd(n, 3, h, w, seed=8)
+    cv = rnd(n, 9 + P, seed=9).requires_grad_(True)
+    full = TF.conv2d(torch.cat([x, cv[:, :, None, None].expand(n, 9 + P, h, w)], dim=1), w1, None, padding=k // 2)
+    rcase, wconst = CN.srcnn_fold_tables(w1)
+    table = (cv.detach() @ rcase).view(n, cout, k, k)
+    iy = torch.tensor([border_case(y, h, k // 2) for y in range(h)])
+    ix = torch.tensor([border_case(xx, w, k // 2) for xx in range(w)])
+    folded = TF.conv2d(x, w1[:, :3], None, padding=k // 2) + table[:, :, iy][:, :, :, ix]
+    assert torch.allclose(folded, full.detach(), rtol=1e-10, atol=1e-10)
+    g = rnd(n, cout, h, w, seed=10)
+    gref, = torch.autograd.grad(full, cv, g)
+    got = rect_sums(g, k).reshape(n, -1) @ wconst
+    assert torch.allclose(got, gref, rtol=1e-10, atol=1e-10)
