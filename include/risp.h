@@ -178,13 +178,15 @@ int risp_conv_pack_weights(const float *w, int cin, int cout, int ksize, int tra
                            void *stream);
 int risp_conv2d(const risp_conv_desc *d, void *stream);
 
-/* The same operator for layers with cout <= 4 (SRCNNRes conv 5x5 32->3, srcnn_res_arch.py:22; backward-data of its
- * 9x9 first layer :18 restricted to the 3 image channels; Path-Restore tails): a direct vector-FMA kernel - the
- * matrix-core kernel above pads cout to 32.  wpack: [cin][k][k][4] floats (couts padded to 4 with zeros), 16-byte
+/* The same operator for layers with cout <= 12 (SRCNNRes conv 5x5 32->3, srcnn_res_arch.py:22; backward-data of its
+ * 9x9 first layer :18 restricted to the 3 image channels; Path-Restore tails; SRCNNDemosaic conv 5x5 32->12,
+ * srcnn_demosaic_arch.py:21): a direct vector-FMA kernel - the matrix-core kernel above pads cout to 32.
+ * wpack: [cin][k][k][P] floats, P = risp_conv_small_cout_pad(cout) = 4 or 12 (couts zero-padded), 16-byte
  * aligned - the layer's weights w[co][ci][ky][kx] for a forward layer, w[ci_b][co_b][k-1-ky][k-1-kx] for a
- * backward-data layer.  load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout == 4;
- * ksize in {3,5,9}. */
-size_t risp_conv_small_wpack_floats(int cin, int ksize);
+ * backward-data layer.  load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout % 4 == 0;
+ * ksize in {3,5,9} (9 only for cout <= 4). */
+int risp_conv_small_cout_pad(int cout);
+size_t risp_conv_small_wpack_floats(int cin, int cout, int ksize);
 int risp_conv2d_small(const risp_conv_desc *d, void *stream);
 
 /* The same operator for 3x3 layers with a one-dimensional Winograd transform F(2,3) along x (2/3 of the matrix-core

@@ -46,16 +46,16 @@ def _wino3_pack(w, transpose):
 
 
 def small_weights(w, transpose=False, keep=None):
-    """[cin][k][k][4] weights of ``risp_conv2d_small`` from a layer's (cout,cin,k,k) tensor; ``transpose``: the
-    backward-data layer of a FORWARD weight (roles swapped, taps rotated by 180 degrees) restricted to its first
-    ``keep`` input channels."""
+    """[cin][k][k][P] weights of ``risp_conv2d_small`` (P = 4 for cout <= 4, else 12) from a layer's (cout,cin,k,k)
+    tensor; ``transpose``: the backward-data layer of a FORWARD weight (roles swapped, taps rotated by 180 degrees)
+    restricted to its first ``keep`` input channels."""
     if transpose:
         w = w[:, :keep].flip(2, 3).permute(0, 2, 3, 1)                # [cin_b = cout_f][ky][kx][cout_b = cin_f]
     else:
         w = w.permute(1, 2, 3, 0)                                      # [cin][ky][kx][cout]
-    if w.shape[3] > 4:
-        raise ValueError('small-cout layer: %d output channels (at most 4)' % w.shape[3])
-    pack = torch.zeros((w.shape[0], w.shape[1], w.shape[2], 4), device=w.device, dtype=w.dtype)
+    if w.shape[3] > 12:
+        raise ValueError('small-cout layer: %d output channels (at most 12)' % w.shape[3])
+    pack = torch.zeros((w.shape[0], w.shape[1], w.shape[2], 4 if w.shape[3] <= 4 else 12), device=w.device, dtype=w.dtype)
     pack[..., :w.shape[3]] = w
     return pack, w.shape[3]
 
@@ -106,7 +106,7 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
     """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 4)."""
     if sc.bias is None:
         epi |= EPI_NOBIAS
-    shape = (n, 1, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, sc.cout, h, w)
+    shape = (n, sc.cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, sc.cout, h, w)
     out = torch.empty(shape, device=x.device, dtype=torch.float32)
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
@@ -395,7 +395,10 @@ class _SrcnnDemosaic(torch.autograd.Function):
         c1, c2, c3 = packs
         t1 = conv(x, c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU)
         t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
-        y = conv(t2, c3, n, h, w, epi=EPI_SHUFFLE2)
+        if getattr(c3, 'small', None) is not None:           # 5x5 32 -> 12 + PixelShuffle: direct small-cout kernel
+            y = conv_small(t2, c3.small, n, h, w, epi=EPI_SHUFFLE2)
+        else:
+            y = conv(t2, c3, n, h, w, epi=EPI_SHUFFLE2)
         ctx.save_for_backward(t1, t2)
         ctx.packs, ctx.dims = packs, (n, h, w)
         return y
@@ -426,4 +429,6 @@ def build_srcnn_packs(seq, residual=False):
     packs[0].fold = SrcnnResFold(seq[0], seq[4]) if residual and seq[4].weight.shape[0] <= 4 else None
     if not residual and seq[0].weight.shape[1] == 4:       # SRCNNDemosaic: backward-data of the 4 -> 64 first layer
         packs[0].small_bwd = SmallConv(seq[0].weight, None, transpose=True, keep=4)
+    if not residual and seq[4].weight.shape[0] <= 12 and seq[4].weight.shape[2] in (3, 5):
+        packs[2].small = SmallConv(seq[4].weight, seq[4].bias)
     return packs

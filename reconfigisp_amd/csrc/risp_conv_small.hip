@@ -29,7 +29,9 @@ template <int KS> struct SmallCfg { static constexpr int CCH = KS == 9 ? 3 : 4; 
 // Thread = 4 x 2 output pixels x 4 couts (16 packed accumulators).  Per input channel the thread walks the
 // KS + 1 tile rows its two output rows need: each row is 3 x 128-bit LDS reads, used by the taps of BOTH output
 // rows, and each filter row (KS x 4 wave-uniform weights, scalar loads) serves both output rows too.
-template <int KS>
+// NP = pairs of output channels held per pixel: 2 (cout <= 4) or 6 (cout <= 12: SRCNNDemosaic's 5x5 32 -> 12 tail,
+// srcnn_demosaic_arch.py:21, which the matrix-core kernel pads to 32).  The weight pack is [cin][k][k][2 NP].
+template <int KS, int NP>
 __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d) {
     constexpr int P = KS / 2, TH_ = SY + 2 * P, CCH = SmallCfg<KS>::CCH, ROWV = STW / 4;
     extern __shared__ float4 lds4[];                       // [CCH][TH_][STW]
@@ -38,14 +40,16 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
     const int H = d.H, W = d.W, cin = d.cin;
     const size_t plane = (size_t)H * W;
     const float *__restrict__ xin = d.x + (size_t)n * cin * plane;
-    const float4 *__restrict__ wp = reinterpret_cast<const float4 *>(d.wpack);      // [cin][KS][KS] x 4 couts
+    const f32x2 *__restrict__ wp = reinterpret_cast<const f32x2 *>(d.wpack);        // [cin][KS][KS][NP] cout pairs
     const bool vecw = (W & 3) == 0;
 
-    f32x2 acc[SPY][SPX][2];
+    f32x2 acc[SPY][SPX][NP];
 #pragma unroll
     for (int r = 0; r < SPY; ++r)
 #pragma unroll
-        for (int p = 0; p < SPX; ++p) acc[r][p][0] = acc[r][p][1] = (f32x2){0.f, 0.f};
+        for (int p = 0; p < SPX; ++p)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) acc[r][p][q] = (f32x2){0.f, 0.f};
 
     // Staging: all global loads of a stage are issued (into registers) before the first LDS write, so a stage costs
     // one memory round trip, which the other resident workgroups of the CU cover with their FMAs.
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
         __syncthreads();
         const int cn = cin - c0 < CCH ? cin - c0 : CCH;
         for (int c = 0; c < cn; ++c) {
-            const float4 *wch = wp + (size_t)(c0 + c) * KS * KS;                   // wave-uniform -> scalar loads
+            const f32x2 *wch = wp + (size_t)(c0 + c) * KS * KS * NP;               // wave-uniform -> scalar loads
 #pragma unroll
             for (int r = 0; r < KS + SPY - 1; ++r) {                               // tile row ly + r
                 const float4 *row = lds4 + ((c * TH_ + ly + r) * STW + lx) / 4;
@@ -95,14 +99,15 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
                     if (ky < 0 || ky >= KS) continue;
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx) {
-                        const float4 w = wch[ky * KS + kx];
-                        const f32x2 w01 = {w.x, w.y}, w23 = {w.z, w.w};
+                        f32x2 wq[NP];
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) wq[q] = wch[(ky * KS + kx) * NP + q];
 #pragma unroll
                         for (int p = 0; p < SPX; ++p) {
                             const float av = a[HPAD - P + kx + p];
                             const f32x2 a2 = {av, av};
-                            acc[o][p][0] = __builtin_elementwise_fma(a2, w01, acc[o][p][0]);
-                            acc[o][p][1] = __builtin_elementwise_fma(a2, w23, acc[o][p][1]);
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) acc[o][p][q] = __builtin_elementwise_fma(a2, wq[q], acc[o][p][q]);
                         }
                     }
                 }
@@ -114,22 +119,23 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
     const int ox = x0 + lx, epi = d.epilogue;
     if (ox >= W) return;
     const bool full = vecw || ox + SPX <= W;
-    if (epi & RISP_EPI_SHUFFLE2) {          // cout == 4 through PixelShuffle(2): (N,4,H,W) -> (N,1,2H,2W), bias only
+    if (epi & RISP_EPI_SHUFFLE2) {          // PixelShuffle(2): (N,4G,H,W) -> (N,G,2H,2W), cout pair 2g+i = row i of group g
+        const int groups = d.cout >> 2;
 #pragma unroll
         for (int o = 0; o < SPY; ++o) {
             const int oy = y0 + ly + o;
             if (oy >= H) break;
-            float b[4];
 #pragma unroll
-            for (int co = 0; co < 4; ++co) b[co] = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float *yp = d.y + ((size_t)n * 2 * H + 2 * oy + i) * (2 * (size_t)W) + 2 * ox;
+            for (int q = 0; q < NP; ++q) {
+                const int g = q >> 1, i = q & 1;
+                if (g < groups) {
+                const float b0 = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[2 * q], b1 = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[2 * q + 1];
+                float *yp = d.y + (((size_t)n * groups + g) * 2 * H + 2 * oy + i) * (2 * (size_t)W) + 2 * ox;
                 float e[2 * SPX];
 #pragma unroll
                 for (int p = 0; p < SPX; ++p) {
-                    e[2 * p] = acc[o][p][i].x + b[2 * i];
-                    e[2 * p + 1] = acc[o][p][i].y + b[2 * i + 1];
+                    e[2 * p] = acc[o][p][q].x + b0;
+                    e[2 * p + 1] = acc[o][p][q].y + b1;
                 }
                 if (vecw) {
                     *reinterpret_cast<float4 *>(yp) = make_float4(e[0], e[1], e[2], e[3]);
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
 #pragma unroll
                     for (int p = 0; p < SPX; ++p)
                         if (ox + p < W) { yp[2 * p] = e[2 * p]; yp[2 * p + 1] = e[2 * p + 1]; }
+                }
                 }
             }
         }
@@ -148,7 +155,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
         const int oy = y0 + ly + o;
         if (oy >= H) break;
         const size_t pix = (size_t)oy * W + ox;
-        for (int co = 0; co < d.cout; ++co) {
+#pragma unroll
+        for (int co = 0; co < 2 * NP; ++co) {
+            if (co < d.cout) {
             const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co];
             float v[SPX];
 #pragma unroll
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
 #pragma unroll
                 for (int p = 0; p < SPX; ++p)
                     if (ox + p < W) yp[p] = v[p];
+            }
             }
         }
     }
@@ -257,12 +267,12 @@ __global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict_
     if (tid < K * K) out[(size_t)blockIdx.x * K * K + tid] = sums[tid / K][tid % K];
 }
 
-template <int KS>
+template <int KS, int NP>
 int launch_small(const risp_conv_desc &d, hipStream_t s) {
     constexpr int P = KS / 2;
     const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (SY + 2 * P) * STW;
     dim3 grid((d.W + SX - 1) / SX, (d.H + SY - 1) / SY, d.N);
-    hipLaunchKernelGGL(conv_small_kernel<KS>, grid, dim3(256), lds, s, d);
+    hipLaunchKernelGGL((conv_small_kernel<KS, NP>), grid, dim3(256), lds, s, d);
     RISP_LAUNCH_CHECK("risp_conv2d_small");
     return 0;
 }
@@ -271,28 +281,37 @@ int launch_small(const risp_conv_desc &d, hipStream_t s) {
 
 extern "C" {
 
-size_t risp_conv_small_wpack_floats(int cin, int ksize) { return (size_t)cin * ksize * ksize * 4; }
+int risp_conv_small_cout_pad(int cout) { return cout <= 4 ? 4 : 12; }
+
+size_t risp_conv_small_wpack_floats(int cin, int cout, int ksize) {
+    return (size_t)cin * ksize * ksize * risp_conv_small_cout_pad(cout);
+}
 
 int risp_conv2d_small(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_small: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_small: null tensor");
-    RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 4,
-                   "risp_conv2d_small: bad shape N=%d H=%d W=%d cin=%d cout=%d (cout <= 4)", d.N, d.H, d.W, d.cin, d.cout);
+    RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 12,
+                   "risp_conv2d_small: bad shape N=%d H=%d W=%d cin=%d cout=%d (cout <= 12)", d.N, d.H, d.W, d.cin, d.cout);
     RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_small: only plain loads");
     RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS | RISP_EPI_SHUFFLE2)),
                    "risp_conv2d_small: epilogue %d not supported", d.epilogue);
     RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_SHUFFLE2) ||
-                       (d.cout == 4 && !(d.epilogue & (RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK))),
-                   "risp_conv2d_small: PixelShuffle store needs cout == 4 and no other epilogue");
+                       (d.cout % 4 == 0 && !(d.epilogue & (RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK))),
+                   "risp_conv2d_small: PixelShuffle store needs cout %% 4 == 0 and no other epilogue");
     RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_small: bias missing");
     RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_small: add tensor missing");
     RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_small: mask tensor missing");
     RISP_CHECK_ARG((reinterpret_cast<uintptr_t>(d.wpack) & 15) == 0, "risp_conv2d_small: wpack must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (d.ksize == 3) return launch_small<3>(d, s);
-    if (d.ksize == 5) return launch_small<5>(d, s);
-    if (d.ksize == 9) return launch_small<9>(d, s);
+    if (d.cout <= 4) {
+        if (d.ksize == 3) return launch_small<3, 2>(d, s);
+        if (d.ksize == 5) return launch_small<5, 2>(d, s);
+        if (d.ksize == 9) return launch_small<9, 2>(d, s);
+    } else {
+        if (d.ksize == 3) return launch_small<3, 6>(d, s);
+        if (d.ksize == 5) return launch_small<5, 6>(d, s);
+    }
     risp_set_error("risp_conv2d_small: unsupported kernel size %d", d.ksize);
     return 1;
 }

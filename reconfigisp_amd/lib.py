@@ -55,7 +55,8 @@ SIGNATURES = {
     'risp_conv_wpack_floats': (_z, [_i, _i, _i]),
     'risp_conv_pack_weights': (_i, [_f, _i, _i, _i, _i, _f, _s]),
     'risp_conv2d': (_i, [C.POINTER(ConvDesc), _s]),
-    'risp_conv_small_wpack_floats': (_z, [_i, _i]),
+    'risp_conv_small_cout_pad': (_i, [_i]),
+    'risp_conv_small_wpack_floats': (_z, [_i, _i, _i]),
     'risp_conv2d_small': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_rect_sums': (_i, [_f, _f, _i, _i, _i, _i, _s]),
     'risp_conv_wino3_chunk': (_i, []),

@@ -230,3 +230,19 @@ def test_small_cout_pixelshuffle_store(hw):
     x = rnd(n, cin, h, w, seed=53)
     ref = TF.pixel_shuffle(TF.conv2d(x, wt, b, padding=1), 2)
     assert_close(CN.conv_small(x, CN.SmallConv(wt, b), n, h, w, epi=CN.EPI_SHUFFLE2), ref, what='small shuffle2')
+
+
+@pytest.mark.parametrize('cout', [5, 8, 12])
+@pytest.mark.parametrize('hw', [(8, 8), (20, 36), (33, 30)])
+def test_small_cout_up_to_12(cout, hw):
+    """cout <= 12 form of the direct kernel (SRCNNDemosaic's 5x5 32 -> 12 tail), plain and through PixelShuffle."""
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n, cin = 2, 32
+    wt, b = rnd(cout, cin, 5, 5, seed=61) * 0.1, rnd(cout, seed=62) * 0.1
+    x = rnd(n, cin, h, w, seed=63)
+    lin = TF.conv2d(x, wt, b, padding=2)
+    sc = CN.SmallConv(wt, b)
+    assert_close(CN.conv_small(x, sc, n, h, w), lin, what='small cout<=12')
+    if cout % 4 == 0:
+        assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_SHUFFLE2), TF.pixel_shuffle(lin, 2), what='small shuffle2 groups')

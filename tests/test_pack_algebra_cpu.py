@@ -62,6 +62,8 @@ def test_small_cout_pack_forward_and_backward_data(k):
     gref, = torch.autograd.grad(TF.conv2d(x, wf, None, padding=k // 2), x, gy)
     pack, cout = CN.small_weights(wf, transpose=True, keep=3)   # backward-data restricted to 3 input channels
     assert torch.allclose(small_emulate(gy, pack, cout, k), gref[:, :3], rtol=1e-10, atol=1e-10)
+    pack12, cout12 = CN.small_weights(wf[:12])
+    assert cout12 == 12 and pack12.shape == (7, k, k, 12)
     with pytest.raises(ValueError):
         CN.small_weights(wf)                                    # 16 output channels
 
