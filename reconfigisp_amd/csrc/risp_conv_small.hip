@@ -19,8 +19,7 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int SX = 64, SPX = 4, SPY = 2;     // tile width; SPX x SPY pixels per thread
-constexpr int SY = 16 * SPY;                 // tile height (16 x 16 threads)
+constexpr int SX = 64, SPX = 4;              // tile width; SPX x SPY pixels per thread, tile height 16 * SPY
 constexpr int HPAD = 4;                      // halo columns kept left and right of the tile (>= k/2, multiple of 4)
 constexpr int STW = SX + 2 * HPAD;           // LDS row stride: tile column t <-> image x0 - HPAD + t
 
@@ -31,8 +30,11 @@ template <int KS> struct SmallCfg { static constexpr int CCH = KS == 9 ? 3 : 4; 
 // rows, and each filter row (KS x 4 wave-uniform weights, scalar loads) serves both output rows too.
 // NP = pairs of output channels held per pixel: 2 (cout <= 4) or 6 (cout <= 12: SRCNNDemosaic's 5x5 32 -> 12 tail,
 // srcnn_demosaic_arch.py:21, which the matrix-core kernel pads to 32).  The weight pack is [cin][k][k][2 NP].
-template <int KS, int NP>
+// SPY = output rows per thread: 2 (64 x 32 tiles) when the grid fills the chip, 1 (64 x 16 tiles, twice the
+// workgroups) for small batches - the per-GPU batch of the 8-GPU search is 4 images.
+template <int KS, int NP, int SPY>
 __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d) {
+    constexpr int SY = 16 * SPY;
     constexpr int P = KS / 2, TH_ = SY + 2 * P, CCH = SmallCfg<KS>::CCH, ROWV = STW / 4;
     extern __shared__ float4 lds4[];                       // [CCH][TH_][STW]
     const int tid = threadIdx.x, n = blockIdx.z, x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
@@ -76,8 +78,12 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
             pf[it] = q;
         }
     };
+    // SPY == 1 (small grids, few waves per CU, half the accumulators): the loads of stage s+1 are issued before the
+    // FMAs of stage s, so their latency does not sit between barriers.
+    constexpr bool PIPE = SPY == 1;
+    if (PIPE) fetch(0);
     for (int c0 = 0; c0 < cin; c0 += CCH) {
-        fetch(c0);
+        if (!PIPE) fetch(c0);
         __syncthreads();                                   // the previous stage has been consumed
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
             if (idx < CCH * TH_ * ROWV) lds4[idx] = pf[it];
         }
         __syncthreads();
+        if (PIPE && c0 + CCH < cin) fetch(c0 + CCH);
         const int cn = cin - c0 < CCH ? cin - c0 : CCH;
         for (int c = 0; c < cn; ++c) {
             const f32x2 *wch = wp + (size_t)(c0 + c) * KS * KS * NP;               // wave-uniform -> scalar loads
@@ -270,9 +277,14 @@ __global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict_
 template <int KS, int NP>
 int launch_small(const risp_conv_desc &d, hipStream_t s) {
     constexpr int P = KS / 2;
-    const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (SY + 2 * P) * STW;
-    dim3 grid((d.W + SX - 1) / SX, (d.H + SY - 1) / SY, d.N);
-    hipLaunchKernelGGL((conv_small_kernel<KS, NP>), grid, dim3(256), lds, s, d);
+    const int tiles_x = (d.W + SX - 1) / SX;
+    if ((size_t)tiles_x * ((d.H + 31) / 32) * d.N >= 384) {            // enough 64 x 32 tiles for every CU
+        const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (32 + 2 * P) * STW;
+        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N), dim3(256), lds, s, d);
+    } else {
+        const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (16 + 2 * P) * STW;
+        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 1>), dim3(tiles_x, (d.H + 15) / 16, d.N), dim3(256), lds, s, d);
+    }
     RISP_LAUNCH_CHECK("risp_conv2d_small");
     return 0;
 }
