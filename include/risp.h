@@ -198,6 +198,14 @@ int risp_conv_wino3_chunk(void);
 size_t risp_conv_wino3_wpack_floats(int cin, int cout);
 int risp_conv2d_wino3(const risp_conv_desc *d, void *stream);
 
+/* 5x5 layers with F(2,5) along x (0.6 of the matrix-core work; SRCNNRes' 64->32 layer and its backward,
+ * srcnn_res_arch.py:20).  wpack: [cout block of 32][chunk of risp_conv_wino5_chunk() cin][ky][t][ci][32] with
+ * U_t = (G g)_t / (4,6,6,24,24,1), G rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16) (1,-2,4,-8,16) (0,0,0,0,1)
+ * applied to filter row g = w[co][ci][ky][0..4].  Same restrictions as risp_conv2d_wino3. */
+int risp_conv_wino5_chunk(void);
+size_t risp_conv_wino5_wpack_floats(int cin, int cout);
+int risp_conv2d_wino5(const risp_conv_desc *d, void *stream);
+
 /* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */

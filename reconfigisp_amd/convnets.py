@@ -45,6 +45,30 @@ def _wino3_pack(w, transpose):
     return wino3_weights(w, transpose, L.load().risp_conv_wino3_chunk())
 
 
+_W5_G = ((1, 0, 0, 0, 0), (1, 1, 1, 1, 1), (1, -1, 1, -1, 1), (1, 2, 4, 8, 16), (1, -2, 4, -8, 16), (0, 0, 0, 0, 1))
+_W5_S = (4., 6., 6., 24., 24., 1.)
+
+
+def wino5_weights(w, transpose, ck):
+    """[cout block of 32][chunk of ``ck`` cin][ky][t][ci][32] Winograd F(2,5)-along-x weights of a 5x5 layer
+    (include/risp.h).  Pure tensor algebra (computed in fp64, stored in the dtype of ``w``)."""
+    if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
+        w = w.flip(2, 3).transpose(0, 1)
+    g = torch.tensor(_W5_G, dtype=torch.float64, device=w.device) / torch.tensor(_W5_S, dtype=torch.float64,
+                                                                                 device=w.device)[:, None]
+    u = torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype)       # (co, ci, ky, t)
+    co, ci = u.shape[0], u.shape[1]
+    ncb, nch = (co + 31) // 32, (ci + ck - 1) // ck
+    p = torch.zeros((ncb * 32, nch * ck, 5, 6), device=w.device, dtype=w.dtype)
+    p[:co, :ci] = u
+    # (cb, co_l, chunk, ci_l, ky, t) -> [cb][chunk][ky][t][ci_l][co_l]
+    return p.view(ncb, 32, nch, ck, 5, 6).permute(0, 2, 4, 5, 3, 1).contiguous()
+
+
+def _wino5_pack(w, transpose):
+    return wino5_weights(w, transpose, L.load().risp_conv_wino5_chunk())
+
+
 def small_weights(w, transpose=False, keep=None):
     """[cin][k][k][P] weights of ``risp_conv2d_small`` (P = 4 for cout <= 4, else 12) from a layer's (cout,cin,k,k)
     tensor; ``transpose``: the backward-data layer of a FORWARD weight (roles swapped, taps rotated by 180 degrees)
@@ -89,6 +113,8 @@ class PackedConv:
         self.wino_fwd = self.wino_bwd = None
         if self.k == 3 and WINOGRAD:
             self.wino_fwd, self.wino_bwd = _wino3_pack(w, False), _wino3_pack(w, True)
+        elif self.k == 5 and WINOGRAD:
+            self.wino_fwd, self.wino_bwd = _wino5_pack(w, False), _wino5_pack(w, True)
 
 
 class SmallConv:
@@ -131,7 +157,7 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wino if use_wino else (pc.bwd if transpose else pc.fwd)),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
-    L.call('risp_conv2d_wino3' if use_wino else 'risp_conv2d', C.byref(d), _stream())
+    L.call(('risp_conv2d_wino3' if pc.k == 3 else 'risp_conv2d_wino5') if use_wino else 'risp_conv2d', C.byref(d), _stream())
     return out
 
 

@@ -237,6 +237,178 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 5x5 layers: F(2,5) along x - 6 multiplications per output pair and filter row instead of 10 (0.6 of the MFMA
+// work of risp_conv2d).  SRCNNRes' 64 -> 32 layer and its backward (srcnn_res_arch.py:20) are 39 % of a search
+// step.  Interpolation points 0, +-1, +-2, inf with the row scalings moved into the weights, so the on-the-fly
+// input transform has small integer coefficients:
+//     V0 = 4 d0 - 5 d2 + d4        V1 =  4 (d1 + d2) - (d3 + d4)     V2 = -4 (d1 - d2) + (d3 - d4)
+//     V3 = -2 (d1 - d3) - (d2 - d4) V4 =  2 (d1 - d3) - (d2 - d4)     V5 = 4 d1 - 5 d3 + d5,   d_j = x[2p - 2 + j]
+//     U_t = (G g)_t / (4, 6, 6, 24, 24, 1),  G = rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16) (1,-2,4,-8,16) (0,0,0,0,1)
+//     y0 = m0 + m1 + m2 + m3 + m4,   y1 = m1 - m2 + 2 m3 - 2 m4 + m5
+// fp32 emulation of a 64 -> 32 layer: rms / max error 3.7e-7 / 6.5e-7 of max|y| against 3.9e-7 / 6.0e-7 for the
+// direct fp32 convolution.  One cout block of 32 per workgroup (6 accumulator tiles = 96 VGPRs); layers with 64
+// couts put the cout block in the grid.  4 input channels per LDS stage (2 x 24.6 KB).
+constexpr int W5IH = WTH + 4, W5TAPS = 30;
+
+#ifndef RISP_W5_WAVES
+#define RISP_W5_WAVES 2
+#endif
+template <int CK>
+__global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const risp_conv_desc d, int ncb) {
+    constexpr int CP = 32;
+    constexpr int XN = CK * W5IH * WIWP, WN = W5TAPS * CK * CP;
+    constexpr int NXV = (XN / 4 + 255) / 256, NWV = (WN / 4 + 255) / 256;
+    constexpr int NF = NXV + NWV;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sx = smem;                                  // [2][CK][W5IH][WIWP]
+    float *sw = smem + 2 * XN;                         // [2][W5TAPS][CK][CP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const int nchunks = (d.cin + CK - 1) / CK;
+    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+    int xoff[NXV], xcl[NXV];
+    float4 xr[NXV], wr[NWV];
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+        const int v = tid + 256 * i;
+        const int cl = v / (W5IH * (WIWP / 4)), rem = v - cl * (W5IH * (WIWP / 4));
+        const int iy = rem / (WIWP / 4), q = rem - iy * (WIWP / 4);
+        const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * q;
+        const bool ok = v < XN / 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        xcl[i] = ok ? cl : -1;                         // -1: outside the image -> zeros
+        xoff[i] = (cl * d.H + gy) * d.W + gx;
+    }
+    auto fetch_one = [&](int ch, int j) {              // j is a compile-time constant at every call site
+        if (j < NXV) {
+            const int ci = ch * CK + xcl[j];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xcl[j] >= 0 && ci < d.cin) v = *reinterpret_cast<const float4 *>(xn + (size_t)ch * CK * hw + xoff[j]);
+            xr[j] = v;
+        } else if (j < NF) {
+            const int v = tid + 256 * (j - NXV);
+            wr[j - NXV] = (v < WN / 4) ? reinterpret_cast<const float4 *>(wpack + (size_t)ch * WN)[v]
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto publish = [&](int buf) {
+        float *sxb = sx + buf * XN, *swb = sw + buf * WN;
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < NF; ++j) fetch_one(0, j);
+    publish(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        __syncthreads();                               // tile ch published, tile ch-1 no longer read
+        const bool more = ch + 1 < nchunks;
+        if (more) {                                    // next chunk's global loads: in flight during this chunk's MFMAs
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fetch_one(ch + 1, j);
+        }
+        // d0 of pair p sits at staged column 2p + 2 (image x0 + 2p - 2): 8-byte aligned
+        const float *bx = sx + buf * XN + (half * W5IH + wave) * WIWP + 2 + 2 * l31;
+        const float *aw = sw + buf * WN + half * CP + l31;
+        constexpr int NG = 5 * (CK / 2);
+        float opa[2][6], opd[2][6];
+        auto load_group = [&](int g, int slot) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+            const float *dp = bx + (2 * cp * W5IH + ky) * WIWP;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) opd[slot][j] = dp[j];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot = g & 1;
+            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);         // keep the reads above this group's MFMAs
+            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3], d4 = opd[slot][4],
+                        d5 = opd[slot][5];
+            const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
+            const float bv[6] = {4.f * d0 - 5.f * d2 + d4, 4.f * s12 - s34, m34 - 4.f * m12, -2.f * m13 - m24, 2.f * m13 - m24,
+                                 4.f * d1 - 5.f * d3 + d5};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) publish(buf ^ 1);
+    }
+
+    // ---- epilogue (as conv_wino3_kernel, one cout block)
+    const int epi = d.epilogue;
+    const float *__restrict__ pbias = d.bias;
+    const float *__restrict__ padd = d.add;
+    const float *__restrict__ pmask = d.mask;
+    float *__restrict__ py = d.y;
+    const int oy = y0 + wave;
+    __syncthreads();                                   // every wave is done with the staging tiles
+    float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
+    const int q4 = 4 * (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int col = (e & 3) + 8 * (e >> 2) + 4 * half;
+        const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+        float2 y2;
+        y2.x = m0 + m1 + m2 + m3 + m4;
+        y2.y = m1 - m2 + 2.f * m3 - 2.f * m4 + m5;
+        *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool row_ok = oy < d.H && x0 + q4 < d.W;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                      // 32 couts x 16 float4 = 512 float4 / 64 lanes
+        const int col = (lane >> 4) + 4 * i, co = cb * 32 + col;
+        float4 o = *reinterpret_cast<const float4 *>(tile + col * WTW + q4);
+        if (!(row_ok && co < d.cout)) continue;
+        const size_t off = ((size_t)n * d.cout + co) * hw + (size_t)oy * d.W + x0 + q4;
+        const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : pbias[co];
+        o.x += b; o.y += b; o.z += b; o.w += b;
+        if ((epi & RISP_EPI_ADD) && co < d.add_c) {
+            const float4 a = *reinterpret_cast<const float4 *>(padd + ((size_t)n * d.add_c + co) * hw + (size_t)oy * d.W + x0 + q4);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        if (epi & RISP_EPI_RELU) {
+            o.x = o.x > 0.f ? o.x : 0.f;
+            o.y = o.y > 0.f ? o.y : 0.f;
+            o.z = o.z > 0.f ? o.z : 0.f;
+            o.w = o.w > 0.f ? o.w : 0.f;
+        }
+        if (epi & RISP_EPI_MASK) {
+            const float4 m = *reinterpret_cast<const float4 *>(pmask + off);
+            o.x = m.x > 0.f ? o.x : 0.f;
+            o.y = m.y > 0.f ? o.y : 0.f;
+            o.z = m.z > 0.f ? o.z : 0.f;
+            o.w = m.w > 0.f ? o.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(py + off) = o;
+    }
+}
+
 template <int CK, int CB>
 int launch_wino(const risp_conv_desc &d, hipStream_t s) {
     constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * 32 * CB;
@@ -296,6 +468,41 @@ int risp_conv2d_wino3(const risp_conv_desc *dp, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d.cout > 32) return launch_wino<WCK, 2>(d, s);
     return launch_wino<WCK, 1>(d, s);
+}
+
+constexpr int W5CK = 4;
+int risp_conv_wino5_chunk(void) { return W5CK; }
+
+size_t risp_conv_wino5_wpack_floats(int cin, int cout) {
+    return (size_t)((cout + 31) / 32) * ((cin + W5CK - 1) / W5CK) * W5TAPS * W5CK * 32;
+}
+
+int risp_conv2d_wino5(const risp_conv_desc *dp, void *stream) {
+    RISP_CHECK_ARG(dp, "risp_conv2d_wino5: null descriptor");
+    const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino5: null tensor");
+    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 && d.ksize == 5 &&
+                       (size_t)d.N * ((d.cout + 31) / 32) <= 65535,
+                   "risp_conv2d_wino5: needs a 5x5 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,
+                   d.W, d.cin, d.cout, d.ksize);
+    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_wino5: only plain loads");
+    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
+                   "risp_conv2d_wino5: epilogue %d not supported", d.epilogue);
+    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_wino5: bias missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_wino5: add tensor missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_wino5: mask tensor missing");
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
+                     reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
+                   "risp_conv2d_wino5: tensors must be 16-byte aligned");
+    const int ncb = (d.cout + 31) / 32;
+    constexpr int XN = W5CK * W5IH * WIWP, WN = W5TAPS * W5CK * 32;
+    size_t lds = sizeof(float) * 2 * (XN + WN);
+    const size_t epi = sizeof(float) * 4 * 32 * WTW;
+    if (lds < epi) lds = epi;
+    dim3 grid((d.W + WTW - 1) / WTW, (d.H + WTH - 1) / WTH, d.N * ncb);
+    hipLaunchKernelGGL(conv_wino5_kernel<W5CK>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
+    RISP_LAUNCH_CHECK("risp_conv2d_wino5");
+    return 0;
 }
 
 }  // extern "C"
