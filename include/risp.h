@@ -198,6 +198,13 @@ int risp_conv_wino3_chunk(void);
 size_t risp_conv_wino3_wpack_floats(int cin, int cout);
 int risp_conv2d_wino3(const risp_conv_desc *d, void *stream);
 
+/* 3x3 layers with F(4,3) along x (half the matrix-core work of risp_conv2d): wpack [cout block of 32][chunk of
+ * risp_conv_wino43_chunk() cin][ky][t][ci][32], U_t = (G g)_t, G rows (1/4,0,0) (1/6,1/6,1/6) (1/6,-1/6,1/6)
+ * (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1).  Same restrictions as risp_conv2d_wino3. */
+int risp_conv_wino43_chunk(void);
+size_t risp_conv_wino43_wpack_floats(int cin, int cout);
+int risp_conv2d_wino43(const risp_conv_desc *d, void *stream);
+
 /* 5x5 layers with F(2,5) along x (0.6 of the matrix-core work; SRCNNRes' 64->32 layer and its backward,
  * srcnn_res_arch.py:20).  wpack: [cout block of 32][chunk of risp_conv_wino5_chunk() cin][ky][t][ci][32] with
  * U_t = (G g)_t / (4,6,6,24,24,1), G rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16) (1,-2,4,-8,16) (0,0,0,0,1)

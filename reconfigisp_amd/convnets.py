@@ -24,6 +24,7 @@ EPI_RELU, EPI_ADD, EPI_MASK, EPI_SHUFFLE2, EPI_NOBIAS, EPI_CASEBIAS = 1, 2, 4, 8
 
 # 3x3 layers run on the Winograd-x kernel (risp_conv2d_wino3) unless RISP_WINOGRAD=0 (A/B switch)
 WINOGRAD = os.environ.get('RISP_WINOGRAD', '1') != '0'
+WINO_F43 = os.environ.get('RISP_WINO_F43', '1') != '0'       # 3x3: F(4,3) (default) or F(2,3)
 _WINO_EPI = EPI_RELU | EPI_ADD | EPI_MASK | EPI_NOBIAS
 
 
@@ -45,6 +46,27 @@ def _wino3_pack(w, transpose):
     return wino3_weights(w, transpose, L.load().risp_conv_wino3_chunk())
 
 
+_W43_G = ((1 / 4, 0, 0), (1 / 6, 1 / 6, 1 / 6), (1 / 6, -1 / 6, 1 / 6), (1 / 24, 1 / 12, 1 / 6), (1 / 24, -1 / 12, 1 / 6), (0, 0, 1))
+
+
+def _wino_blocked_pack(u, ck):
+    """(co, ci, ky, t) transformed weights -> [cout block of 32][chunk of ck cin][ky][t][ci][32]."""
+    co, ci, kk, nt = u.shape
+    ncb, nch = (co + 31) // 32, (ci + ck - 1) // ck
+    p = torch.zeros((ncb * 32, nch * ck, kk, nt), device=u.device, dtype=u.dtype)
+    p[:co, :ci] = u
+    return p.view(ncb, 32, nch, ck, kk, nt).permute(0, 2, 4, 5, 3, 1).contiguous()
+
+
+def wino43_weights(w, transpose, ck):
+    """Winograd F(4,3)-along-x weights of a 3x3 layer in the blocked layout of ``risp_conv2d_wino43`` (fp64 algebra,
+    stored in the dtype of ``w``)."""
+    if transpose:
+        w = w.flip(2, 3).transpose(0, 1)
+    g = torch.tensor(_W43_G, dtype=torch.float64, device=w.device)
+    return _wino_blocked_pack(torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype), ck)
+
+
 _W5_G = ((1, 0, 0, 0, 0), (1, 1, 1, 1, 1), (1, -1, 1, -1, 1), (1, 2, 4, 8, 16), (1, -2, 4, -8, 16), (0, 0, 0, 0, 1))
 _W5_S = (4., 6., 6., 24., 24., 1.)
 
@@ -56,13 +78,7 @@ def wino5_weights(w, transpose, ck):
         w = w.flip(2, 3).transpose(0, 1)
     g = torch.tensor(_W5_G, dtype=torch.float64, device=w.device) / torch.tensor(_W5_S, dtype=torch.float64,
                                                                                  device=w.device)[:, None]
-    u = torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype)       # (co, ci, ky, t)
-    co, ci = u.shape[0], u.shape[1]
-    ncb, nch = (co + 31) // 32, (ci + ck - 1) // ck
-    p = torch.zeros((ncb * 32, nch * ck, 5, 6), device=w.device, dtype=w.dtype)
-    p[:co, :ci] = u
-    # (cb, co_l, chunk, ci_l, ky, t) -> [cb][chunk][ky][t][ci_l][co_l]
-    return p.view(ncb, 32, nch, ck, 5, 6).permute(0, 2, 4, 5, 3, 1).contiguous()
+    return _wino_blocked_pack(torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype), ck)
 
 
 def _wino5_pack(w, transpose):
@@ -111,10 +127,13 @@ class PackedConv:
         L.call('risp_conv_pack_weights', _p(w), self.cin, self.cout, self.k, 0, _p(self.fwd), _stream())
         L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
         self.wino_fwd = self.wino_bwd = None
+        self.wino_entry = self.wino43_fwd = None
         if self.k == 3 and WINOGRAD:
-            self.wino_fwd, self.wino_bwd = _wino3_pack(w, False), _wino3_pack(w, True)
+            self.wino_fwd, self.wino_bwd, self.wino_entry = _wino3_pack(w, False), _wino3_pack(w, True), 'risp_conv2d_wino3'
+            if WINO_F43:                              # inference-only forward form (see conv())
+                self.wino43_fwd = wino43_weights(w, False, L.load().risp_conv_wino43_chunk())
         elif self.k == 5 and WINOGRAD:
-            self.wino_fwd, self.wino_bwd = _wino5_pack(w, False), _wino5_pack(w, True)
+            self.wino_fwd, self.wino_bwd, self.wino_entry = _wino5_pack(w, False), _wino5_pack(w, True), 'risp_conv2d_wino5'
 
 
 class SmallConv:
@@ -142,22 +161,28 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
 
 
 def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None, epi=0, add=None, add_c=0,
-         mask=None, out=None):
-    """One fused convolution launch at resolution (h,w); returns the output tensor."""
+         mask=None, out=None, infer=False):
+    """One fused convolution launch at resolution (h,w); returns the output tensor.  ``infer``: no backward pass
+    will read this layer's activations (selects the F(4,3) form of a 3x3 layer)."""
     cin, cout = (pc.cout, pc.cin) if transpose else (pc.cin, pc.cout)
     if transpose:
         epi |= EPI_NOBIAS
     if out is None:
         shape = (n, cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, cout, h, w)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
-    wino = pc.wino_bwd if transpose else pc.wino_fwd
+    wino, entry = (pc.wino_bwd if transpose else pc.wino_fwd), pc.wino_entry
+    # F(4,3) has about twice the rounding error of F(2,3) (still ~2e-7 of max|y|): harmless for outputs, but in
+    # training it flips more ReLU masks relative to the reference's arithmetic, and gradients are discontinuous
+    # there - so it serves inference only, F(2,3) everything that feeds a backward pass.
+    if pc.wino43_fwd is not None and not transpose and infer:
+        wino, entry = pc.wino43_fwd, 'risp_conv2d_wino43'
     use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
                 (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
                  (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wino if use_wino else (pc.bwd if transpose else pc.fwd)),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
-    L.call(('risp_conv2d_wino3' if pc.k == 3 else 'risp_conv2d_wino5') if use_wino else 'risp_conv2d', C.byref(d), _stream())
+    L.call(entry if use_wino else 'risp_conv2d', C.byref(d), _stream())
     return out
 
 
@@ -190,16 +215,16 @@ class PackCache:
 # --------------------------------------------------------------------------- Path-Restore (14 layers)
 class _Path14l(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, packs, bayer):
+    def forward(ctx, x, packs, bayer, infer):
         x = _dev(x, 'img')
         n = x.shape[0]
         h, w = (x.shape[2] // 2, x.shape[3] // 2) if bayer else (x.shape[2], x.shape[3])
         first, blocks, last = packs
-        r = conv(x, first, n, h, w, load=LOAD_UNSHUFFLE2 if bayer else LOAD_PLAIN, epi=EPI_RELU)
+        r = conv(x, first, n, h, w, load=LOAD_UNSHUFFLE2 if bayer else LOAD_PLAIN, epi=EPI_RELU, infer=infer)
         saved = [r]
         for c1, c2 in blocks:
-            u = conv(r, c1, n, h, w, epi=EPI_RELU)
-            r = conv(u, c2, n, h, w, epi=EPI_ADD | EPI_RELU, add=r, add_c=64)
+            u = conv(r, c1, n, h, w, epi=EPI_RELU, infer=infer)
+            r = conv(u, c2, n, h, w, epi=EPI_ADD | EPI_RELU, add=r, add_c=64, infer=infer)
             saved += [u, r]
         # the 64 -> 4 / 3 tail runs on the direct small-cout kernel (the matrix-core kernel pads cout to 32)
         y = conv_small(r, last.small, n, h, w, epi=EPI_SHUFFLE2 if bayer else 0)
@@ -222,7 +247,7 @@ class _Path14l(torch.autograd.Function):
             gu = conv(g, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=u)
             g = conv(gu, c1, n, h, w, transpose=True, epi=EPI_ADD | EPI_MASK, add=g, add_c=64, mask=r_in)
         gx = conv_small(g, first.small_bwd, n, h, w, epi=EPI_SHUFFLE2 if ctx.bayer else 0)
-        return gx, None, None
+        return gx, None, None, None
 
 
 def build_path14l_packs(seq, flip_bgr):
@@ -241,7 +266,11 @@ def build_path14l_packs(seq, flip_bgr):
 
 
 def path14l(x, packs, bayer):
-    return _Path14l.apply(x, packs, bayer)
+    # autograd globally off (test.py / test_split.py / serving): nothing in the process will differentiate through
+    # these activations, so the 3x3 layers may take the F(4,3) form.  With autograd on - even for an op whose own
+    # input needs no gradient - the F(2,3) form keeps the rounding, and with it the ReLU masks of every downstream
+    # op, as close to the reference's arithmetic as the direct kernel does.
+    return _Path14l.apply(x, packs, bayer, not torch.is_grad_enabled())
 
 
 # --------------------------------------------------------------------------- SRCNN (residual proxy)

@@ -409,6 +409,191 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 layers, F(4,3) along x: FOUR adjacent outputs of a filter row from 6 multiplications - 18 "taps" per output
+// quad where F(2,3) above needs 24 and the direct kernel 36 (half its MFMA work).  Same interpolation points and
+// scaled input transform as F(2,5); U_t = (G g)_t with G rows (1/4,0,0) (1/6,1/6,1/6) (1/6,-1/6,1/6)
+// (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1);  y0 = m0+m1+m2+m3+m4, y1 = m1-m2+2m3-2m4, y2 = m1+m2+4m3+4m4,
+// y3 = m1-m2+8m3-8m4+m5;  d_j = x[4q - 1 + j].  fp32 emulation of a 64 -> 64 layer: rms error 2.1e-7 of max|y|
+// (direct fp32: 1.5e-7).  Wave = one output row of 128 pixels (MFMA column = pixel quad) x one cout block of 32
+// (6 accumulator tiles); the lane's four pixels of a cout row leave as ONE 16-byte store, no LDS transposition.
+constexpr int W43TW = 128, W43WP = W43TW + 8, W43TAPS = 18;
+
+#ifndef RISP_W43_WAVES
+#define RISP_W43_WAVES 2
+#endif
+template <int CK>
+__global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const risp_conv_desc d, int ncb) {
+    constexpr int CP = 32;
+    constexpr int XN = CK * WIH * W43WP, WN = W43TAPS * CK * CP;
+    constexpr int NXV = (XN / 4 + 255) / 256, NWV = (WN / 4 + 255) / 256;
+    constexpr int NF = NXV + NWV;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sx = smem;                                  // [2][CK][WIH][W43WP]
+    float *sw = smem + 2 * XN;                         // [2][W43TAPS][CK][CP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * W43TW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const int nchunks = (d.cin + CK - 1) / CK;
+    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
+    unsigned long long t_k0 = 0, rt_k0 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, s_bar = 0, s_cmp = 0, s_pub = 0, t_begin = 0, t_loop_end = 0;
+    (void)t_k0; (void)rt_k0; (void)t0; (void)t1; (void)t2; (void)t3; (void)s_bar; (void)s_cmp; (void)s_pub; (void)t_begin; (void)t_loop_end;
+    WSTAMP(t_k0);
+#ifdef RISP_CONV_STAMPS
+    rt_k0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+    int xoff[NXV], xcl[NXV];
+    float4 xr[NXV], wr[NWV];
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+        const int v = tid + 256 * i;
+        const int cl = v / (WIH * (W43WP / 4)), rem = v - cl * (WIH * (W43WP / 4));
+        const int iy = rem / (W43WP / 4), q = rem - iy * (W43WP / 4);
+        const int gy = y0 + iy - 1, gx = x0 - 4 + 4 * q;
+        const bool ok = v < XN / 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        xcl[i] = ok ? cl : -1;                         // -1: outside the image -> zeros
+        xoff[i] = (cl * d.H + gy) * d.W + gx;
+    }
+    auto fetch_one = [&](int ch, int j) {              // j is a compile-time constant at every call site
+        if (j < NXV) {
+            const int ci = ch * CK + xcl[j];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xcl[j] >= 0 && ci < d.cin) v = *reinterpret_cast<const float4 *>(xn + (size_t)ch * CK * hw + xoff[j]);
+            xr[j] = v;
+        } else if (j < NF) {
+            const int v = tid + 256 * (j - NXV);
+            wr[j - NXV] = (v < WN / 4) ? reinterpret_cast<const float4 *>(wpack + (size_t)ch * WN)[v]
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto publish = [&](int buf) {
+        float *sxb = sx + buf * XN, *swb = sw + buf * WN;
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int v = tid + 256 * i;
+            if (v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
+        }
+    };
+
+    WSTAMP(t_begin);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) fetch_one(0, j);
+    publish(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        WSTAMP(t0);
+        __syncthreads();                               // tile ch published, tile ch-1 no longer read
+        WSTAMP(t1);
+        const bool more = ch + 1 < nchunks;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fetch_one(ch + 1, j);
+        }
+        // d0 of quad q sits at staged column 4q + 3 (image x0 + 4q - 1)
+        const float *bx = sx + buf * XN + (half * WIH + wave) * W43WP + 3 + 4 * l31;
+        const float *aw = sw + buf * WN + half * CP + l31;
+        constexpr int NG = 3 * (CK / 2);
+        float opa[2][6], opd[2][6];
+        auto load_group = [&](int g, int slot) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+            const float *dp = bx + (2 * cp * WIH + ky) * W43WP;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) opd[slot][j] = dp[j];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot = g & 1;
+            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);         // keep the reads above this group's MFMAs
+            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3], d4 = opd[slot][4],
+                        d5 = opd[slot][5];
+            const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
+            const float bv[6] = {4.f * d0 - 5.f * d2 + d4, 4.f * s12 - s34, m34 - 4.f * m12, -2.f * m13 - m24, 2.f * m13 - m24,
+                                 4.f * d1 - 5.f * d3 + d5};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        WSTAMP(t2);
+        if (more) publish(buf ^ 1);
+        WSTAMP(t3);
+#ifdef RISP_CONV_STAMPS
+        s_bar += t1 - t0;
+        s_cmp += t2 - t1;
+        s_pub += t3 - t2;
+#endif
+    }
+    WSTAMP(t_loop_end);
+
+    // ---- epilogue: the lane owns 4 consecutive pixels of 16 cout rows - one 16-byte store each
+    const int epi = d.epilogue;
+    const int oy = y0 + wave, ox = x0 + 4 * l31;
+    if (oy < d.H && ox < d.W) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (co >= d.cout) continue;
+        const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+        const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
+        const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co];
+        float4 o = make_float4(m0 + a12 + a34 + b, s12 + 2.f * s34 + b, a12 + 4.f * a34 + b, s12 + 8.f * s34 + m5 + b);
+        const size_t off = ((size_t)n * d.cout + co) * hw + (size_t)oy * d.W + ox;
+        if ((epi & RISP_EPI_ADD) && co < d.add_c) {
+            const float4 a = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + co) * hw + (size_t)oy * d.W + ox);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        if (epi & RISP_EPI_RELU) {
+            o.x = o.x > 0.f ? o.x : 0.f;
+            o.y = o.y > 0.f ? o.y : 0.f;
+            o.z = o.z > 0.f ? o.z : 0.f;
+            o.w = o.w > 0.f ? o.w : 0.f;
+        }
+        if (epi & RISP_EPI_MASK) {
+            const float4 m = *reinterpret_cast<const float4 *>(d.mask + off);
+            o.x = m.x > 0.f ? o.x : 0.f;
+            o.y = m.y > 0.f ? o.y : 0.f;
+            o.z = m.z > 0.f ? o.z : 0.f;
+            o.w = m.w > 0.f ? o.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(d.y + off) = o;
+    }
+    }
+#ifdef RISP_CONV_STAMPS
+    if (lane == 0 && d.mask && !(d.epilogue & RISP_EPI_MASK)) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(d.mask)) +
+                                8 * ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave);
+        unsigned long long t_end;
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        WSTAMP(t_end);
+        o[0] = s_bar; o[1] = s_cmp; o[2] = s_pub;
+        o[3] = t_begin - t_k0;
+        o[4] = t_loop_end - t_begin;
+        o[5] = t_end - t_loop_end;
+        o[6] = rt_k0;
+        o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
 template <int CK, int CB>
 int launch_wino(const risp_conv_desc &d, hipStream_t s) {
     constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * 32 * CB;
@@ -468,6 +653,39 @@ int risp_conv2d_wino3(const risp_conv_desc *dp, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d.cout > 32) return launch_wino<WCK, 2>(d, s);
     return launch_wino<WCK, 1>(d, s);
+}
+
+constexpr int W43CK = 4;
+int risp_conv_wino43_chunk(void) { return W43CK; }
+
+size_t risp_conv_wino43_wpack_floats(int cin, int cout) {
+    return (size_t)((cout + 31) / 32) * ((cin + W43CK - 1) / W43CK) * W43TAPS * W43CK * 32;
+}
+
+int risp_conv2d_wino43(const risp_conv_desc *dp, void *stream) {
+    RISP_CHECK_ARG(dp, "risp_conv2d_wino43: null descriptor");
+    const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino43: null tensor");
+    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 && d.ksize == 3 &&
+                       (size_t)d.N * ((d.cout + 31) / 32) <= 65535,
+                   "risp_conv2d_wino43: needs a 3x3 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,
+                   d.W, d.cin, d.cout, d.ksize);
+    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_wino43: only plain loads");
+    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
+                   "risp_conv2d_wino43: epilogue %d not supported", d.epilogue);
+    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_wino43: bias missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_wino43: add tensor missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_wino43: mask tensor missing");
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
+                     reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
+                   "risp_conv2d_wino43: tensors must be 16-byte aligned");
+    const int ncb = (d.cout + 31) / 32;
+    constexpr int XN = W43CK * WIH * W43WP, WN = W43TAPS * W43CK * 32;
+    const size_t lds = sizeof(float) * 2 * (XN + WN);
+    dim3 grid((d.W + W43TW - 1) / W43TW, (d.H + WTH - 1) / WTH, d.N * ncb);
+    hipLaunchKernelGGL(conv_wino43_kernel<W43CK>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
+    RISP_LAUNCH_CHECK("risp_conv2d_wino43");
+    return 0;
 }
 
 constexpr int W5CK = 4;

@@ -62,6 +62,9 @@ SIGNATURES = {
     'risp_conv_wino3_chunk': (_i, []),
     'risp_conv_wino3_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino3': (_i, [C.POINTER(ConvDesc), _s]),
+    'risp_conv_wino43_chunk': (_i, []),
+    'risp_conv_wino43_wpack_floats': (_z, [_i, _i]),
+    'risp_conv2d_wino43': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wino5_chunk': (_i, []),
     'risp_conv_wino5_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino5': (_i, [C.POINTER(ConvDesc), _s]),

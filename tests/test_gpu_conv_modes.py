@@ -246,3 +246,24 @@ def test_small_cout_up_to_12(cout, hw):
     assert_close(CN.conv_small(x, sc, n, h, w), lin, what='small cout<=12')
     if cout % 4 == 0:
         assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_SHUFFLE2), TF.pixel_shuffle(lin, 2), what='small shuffle2 groups')
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 64), (4, 64), (64, 33), (3, 64), (64, 3)])
+@pytest.mark.parametrize('hw', SIZES + [(12, 128), (6, 260)])
+def test_inference_dispatch_f43(cin, cout, hw):
+    """3x3 layers whose activations no backward pass reads go through risp_conv2d_wino43 (F(4,3)), the others
+    through F(2,3).  Both against PyTorch, every epilogue the kernels share."""
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n = 2
+    wt, b = rnd(cout, cin, 3, 3, seed=71) * 0.1, rnd(cout, seed=72) * 0.1
+    pc = CN.PackedConv(wt, b)
+    assert pc.wino43_fwd is not None and pc.wino_fwd is not None
+    x, add, mask = rnd(n, cin, h, w, seed=73), rnd(n, cout, h, w, seed=74), rnd(n, cout, h, w, seed=75)
+    lin = TF.conv2d(x, wt, b, padding=1)
+    for infer in (True, False):
+        assert_close(CN.conv(x, pc, n, h, w, infer=infer), lin, what='plain infer=%s' % infer)
+        assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=cout, infer=infer),
+                     torch.relu(lin + add), what='add+relu infer=%s' % infer)
+        assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_MASK, mask=mask, infer=infer), lin * (mask > 0),
+                     what='mask infer=%s' % infer)

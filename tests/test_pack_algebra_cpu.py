@@ -78,6 +78,38 @@ def test_winograd5_pack_forward_and_backward_data(cin, cout, ck):
     assert torch.allclose(got, gref, rtol=1e-9, atol=1e-9)
 
 
+def wino43_emulate(x, pack, ck, cout):
+    """What conv_wino43_kernel computes from its pack: F(4,3), four outputs per quad from 6 products per filter row."""
+    n, cin, h, w = x.shape
+    nq = (w + 3) // 4
+    xp = TF.pad(x, (1, 4 * nq - w + 4, 1, 1))
+    d = [xp[:, :, :, j:j + 4 * nq:4] for j in range(6)]                  # d_j = x[4q - 1 + j]
+    s12, s34, m12, m34, m13, m24 = d[1] + d[2], d[3] + d[4], d[1] - d[2], d[3] - d[4], d[1] - d[3], d[2] - d[4]
+    v = torch.stack([4 * d[0] - 5 * d[2] + d[4], 4 * s12 - s34, m34 - 4 * m12, -2 * m13 - m24, 2 * m13 - m24,
+                     4 * d[1] - 5 * d[3] + d[5]], dim=-1)
+    ncb, nch = pack.shape[0], pack.shape[1]
+    u = pack.permute(0, 5, 1, 4, 2, 3).reshape(ncb * 32, nch * ck, 3, 6)[:cout, :cin]
+    m = torch.zeros(n, cout, h, nq, 6, dtype=x.dtype)
+    for ky in range(3):
+        m += torch.einsum('nchqt,oct->nohqt', v[:, :, ky:ky + h], u[:, :, ky])
+    a12, s12, a34, s34 = m[..., 1] + m[..., 2], m[..., 1] - m[..., 2], m[..., 3] + m[..., 4], m[..., 3] - m[..., 4]
+    y = torch.stack([m[..., 0] + a12 + a34, s12 + 2 * s34, a12 + 4 * a34, s12 + 8 * s34 + m[..., 5]], dim=-1)
+    return y.reshape(n, cout, h, 4 * nq)[..., :w]
+
+
+@pytest.mark.parametrize('cin,cout,ck', [(64, 64, 4), (5, 3, 4), (12, 33, 2)])
+def test_winograd43_pack_forward_and_backward_data(cin, cout, ck):
+    wt = rnd(cout, cin, 3, 3, seed=21)
+    x = rnd(2, cin, 6, 12, seed=22).requires_grad_(True)
+    ref = TF.conv2d(x, wt, None, padding=1)
+    got = wino43_emulate(x.detach(), CN.wino43_weights(wt, False, ck), ck, cout)
+    assert torch.allclose(got, ref.detach(), rtol=1e-9, atol=1e-9)
+    gy = rnd(2, cout, 6, 12, seed=23)
+    gref, = torch.autograd.grad(ref, x, gy)
+    got = wino43_emulate(gy, CN.wino43_weights(wt, True, ck), ck, cin)
+    assert torch.allclose(got, gref, rtol=1e-9, atol=1e-9)
+
+
 def small_emulate(x, pack, cout, k):
     w = pack[..., :cout].permute(3, 0, 1, 2)                  # back to (cout, cin, k, k)
     return TF.conv2d(x, w, None, padding=k // 2)

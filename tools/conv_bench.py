@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of one risp_conv2d layer (GPU box): python tools/conv_bench.py [cin cout k N H W reps]"""
+"""Micro-benchmark of one convolution layer (GPU box): python tools/conv_bench.py [cin cout k N H W reps]
+Default: the inference dispatch (infer=True: 3x3 -> F(4,3)); RISP_BENCH_GRAD=1 times the training dispatch
+(3x3 -> F(2,3)); RISP_WINOGRAD=0 the direct kernel."""
 import os
 import sys
 import time
@@ -16,16 +18,17 @@ wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
 b = torch.randn(cout, device=dev) * 0.01
 pc = CN.PackedConv(wt, b)
 x = torch.rand(n, cin, h, w, device=dev)
-y = CN.conv(x, pc, n, h, w, epi=CN.EPI_RELU)
+INFER = os.environ.get('RISP_BENCH_GRAD') != '1'
+y = CN.conv(x, pc, n, h, w, epi=CN.EPI_RELU, infer=INFER)
 ref = torch.relu(torch.nn.functional.conv2d(x[:2], wt, b, padding=k // 2))
 err = (y[:2] - ref).abs().max().item()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(3):
-    CN.conv(x, pc, n, h, w, epi=CN.EPI_RELU, out=y)
+    CN.conv(x, pc, n, h, w, epi=CN.EPI_RELU, out=y, infer=INFER)
 e0.record()
 for _ in range(reps):
-    CN.conv(x, pc, n, h, w, epi=CN.EPI_RELU, out=y)
+    CN.conv(x, pc, n, h, w, epi=CN.EPI_RELU, out=y, infer=INFER)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps

@@ -19,7 +19,9 @@ from reconfigisp_amd import lib as L
 L.LIB_PATH = so
 from reconfigisp_amd import convnets as CN
 
-wino = len(sys.argv) > 1 and sys.argv[1] == 'wino'      # python tools/conv_stamps.py wino [cin cout 3 n h w]: the Winograd kernel
+# python tools/conv_stamps.py wino|wino43 [cin cout 3 n h w]: the F(2,3) / F(4,3) Winograd kernels
+wino = len(sys.argv) > 1 and sys.argv[1] in ('wino', 'wino43')
+w43 = wino and sys.argv[1] == 'wino43'
 if wino:
     del sys.argv[1]
 cin, cout, k, n, h, w = (int(v) for v in (sys.argv[1:7] + ['64', '64', '3', '64', '128', '128'][len(sys.argv) - 1:]))
@@ -27,14 +29,15 @@ dev = torch.device('cuda')
 wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
 pc = CN.PackedConv(wt, torch.zeros(cout, device=dev))
 x = torch.rand(n, cin, h, w, device=dev)
-nwg = (((w + 63) // 64) * ((h + 3) // 4) * n) if wino else (((w + 31) // 32) * ((h + 15) // 16) * n)
+nwg = (((w + 127) // 128) * ((h + 3) // 4) * n * ((cout + 31) // 32)) if w43 else \
+      (((w + 63) // 64) * ((h + 3) // 4) * n) if wino else (((w + 31) // 32) * ((h + 15) // 16) * n)
 stamps = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
 y = torch.empty(n, cout, h, w, device=dev)
 for _ in range(2):
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=0, cin_img=0, epilogue=CN.EPI_RELU, add_c=0,
-                   x=x.data_ptr(), wpack=(pc.wino_fwd if wino else pc.fwd).data_ptr(), bias=pc.bias.data_ptr(), cvals=None,
+                   x=x.data_ptr(), wpack=(pc.wino43_fwd if w43 else pc.wino_fwd if wino else pc.fwd).data_ptr(), bias=pc.bias.data_ptr(), cvals=None,
                    add=None, mask=stamps.data_ptr(), y=y.data_ptr())
-    L.call('risp_conv2d_wino3' if wino else 'risp_conv2d', C.byref(d), None)
+    L.call('risp_conv2d_wino43' if w43 else pc.wino_entry if wino else 'risp_conv2d', C.byref(d), None)
 torch.cuda.synchronize()
 s = stamps.view(nwg * 4, 8).cpu().double()
 life_ticks = s[:, 7] - s[:, 6]
