@@ -268,8 +268,8 @@ def main():
                      cnn_ms_per_step=round(dev_ms_c, 3),
                      cnn_mfma_TFLOPs=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12, 2),
                      cnn_mfma_frac=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     cnn_note='algorithmic (direct-convolution) FLOPs / time; the 3x3 layers run a Winograd F(2,3) '
-                              'kernel that issues 2/3 of those FLOPs on the matrix cores')
+                     cnn_note='algorithmic (direct-convolution) FLOPs / time; the 3x3 layers run a Winograd F(4,3) '
+                              'kernel that issues half of those FLOPs on the matrix cores')
 
     if rank == 0:
         line = {
