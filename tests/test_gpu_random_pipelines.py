@@ -1,0 +1,67 @@
+"""GPU: randomly drawn fixed pipelines (both registries) against the oracle, stage by stage.
+
+The architecture strings are sampled from the reference's pools (isp_universal.py:62-101); every stage output of the
+GPU forward (segment fusion, fused stencil segments, proxies on the matrix-core kernels) is compared with the oracle's
+single-stage function applied to the GPU's previous stage output, so a one-code difference of an 8-bit classical op
+does not cascade.  Parameters are perturbed away from their initial values."""
+import numpy as np
+import pytest
+import torch
+
+import isp_oracle as O
+from conftest import assert_close
+from test_host_logic import seed_ops, weight_kind
+
+pytestmark = pytest.mark.gpu
+
+SRGB_ISP = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]          # 16-18 conditional heads: test_gpu_pointwise
+SRGB_ORIGIN = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14]
+
+
+def draw_arch(rng, origin):
+    bayer = int(rng.integers(1, 3))
+    demosaic = int(rng.integers(1, 4))                                    # 04 = DemosaicNet: absent plugin
+    pool = SRGB_ORIGIN if origin else SRGB_ISP
+    stages = [int(pool[i]) for i in rng.integers(0, len(pool), size=int(rng.integers(1, 5)))]
+    return 'Bayer_%02d_Demosaic_%02d_sRGB_%s' % (bayer, demosaic, '_'.join('%02d' % s for s in stages))
+
+
+@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('cls', ['IspUniversal', 'OriginUniversal'])
+def test_random_fixed_pipeline_matches_oracle(cls, seed):
+    from reconfigisp_amd.codes.models import networks
+    origin = cls == 'OriginUniversal'
+    rng = np.random.default_rng(1000 * origin + seed)
+    arch = draw_arch(rng, origin)
+    net = networks.define_G({'network_G': {'which_model_G': cls, 'architecture': arch, 'module_path': None,
+                                           'individual_module_paths': [None] * 8}})
+    names = O.parse_architecture(arch)
+    assert list(net.step_names) == names, arch
+    seed_ops(net.all_modules, net.step_names, 700 + 20 * seed)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for p in net.all_params:
+            if p.numel():
+                p.add_(torch.randn_like(p) * 0.3)
+    net = net.cuda().eval()
+    n, h, w = 2, 32, 40
+    bay, _ = O.synthetic_raw(n, h, w, seed=40 + seed)
+    with torch.no_grad():
+        y = net(bay.cuda())
+    assert torch.equal(y, net.intermediate_results[-1])
+    x = bay
+    for k, (name, got, raw) in enumerate(zip(names, net.intermediate_results, net.all_params)):
+        par = None if raw.numel() == 0 else torch.sigmoid(raw.detach().cpu()).repeat(n, 1)
+        got = got.cpu()
+        if origin and name in O.ORIGIN_NAMES:
+            ref = O.origin_stage(name, x, par)
+            d = (got - ref).abs()
+            assert d.max().item() <= 1.01 / 255 and (d > 1e-5).float().mean().item() < 5e-3, \
+                '%s stage %d (%s): max diff %g' % (arch, k, name, d.max().item())
+        else:
+            kind, P = weight_kind(name)
+            wts = O.make_weights(kind, 700 + 20 * seed + k, P) if kind else None
+            ref = O.apply_op(name, x, par, wts)
+            # CNN stages on random weights and anything after gamma's toe: norm-wise (tests/test_gpu_pipeline.py)
+            assert_close(got, ref, floor=1.0, rtol=5e-4, what='%s stage %d (%s)' % (arch, k, name))
+        x = got                                          # continue from the GPU result
