@@ -65,3 +65,36 @@ def test_random_fixed_pipeline_matches_oracle(cls, seed):
             # CNN stages on random weights and anything after gamma's toe: norm-wise (tests/test_gpu_pipeline.py)
             assert_close(got, ref, floor=1.0, rtol=5e-4, what='%s stage %d (%s)' % (arch, k, name))
         x = got                                          # continue from the GPU result
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_random_supernet_forward_matches_oracle(seed):
+    """The DARTS mixture with random architecture logits (several ops pruned, some slots nearly one-hot): every slot
+    output and prune count against oracle.mixed_slot fed with the GPU's previous slot output."""
+    from test_host_logic import build_supernet
+    net = build_supernet(2, 'cuda')
+    g = torch.Generator().manual_seed(50 + seed)
+    with torch.no_grad():
+        for a in net.all_alphas:
+            a.copy_((torch.randn(a.shape, generator=g) * 2.0).to(a.device))
+        for pars in net.all_params:
+            for p in pars:
+                if p.numel():
+                    p.add_((torch.randn(p.shape, generator=g) * 0.3).to(p.device))
+    n, h, w = 2, 16, 16
+    bay, _ = O.synthetic_raw(n, h, w, seed=60 + seed)
+    with torch.no_grad():
+        net(bay.cuda())
+    x = bay
+    for s, (names, pars, alpha, got) in enumerate(zip(net.slot_names, net.all_params, net.all_alphas, net.intermediate_results)):
+        al = alpha.detach().cpu().clone()
+        if 'demosaicnet' in names:
+            al[names.index('demosaicnet')] = -float('inf')    # how the build disables the op it cannot run
+        wts = []
+        for k, name in enumerate(names):
+            kind, P = weight_kind(name)
+            wts.append(O.make_weights(kind, 1000 + 100 * s + k, P) if kind else None)
+        ref, pruned = O.mixed_slot(x, names, [p.detach().cpu() for p in pars], al, wts, 0.2)
+        assert net.pruned_paths[s] == pruned, 'slot %d prune count' % s
+        assert_close(got.cpu(), ref, floor=1.0, rtol=5e-4, what='slot %d' % s)
+        x = got.cpu()
