@@ -230,6 +230,20 @@ int risp_conv2d_wgrad(const risp_conv_desc *d, const float *gy, float *dw, float
 int risp_plane_sums(const float *x, float *out, int N, int C, int c0, int nc, int HW, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Conditional modules (sRGB pool 16-18): the fully connected head, ConditionalModuleBGR._fc_forward
+ * (tools_origin.py:109-163).  hist (N, widths[0]) raw histogram counts (risp_histc; no gradient);
+ * flat: per layer an (in,out) row-major weight then a bias, then the "global" block whose FIRST entry is
+ * added to every output unit (:158-160); ReLU between layers, sigmoid at the end.
+ * acts / deltas: (N, risp_cond_fc_row_floats) scratch rows kept by the caller between forward and backward.
+ * out (N, widths[n_layers]); dflat (total_params) is fully written (deterministic, no atomics).
+ * ------------------------------------------------------------------------- */
+int risp_cond_fc_row_floats(const int *widths, int n_layers);
+int risp_cond_fc_fwd(const float *hist, const float *flat, const int *widths, int n_layers, float *acts, float *out, int N,
+                     void *stream);
+int risp_cond_fc_bwd(const float *flat, const int *widths, int n_layers, const float *acts, const float *out, const float *gout,
+                     float *deltas, float *dflat, int total_params, int N, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Overlapped tiling (utils/util_path_restore.py:47-134), NCHW on device.
  * positions: host int32 [T][2] (y,x).
  * ------------------------------------------------------------------------- */

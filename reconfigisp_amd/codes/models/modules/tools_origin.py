@@ -131,17 +131,9 @@ class ConditionalModuleBGR(nn.Module):
             raise AssertionError('expected %d conditional parameters, got %d' % (self.total_params, params.size(0)))
         if img.size(1) != 3:
             raise AssertionError('conditional modules take BGR images')
-        feat = F.hist_features(img, self.hist_bin)           # (N, 3*bins), raw counts, no gradient
-        widths, at = self.in_out_channels, 0
-        for li in range(len(widths) - 1):
-            fan_in, fan_out = widths[li], widths[li + 1]
-            weight = params[at: at + fan_in * fan_out].view(fan_in, fan_out)
-            at += fan_in * fan_out
-            feat = feat @ weight + params[at: at + fan_out]
-            at += fan_out
-            if li < len(widths) - 2:
-                feat = torch.relu(feat)
-        return torch.sigmoid(feat + params[at])
+        # histogram (raw counts, no gradient) -> MLP sliced out of the flat vector -> + the first "global" entry ->
+        # sigmoid: one HIP launch forward, two backward (risp_cond_fc_fwd / _bwd)
+        return F.conditional_fc(img, params, self.in_out_channels)
 
 
 class ConditionalGamma(ConditionalModuleBGR):

@@ -121,6 +121,41 @@ def histc01(x, bins):
     return hist
 
 
+class _CondFc(torch.autograd.Function):
+    """sigmoid(MLP(hist) + flat[global]) of the conditional heads (tools_origin.py:109-163): risp_cond_fc_fwd /
+    risp_cond_fc_bwd.  ``hist`` carries no gradient; the gradient of the flat parameter vector is fully written."""
+
+    @staticmethod
+    def forward(ctx, hist, flat, widths):
+        hist, flat = _dev(hist.detach(), 'hist'), _dev(flat, 'params')
+        n, nl = hist.shape[0], len(widths) - 1
+        cw = (C.c_int * len(widths))(*widths)
+        row = L.load().risp_cond_fc_row_floats(cw, nl)
+        acts = torch.empty((n, row), device=hist.device, dtype=torch.float32)
+        out = torch.empty((n, widths[-1]), device=hist.device, dtype=torch.float32)
+        L.call('risp_cond_fc_fwd', _p(hist), _p(flat), cw, nl, _p(acts), _p(out), n, _stream())
+        ctx.save_for_backward(flat, acts, out)
+        ctx.widths = tuple(widths)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        flat, acts, out = ctx.saved_tensors
+        widths, nl = ctx.widths, len(ctx.widths) - 1
+        cw = (C.c_int * len(widths))(*widths)
+        gout = _dev(gout, 'grad')
+        deltas = torch.empty_like(acts)
+        dflat = torch.empty_like(flat)
+        L.call('risp_cond_fc_bwd', _p(flat), cw, nl, _p(acts), _p(out), _p(gout), _p(deltas), _p(dflat), flat.numel(),
+               acts.shape[0], _stream())
+        return None, dflat, None
+
+
+def _hip_conditional_fc(img, flat, widths):
+    bins = widths[0] // 3
+    return _CondFc.apply(histc01(img, bins), flat, tuple(int(v) for v in widths))
+
+
 class _Grayworld(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -322,6 +357,10 @@ class _HipImpl:
         return histc01(x, bins)
 
     @staticmethod
+    def conditional_fc(img, flat, widths):
+        return _hip_conditional_fc(img, flat, widths)
+
+    @staticmethod
     def origin_demosaic(x, option, scales=(1.0, 1.0)):
         return _hip_origin_demosaic(x, option, scales)
 
@@ -411,6 +450,11 @@ def mix(w, outs):
 
 def hist_features(x, bins):
     return _IMPL.histc01(x, bins)
+
+
+def conditional_fc(img, flat, widths):
+    """(N, widths[-1]) = sigmoid(MLP(per-channel histograms of img) + flat[global]); widths = (3*bins, ..., out)."""
+    return _IMPL.conditional_fc(img, flat, widths)
 
 
 def srcnn_res(x, pv, module):

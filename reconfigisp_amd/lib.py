@@ -71,6 +71,9 @@ SIGNATURES = {
     'risp_conv_wgrad_scratch_floats': (_z, [_i]),
     'risp_conv2d_wgrad': (_i, [C.POINTER(ConvDesc), _f, _f, _f, _s]),
     'risp_plane_sums': (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
+    'risp_cond_fc_row_floats': (_i, [C.POINTER(C.c_int), _i]),
+    'risp_cond_fc_fwd': (_i, [_f, _f, C.POINTER(C.c_int), _i, _f, _f, _i, _s]),
+    'risp_cond_fc_bwd': (_i, [_f, C.POINTER(C.c_int), _i, _f, _f, _f, _f, _f, _i, _i, _s]),
     'risp_tile_gather': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _s]),
     'risp_tile_blend': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     'risp_origin_demosaic': (_i, [_f, _f, _i, _i, _i, _i, _fl, _fl, _s]),

@@ -18,6 +18,7 @@ class OracleImpl:
     gtm_manual = staticmethod(O.gtm_manual)
     wb_quadratic = staticmethod(O.wb_quadratic)
     grayworld = staticmethod(lambda x, p=None: O.grayworld(x))
+    conditional_fc = staticmethod(lambda img, flat, widths: O.conditional_fc(img, flat, tuple(widths[:-1]), widths[-1]))
     demosaic_nearest = staticmethod(lambda x, p=None: O.demosaic_nearest(x))
 
     @staticmethod

@@ -148,3 +148,37 @@ def test_mix_fwd_bwd(F):
 def test_cpu_tensor_raises(F):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         F.gamma(torch.rand(1, 3, 4, 4), torch.rand(1, 1))
+
+
+@pytest.mark.parametrize('widths', [(12, 8, 1), (24, 8, 30), (30, 16, 7, 3), (96, 3)])
+def test_conditional_head_mlp_forward_and_parameter_gradient(widths):
+    """risp_cond_fc_fwd / _bwd (histogram -> MLP sliced from one flat vector -> + global scalar -> sigmoid) against
+    the oracle's restatement of tools_origin.py:109-163, forward and d/d(flat)."""
+    import reconfigisp_amd.functional as F
+    import isp_oracle as O
+    n = 3
+    g = torch.Generator().manual_seed(len(widths) * 100 + widths[0])
+    img = torch.rand(n, 3, 16, 20, generator=g)
+    total = O.conditional_total_params(widths[:-1], widths[-1])
+    flat = (torch.randn(total, generator=g) * 0.05)
+    flat[-widths[-1]:] = torch.randn(widths[-1], generator=g)          # the "global" block: only its first entry counts
+    gout = torch.randn(n, widths[-1], generator=g)
+    ref_flat = flat.clone().requires_grad_(True)
+    ref = O.conditional_fc(img, ref_flat, tuple(widths[:-1]), widths[-1])
+    ref.backward(gout)
+    dev_flat = flat.clone().cuda().requires_grad_(True)
+    got = F.conditional_fc(img.cuda(), dev_flat, widths)
+    got.backward(gout.cuda())
+    assert_close(got.detach(), ref.detach(), what='head output')
+    assert_close(dev_flat.grad, ref_flat.grad, rtol=2e-4, what='d/d flat')
+    assert torch.count_nonzero(dev_flat.grad[-widths[-1] + 1:]) == 0 or widths[-1] == 1   # unused tail of the global block
+
+
+def test_conditional_head_matches_reference_golden():
+    import reconfigisp_amd.functional as F
+    g = load_golden('conditional')
+    x = torch.from_numpy(np.asarray(g['x'])).cuda()
+    for tag, nout in (('gamma', 1), ('wbm', 3), ('wbq', 30)):
+        inch = tuple(int(v) for v in g[tag + '_inch'])
+        flat = torch.from_numpy(np.asarray(g[tag + '_flat'])).cuda()
+        assert_close(F.conditional_fc(x, flat, inch + (nout,)), g[tag + '_fc'], what=tag)
