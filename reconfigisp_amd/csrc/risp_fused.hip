@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, RISP_FUSED_WAVES) void bilateral_chain_kernel(
     r = r < 0 ? 0 : (r > R ? R : r);                   // never walk outside the staged halo
     const bool full = RT > 0 && r == RT;               // wave-uniform: unrolled window, LDS reads shared by the 4 pixels
     const float ks = -1.f / (2.f * a.sig_s[n] * a.sig_s[n]), kc = -1.f / (2.f * a.sig_c[n] * a.sig_c[n]);
+    const float ks2 = ks * 1.4426950408889634f, kc2 = kc * 1.4426950408889634f;     // base-2 exponent coefficients
     f3 pix[PXT];
 #pragma unroll
     for (int i = 0; i < PXT; ++i) {
@@ -189,8 +190,11 @@ __global__ __launch_bounds__(256, RISP_FUSED_WAVES) void bilateral_chain_kernel(
             const float *q = c0 + dy * tw + dx;
             const float qb = q[0] * 255.f, qg = q[per] * 255.f, qr = q[2 * per] * 255.f;
             const float dist = fabsf(qb - cb) + fabsf(qg - cg) + fabsf(qr - cr);
-            const float wgt = __expf((float)(dy * dy + dx * dx) * ks + dist * dist * kc);
-            nb += wgt * qb; ng += wgt * qg; nr += wgt * qr; den += wgt;
+            // exp(-|d|^2 / 2 sigma_s^2 - dist^2 / 2 sigma_c^2) as one fma feeding v_exp_f32 (log2 e folded into the two
+            // coefficients) and fma accumulation: 5 vector instructions per tap fewer than the mul / add form
+            // (measured -4 % launch time); bilateral_kernel of risp_origin.hip evaluates the same expressions.
+            const float wgt = __builtin_amdgcn_exp2f(__builtin_fmaf(dist * dist, kc2, (float)(dy * dy + dx * dx) * ks2));
+            nb = __builtin_fmaf(wgt, qb, nb); ng = __builtin_fmaf(wgt, qg, ng); nr = __builtin_fmaf(wgt, qr, nr); den += wgt;
         };
         if (full) {
 #pragma unroll

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
     int r = win[n] / 2;
     r = r < 0 ? 0 : (r > R ? R : r);                   // never walk outside the staged halo
     const float ks = -1.f / (2.f * sig_s[n] * sig_s[n]), kc = -1.f / (2.f * sig_c[n] * sig_c[n]);
+    const float ks2 = ks * 1.4426950408889634f, kc2 = kc * 1.4426950408889634f;     // base-2 exponent coefficients
     const float *ctr = lds + (ly + R) * tw + lx + R;
     const float cb = ctr[0], cg = ctr[per], cr = ctr[2 * per];
     float nb = 0.f, ng = 0.f, nr = 0.f, den = 0.f;
@@ -108,8 +109,9 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
                 continue;
             }
             const float dist = fabsf(qb - cb) + fabsf(qg - cg) + fabsf(qr - cr);
-            const float wgt = __expf((float)(dy * dy + dx * dx) * ks + dist * dist * kc);
-            nb += wgt * qb; ng += wgt * qg; nr += wgt * qr; den += wgt;
+            // same expressions as the fused segment kernel (risp_fused.hip): base-2 exponent by one fma, fma sums
+            const float wgt = __builtin_amdgcn_exp2f(__builtin_fmaf(dist * dist, kc2, (float)(dy * dy + dx * dx) * ks2));
+            nb = __builtin_fmaf(wgt, qb, nb); ng = __builtin_fmaf(wgt, qg, ng); nr = __builtin_fmaf(wgt, qr, nr); den += wgt;
         }
     const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)py * W + px;
     const float rden = 1.f / den;                       // OPSPEC: normalise by one reciprocal, not three divisions
