@@ -51,7 +51,7 @@ __device__ __forceinline__ float q8f(float v) {
 
 // RT: compile-time halo radius (1 = the 3x3 window every reference configuration produces, because
 // `.int()` precedes `*7` at tools_origin.py:698); 0 = run-time radius a.R.
-template <bool FROM_BAYER, int RT>
+template <bool FROM_BAYER, int RT, bool WBQ>
 #ifndef RISP_FUSED_WAVES
 #define RISP_FUSED_WAVES 1
 #endif
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, RISP_FUSED_WAVES) void bilateral_chain_kernel(
 
     // ---- element-wise stages
     for (int k = 0; k < a.n_ops; ++k) {
-        apply_op<PXT>(a.ops[k], a.params[k], n, pix);
+        apply_op<PXT, WBQ>(a.ops[k], a.params[k], n, pix);
         if (a.outs[k]) store(a.outs[k], k < a.last_out);
     }
 }
@@ -283,13 +283,24 @@ int risp_bilateral_chain_fwd(const float *in, int from_bayer, float *out_demosai
     const size_t lds = sizeof(float) * 3 * (FX + 2 * a.R) * (FY + 2 * a.R);
     dim3 grid((W + FX - 1) / FX, (H + FY - 1) / FY, N);
     hipStream_t s = (hipStream_t)stream;
+    bool wbq = false;
+    for (int k = 0; k < n_ops; ++k) wbq |= a.ops[k] == RISP_OP_WB_QUADRATIC;
+#ifdef RISP_CHAIN_ALWAYS_WBQ
+    wbq = true;
+#endif
+#define RISP_FUSED_LAUNCH(FB, RTV)                                                                            \
+    do {                                                                                                      \
+        if (wbq) hipLaunchKernelGGL((bilateral_chain_kernel<FB, RTV, true>), grid, dim3(256), lds, s, a);     \
+        else hipLaunchKernelGGL((bilateral_chain_kernel<FB, RTV, false>), grid, dim3(256), lds, s, a);        \
+    } while (0)
     if (a.R == 1) {
-        if (from_bayer) hipLaunchKernelGGL((bilateral_chain_kernel<true, 1>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((bilateral_chain_kernel<false, 1>), grid, dim3(256), lds, s, a);
+        if (from_bayer) RISP_FUSED_LAUNCH(true, 1);
+        else RISP_FUSED_LAUNCH(false, 1);
     } else {
-        if (from_bayer) hipLaunchKernelGGL((bilateral_chain_kernel<true, 0>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((bilateral_chain_kernel<false, 0>), grid, dim3(256), lds, s, a);
+        if (from_bayer) RISP_FUSED_LAUNCH(true, 0);
+        else RISP_FUSED_LAUNCH(false, 0);
     }
+#undef RISP_FUSED_LAUNCH
     RISP_LAUNCH_CHECK("risp_bilateral_chain_fwd");
     return 0;
 }

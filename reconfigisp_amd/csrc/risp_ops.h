@@ -183,14 +183,18 @@ __device__ __forceinline__ void apply_all(const float *p, int n, f3 *px) {
     for (int i = 0; i < NPX; ++i) px[i] = ctx.fwd(px[i]);
 }
 
-// one element-wise stage (RISP_OP_*) on NPX pixels held in registers; op is wave-uniform
-template <int NPX>
+// one element-wise stage (RISP_OP_*) on NPX pixels held in registers; op is wave-uniform.  WBQ = false compiles the
+// 30-coefficient WbQuadratic out: its live range alone sets the register count (and so the occupancy) of a kernel
+// that contains it, so launchers pick the lean instantiation whenever the op list has no WbQuadratic.
+template <int NPX, bool WBQ = true>
 __device__ __forceinline__ void apply_op(int op, const float *p, int n, f3 *px) {
     switch (op) {
         case RISP_OP_WB_MANUAL: apply_all<WbManualCtx, NPX>(p, n, px); break;
         case RISP_OP_GAMMA: apply_all<GammaCtx, NPX>(p, n, px); break;
         case RISP_OP_GTM_MANUAL: apply_all<GtmCtx, NPX>(p, n, px); break;
-        case RISP_OP_WB_QUADRATIC: apply_all<WbqCtx, NPX>(p, n, px); break;
+        case RISP_OP_WB_QUADRATIC:
+            if constexpr (WBQ) apply_all<WbqCtx, NPX>(p, n, px);
+            break;
         case RISP_OP_GAIN3: apply_all<Gain3Ctx, NPX>(p, n, px); break;
         default: break;  // SKIP, DEMOSAIC_NEAREST (applied at load)
     }

@@ -176,7 +176,7 @@ struct ChainArgs {
     float *outs[RISP_MAX_CHAIN];
 };
 
-template <int QW>
+template <int QW, bool WBQ>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     const int n = blockIdx.y, W = a.W, H = a.H, wq = W / (2 * QW);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     for (int k = k0; k < a.n_ops; ++k) {
         const int op = a.ops[k];
         const float *p = a.params[k];
-        apply_op<4 * QW>(op, p, n, &px[0][0]);
+        apply_op<4 * QW, WBQ>(op, p, n, &px[0][0]);
         float *o = a.outs[k];
         if (o == nullptr) continue;
 #pragma unroll
@@ -272,10 +272,19 @@ static int chain_launch(const ChainArgs &a, void *stream) {
     const bool wide = (a.W % 4 == 0);
     const int nq = (a.W / (wide ? 4 : 2)) * (a.H / 2);
     dim3 grid((nq + 255) / 256, a.N), block(256);
-    if (wide)
-        hipLaunchKernelGGL(chain_kernel<2>, grid, block, 0, (hipStream_t)stream, a);
+    bool wbq = false;
+    for (int k = 0; k < a.n_ops; ++k) wbq |= a.ops[k] == RISP_OP_WB_QUADRATIC;
+#ifdef RISP_CHAIN_ALWAYS_WBQ
+    wbq = true;
+#endif
+    if (wide && wbq)
+        hipLaunchKernelGGL((chain_kernel<2, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (wide)
+        hipLaunchKernelGGL((chain_kernel<2, false>), grid, block, 0, (hipStream_t)stream, a);
+    else if (wbq)
+        hipLaunchKernelGGL((chain_kernel<1, true>), grid, block, 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(chain_kernel<1>, grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((chain_kernel<1, false>), grid, block, 0, (hipStream_t)stream, a);
     RISP_LAUNCH_CHECK("risp_chain_fwd");
     return 0;
 }
