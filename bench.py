@@ -3,7 +3,7 @@
 (BASELINE.json metric), one process per GPU, batch sharded across ranks (weak scaling, no
 data-path collective: every image is independent).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one forward of the pipeline over one batch of 64 synthetic 256x256 RGGB patches that is
@@ -58,6 +58,11 @@ def build_pipeline(arch, device, which='IspUniversal'):
 
 
 def timed(fn, steps, warmup, device, world):
+    # The cyclic GC is collected once BEFORE the warm-up and paused until the timed region ends (as timeit does): a
+    # collection of this process's heap is a ~40 ms host stall, and 40 ms of idle GPU right before the timed region
+    # drops the device into its low-power clocks, which the first ~2 ms of timed launches then pay for.
+    gc.collect()
+    gc.disable()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize(device)
@@ -65,8 +70,6 @@ def timed(fn, steps, warmup, device, world):
         dist.barrier()
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    gc.collect()
-    gc.disable()                # as timeit does: no cyclic-GC pause (tens of ms on a torch-sized heap) inside the timed region
     t0 = time.perf_counter()
     ev0.record()
     marks = []
@@ -177,8 +180,10 @@ def cpu_baseline(bay, arch, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=2000,
+                    help='timed steps (default 2000 = ~0.1 s: right after an idle period the device spends some 100 '
+                         'launches in a boost-then-clamp power transient, tools/diag_ramp.py)')
+    ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--batch', type=int, default=64, help='patches per GPU per step')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--launch', choices=('stream', 'graph'), default='stream',
