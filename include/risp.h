@@ -188,6 +188,11 @@ int risp_conv2d(const risp_conv_desc *d, void *stream);
 int risp_conv_small_cout_pad(int cout);
 size_t risp_conv_small_wpack_floats(int cin, int cout, int ksize);
 int risp_conv2d_small(const risp_conv_desc *d, void *stream);
+/* Small grids (the per-GPU batch of the 8-GPU search is 4 images): the input channels are split over `groups`
+ * workgroups per tile, partial sums go to scratch (groups * N * cout * H * W floats) and a second launch adds them
+ * in index order and applies the epilogue (deterministic).  risp_conv_small_groups: the split worth using (1 = none). */
+int risp_conv_small_groups(const risp_conv_desc *d);
+int risp_conv2d_small_split(const risp_conv_desc *d, float *scratch, int groups, void *stream);
 
 /* The same operator for 3x3 layers with a one-dimensional Winograd transform F(2,3) along x (2/3 of the matrix-core
  * work of risp_conv2d; Path-Restore's 64->64 layers, path_14l_bayer_arch.py:6-21).  wpack: [chunk of risp_conv_wino3_chunk()

@@ -156,7 +156,12 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
-    L.call('risp_conv2d_small', C.byref(d), _stream())
+    groups = L.load().risp_conv_small_groups(C.byref(d))
+    if groups > 1:                                  # small grid: split the input channels over several workgroups per tile
+        scratch = torch.empty((groups,) + tuple(out.shape), device=x.device, dtype=torch.float32)
+        L.call('risp_conv2d_small_split', C.byref(d), _p(scratch), groups, _stream())
+    else:
+        L.call('risp_conv2d_small', C.byref(d), _stream())
     return out
 
 

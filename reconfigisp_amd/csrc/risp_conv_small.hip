@@ -33,11 +33,15 @@ template <int KS> struct SmallCfg { static constexpr int CCH = KS == 9 ? 3 : 4; 
 // SPY = output rows per thread: 2 (64 x 32 tiles) when the grid fills the chip, 1 (64 x 16 tiles, twice the
 // workgroups) for small batches - the per-GPU batch of the 8-GPU search is 4 images.
 template <int KS, int NP, int SPY>
-__global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d) {
+__global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d, int groups, float *__restrict__ partial) {
     constexpr int SY = 16 * SPY;
     constexpr int P = KS / 2, TH_ = SY + 2 * P, CCH = SmallCfg<KS>::CCH, ROWV = STW / 4;
     extern __shared__ float4 lds4[];                       // [CCH][TH_][STW]
-    const int tid = threadIdx.x, n = blockIdx.z, x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
+    // groups > 1 (small grids): the input channels are split over `groups` workgroups per tile, each writes its raw
+    // partial sums to `partial` [group][N][cout][H][W] and small_reduce_kernel finishes (fixed order: deterministic)
+    const int tid = threadIdx.x, n = blockIdx.z / groups, grp = blockIdx.z - n * groups;
+    const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
+    const int cpg = (d.cin + groups - 1) / groups, cbeg = grp * cpg, cend = (cbeg + cpg < d.cin) ? cbeg + cpg : d.cin;
     const int lx = (tid & 15) * SPX, ly = (tid >> 4) * SPY;
     const int H = d.H, W = d.W, cin = d.cin;
     const size_t plane = (size_t)H * W;
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
             const int c = idx / (TH_ * ROWV), rem = idx - c * (TH_ * ROWV);
             const int ty = rem / ROWV, v = rem - ty * ROWV;
             const int gy = y0 - P + ty, gx = x0 - HPAD + 4 * v, ci = c0 + c;
-            const bool row_ok = idx < CCH * TH_ * ROWV && ci < cin && gy >= 0 && gy < H;
+            const bool row_ok = idx < CCH * TH_ * ROWV && ci < cend && gy >= 0 && gy < H;
             const float *src = xin + (size_t)(row_ok ? ci : 0) * plane + (size_t)(row_ok ? gy : 0) * W;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
             if (vecw) {                                    // W % 4 == 0: the float4 is entirely in or out
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
     // SPY == 1 (small grids, few waves per CU, half the accumulators): the loads of stage s+1 are issued before the
     // FMAs of stage s, so their latency does not sit between barriers.
     constexpr bool PIPE = SPY == 1;
-    if (PIPE) fetch(0);
-    for (int c0 = 0; c0 < cin; c0 += CCH) {
+    if (PIPE) fetch(cbeg);
+    for (int c0 = cbeg; c0 < cend; c0 += CCH) {
         if (!PIPE) fetch(c0);
         __syncthreads();                                   // the previous stage has been consumed
 #pragma unroll
@@ -91,8 +95,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
             if (idx < CCH * TH_ * ROWV) lds4[idx] = pf[it];
         }
         __syncthreads();
-        if (PIPE && c0 + CCH < cin) fetch(c0 + CCH);
-        const int cn = cin - c0 < CCH ? cin - c0 : CCH;
+        if (PIPE && c0 + CCH < cend) fetch(c0 + CCH);
+        const int cn = cend - c0 < CCH ? cend - c0 : CCH;
         for (int c = 0; c < cn; ++c) {
             const f32x2 *wch = wp + (size_t)(c0 + c) * KS * KS * NP;               // wave-uniform -> scalar loads
 #pragma unroll
@@ -126,6 +130,24 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d)
     const int ox = x0 + lx, epi = d.epilogue;
     if (ox >= W) return;
     const bool full = vecw || ox + SPX <= W;
+    if (groups > 1) {                           // raw partial sums of this channel group
+#pragma unroll
+        for (int o = 0; o < SPY; ++o) {
+            const int oy = y0 + ly + o;
+            if (oy < H) {
+#pragma unroll
+                for (int co = 0; co < 2 * NP; ++co) {
+                    if (co < d.cout) {
+                        float *pp = partial + (((size_t)grp * d.N + n) * d.cout + co) * plane + (size_t)oy * W + ox;
+#pragma unroll
+                        for (int p = 0; p < SPX; ++p)
+                            if (full || ox + p < W) pp[p] = co & 1 ? acc[o][p][co >> 1].y : acc[o][p][co >> 1].x;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (epi & RISP_EPI_SHUFFLE2) {          // PixelShuffle(2): (N,4G,H,W) -> (N,G,2H,2W), cout pair 2g+i = row i of group g
         const int groups = d.cout >> 2;
 #pragma unroll
@@ -274,16 +296,39 @@ __global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict_
     if (tid < K * K) out[(size_t)blockIdx.x * K * K + tid] = sums[tid / K][tid % K];
 }
 
+// y = epilogue(sum over channel groups of the partial sums), the groups added in index order
+__global__ __launch_bounds__(256) void small_reduce_kernel(const risp_conv_desc d, int groups, const float *__restrict__ partial) {
+    const size_t plane = (size_t)d.H * d.W, total = (size_t)d.N * d.cout * plane;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)((i / plane) % d.cout);
+    const size_t n = i / (plane * d.cout), pix = i % plane;
+    float v = partial[i];
+    for (int g = 1; g < groups; ++g) v += partial[(size_t)g * total + i];
+    const int epi = d.epilogue;
+    if (!(epi & RISP_EPI_NOBIAS)) v += d.bias[co];
+    if ((epi & RISP_EPI_ADD) && co < d.add_c) v += d.add[(n * d.add_c + co) * plane + pix];
+    if (epi & RISP_EPI_RELU) v = v > 0.f ? v : 0.f;
+    if (epi & RISP_EPI_MASK) v = d.mask[i] > 0.f ? v : 0.f;
+    d.y[i] = v;
+}
+
 template <int KS, int NP>
-int launch_small(const risp_conv_desc &d, hipStream_t s) {
+int launch_small(const risp_conv_desc &d, float *scratch, int groups, hipStream_t s) {
     constexpr int P = KS / 2;
     const int tiles_x = (d.W + SX - 1) / SX;
-    if ((size_t)tiles_x * ((d.H + 31) / 32) * d.N >= 384) {            // enough 64 x 32 tiles for every CU
+    if (groups <= 1 && (size_t)tiles_x * ((d.H + 31) / 32) * d.N >= 384) {          // enough 64 x 32 tiles for every CU
         const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (32 + 2 * P) * STW;
-        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N), dim3(256), lds, s, d);
+        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N), dim3(256), lds, s, d, 1, nullptr);
     } else {
+        if (groups < 1) groups = 1;
         const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (16 + 2 * P) * STW;
-        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 1>), dim3(tiles_x, (d.H + 15) / 16, d.N), dim3(256), lds, s, d);
+        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 1>), dim3(tiles_x, (d.H + 15) / 16, d.N * groups), dim3(256), lds, s, d, groups,
+                           scratch);
+        if (groups > 1) {
+            const size_t total = (size_t)d.N * d.cout * d.H * d.W;
+            hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d, groups, scratch);
+        }
     }
     RISP_LAUNCH_CHECK("risp_conv2d_small");
     return 0;
@@ -299,8 +344,31 @@ size_t risp_conv_small_wpack_floats(int cin, int cout, int ksize) {
     return (size_t)cin * ksize * ksize * risp_conv_small_cout_pad(cout);
 }
 
-int risp_conv2d_small(const risp_conv_desc *dp, void *stream) {
+// Channel groups worth using for this layer on this grid (1 = none): small grids with many input channels, where one
+// workgroup per tile leaves most of the chip idle and a lone wave per SIMD cannot hide its scalar-load latency.
+int risp_conv_small_groups(const risp_conv_desc *dp) {
+    if (!dp || dp->cin < 32 || (dp->epilogue & RISP_EPI_SHUFFLE2)) return 1;
+    const size_t tiles = (size_t)((dp->W + SX - 1) / SX) * ((dp->H + 15) / 16) * dp->N;
+    if (tiles >= 768) return 1;
+    int g = (int)(1024 / (tiles ? tiles : 1));
+    if (g > 4) g = 4;
+    while (g > 1 && dp->cin / g < 8) --g;
+    return g < 1 ? 1 : g;
+}
+
+static int conv2d_small_impl(const risp_conv_desc *dp, float *scratch, int groups, void *stream);
+
+int risp_conv2d_small(const risp_conv_desc *dp, void *stream) { return conv2d_small_impl(dp, nullptr, 1, stream); }
+
+/* scratch: groups * N * cout * H * W floats, groups = risp_conv_small_groups(d) (or fewer); groups <= 1 ignores it */
+int risp_conv2d_small_split(const risp_conv_desc *dp, float *scratch, int groups, void *stream) {
+    return conv2d_small_impl(dp, scratch, groups, stream);
+}
+
+static int conv2d_small_impl(const risp_conv_desc *dp, float *scratch, int groups, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_small: null descriptor");
+    RISP_CHECK_ARG(groups <= 1 || (scratch && groups <= 16 && !(dp->epilogue & RISP_EPI_SHUFFLE2) && (size_t)dp->N * groups <= 65535),
+                   "risp_conv2d_small_split: %d groups need a scratch buffer, no PixelShuffle store and N * groups <= 65535", groups);
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_small: null tensor");
     RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 12,
@@ -317,12 +385,12 @@ int risp_conv2d_small(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG((reinterpret_cast<uintptr_t>(d.wpack) & 15) == 0, "risp_conv2d_small: wpack must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (d.cout <= 4) {
-        if (d.ksize == 3) return launch_small<3, 2>(d, s);
-        if (d.ksize == 5) return launch_small<5, 2>(d, s);
-        if (d.ksize == 9) return launch_small<9, 2>(d, s);
+        if (d.ksize == 3) return launch_small<3, 2>(d, scratch, groups, s);
+        if (d.ksize == 5) return launch_small<5, 2>(d, scratch, groups, s);
+        if (d.ksize == 9) return launch_small<9, 2>(d, scratch, groups, s);
     } else {
-        if (d.ksize == 3) return launch_small<3, 6>(d, s);
-        if (d.ksize == 5) return launch_small<5, 6>(d, s);
+        if (d.ksize == 3) return launch_small<3, 6>(d, scratch, groups, s);
+        if (d.ksize == 5) return launch_small<5, 6>(d, scratch, groups, s);
     }
     risp_set_error("risp_conv2d_small: unsupported kernel size %d", d.ksize);
     return 1;
