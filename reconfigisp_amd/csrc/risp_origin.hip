@@ -208,6 +208,11 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float b = e[k] * si / 255.f, g = e[4 + k] * si / 255.f, r = e[8 + k] * si / 255.f;
+            if (MODE != TM_GAIN) {               // OPSPEC: the tone curves take max(sample, 0) - an upstream stage (a CNN
+                b = fmaxf(b, 0.f);               // proxy, an unclipped gain) can hand over negative samples, for which
+                g = fmaxf(g, 0.f);               // the log-average luminance and Hable's rational curve are undefined
+                r = fmaxf(r, 0.f);
+            }
             if (MODE == TM_REINHARD) {           // p0 = key / log-average luminance, p1 = 1 / Lwhite^2
                 const float L = 0.114f * b + 0.587f * g + 0.299f * r;
                 const float ls = p0 * L;
@@ -236,7 +241,8 @@ __global__ __launch_bounds__(256) void loglum_kernel(const float *__restrict__ x
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
         const float4 b = xb[i], g = xb[hw4 + i], r = xb[2 * hw4 + i];
         auto L = [si](float bb, float gg, float rr) {
-            return __logf((0.114f * (bb * si) + 0.587f * (gg * si) + 0.299f * (rr * si)) / 255.f + 1e-4f);
+            bb = fmaxf(bb * si, 0.f); gg = fmaxf(gg * si, 0.f); rr = fmaxf(rr * si, 0.f);     // as tonemap_kernel
+            return __logf((0.114f * bb + 0.587f * gg + 0.299f * rr) / 255.f + 1e-4f);
         };
         acc[0] += (L(b.x, g.x, r.x) + L(b.y, g.y, r.y)) + (L(b.z, g.z, r.z) + L(b.w, g.w, r.w));
     }
