@@ -267,3 +267,45 @@ def test_inference_dispatch_f43(cin, cout, hw):
                      torch.relu(lin + add), what='add+relu infer=%s' % infer)
         assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_MASK, mask=mask, infer=infer), lin * (mask > 0),
                      what='mask infer=%s' % infer)
+
+
+# ---------------------------------------------------------------------------------------------------
+# randomized layer shapes through the dispatching wrappers (direct / F(2,3) / F(4,3) / F(2,5) / small-cout kernels)
+import os
+_FUZZ = int(os.environ.get('RISP_TEST_SEEDS', '8')) * 6            # soak runs: RISP_TEST_SEEDS=64
+
+
+@pytest.mark.parametrize('seed', range(_FUZZ))
+def test_random_layer_shapes(seed):
+    from reconfigisp_amd import convnets as CN
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.choice([1, 3, 3, 5, 5, 9]))
+    cin, cout = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+    n, h = int(rng.integers(1, 4)), int(rng.integers(max(2, k // 2 + 1), 72))
+    w = int(rng.integers(max(2, k // 2 + 1), 150))
+    if rng.random() < 0.6:
+        w = max(4, w // 4 * 4)                                       # the vector paths need W % 4 == 0
+    wt, b = rnd(cout, cin, k, k, seed=seed) * (0.5 / k), rnd(cout, seed=seed + 1) * 0.1
+    x = rnd(n, cin, h, w, seed=seed + 2)
+    add, mask = rnd(n, cout, h, w, seed=seed + 3), rnd(n, cout, h, w, seed=seed + 4)
+    pc = CN.PackedConv(wt, b)
+    lin = TF.conv2d(x, wt, b, padding=k // 2)
+    tag = 'k%d %d->%d N%d %dx%d' % (k, cin, cout, n, h, w)
+    mode = int(rng.integers(0, 4))
+    for infer in (False, True):
+        if mode == 0:
+            got, ref = CN.conv(x, pc, n, h, w, infer=infer), lin
+        elif mode == 1:
+            got, ref = CN.conv(x, pc, n, h, w, epi=CN.EPI_RELU, infer=infer), torch.relu(lin)
+        elif mode == 2:
+            got, ref = CN.conv(x, pc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=cout, infer=infer), torch.relu(lin + add)
+        else:
+            got, ref = CN.conv(x, pc, n, h, w, epi=CN.EPI_MASK, mask=mask, infer=infer), lin * (mask > 0)
+        assert_close(got, ref, what='%s mode %d infer=%s' % (tag, mode, infer))
+    gy = rnd(n, cout, h, w, seed=seed + 5)
+    gref = TF.conv_transpose2d(gy, wt, padding=k // 2)
+    addb, maskb = rnd(n, cin, h, w, seed=seed + 6), rnd(n, cin, h, w, seed=seed + 7)
+    got = CN.conv(gy, pc, n, h, w, transpose=True, epi=CN.EPI_ADD | CN.EPI_MASK, add=addb, add_c=cin, mask=maskb)
+    assert_close(got, (gref + addb) * (maskb > 0), what=tag + ' bwd-data add+mask')
+    if cout <= 12 and k in (3, 5) or cout <= 4 and k == 9:
+        assert_close(CN.conv_small(x, CN.SmallConv(wt, b), n, h, w, epi=CN.EPI_RELU), torch.relu(lin), what=tag + ' small')
