@@ -200,3 +200,24 @@ def test_train_ft_driver_with_finetuning(tmp_path, monkeypatch, capsys):
     assert out.count('proxy nets fine-tuned!') == 2
     saved = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / 'exp' / 'models' / '4_*.pth')))
     assert saved == ['4_G.pth', '4_bilateral.pth', '4_crysisengine.pth', '4_fastnlm.pth', '4_median.pth', '4_whiteworld.pth']
+
+
+_FUZZ = int(os.environ.get('RISP_TEST_SEEDS', '8'))               # soak runs: RISP_TEST_SEEDS=64
+
+
+@pytest.mark.parametrize('seed', range(_FUZZ))
+def test_random_tiling_geometry_matches_oracle(seed):
+    """Random frame / patch / stride geometry (including patches as large as the frame and stride == patch): tile
+    positions bit-exact, gather exact, blend within 1e-6 of the oracle's restatement of util_path_restore.py."""
+    from reconfigisp_amd.codes.utils import util_path_restore as U
+    rng = np.random.default_rng(500 + seed)
+    H, W = int(rng.integers(24, 200)), int(rng.integers(24, 260))
+    ph, pw = int(rng.integers(8, H + 1)), int(rng.integers(8, W + 1))
+    sh, sw = int(rng.integers(max(1, ph // 2), ph + 1)), int(rng.integers(max(1, pw // 2), pw + 1))
+    img = rng.random((H, W, 3), dtype=np.float32)
+    p_ref, q_ref, c_ref = O.whole2patch(img, (ph, pw), (sh, sw))
+    p, q, c = U.whole2patch(img, (ph, pw), (sh, sw))
+    assert np.array_equal(q, q_ref) and np.array_equal(p, p_ref) and np.array_equal(c, c_ref)
+    proc = p * 0.75 + 0.1
+    assert_close(U.patch2whole(proc, q, c, (sh, sw)), O.patch2whole(proc, q_ref, c_ref, (sh, sw)), rtol=1e-6,
+                 what='blend H%d W%d patch %dx%d stride %dx%d' % (H, W, ph, pw, sh, sw))
