@@ -63,6 +63,19 @@ def timed(fn, steps, warmup, device, world):
     # drops the device into its low-power clocks, which the first ~2 ms of timed launches then pay for.
     gc.collect()
     gc.disable()
+    # Spin-up (untimed, before the W warm-up steps): ~50 ms of the same work issued WITHOUT intermediate synchronisation.
+    # After an idle period - and while launches are interleaved with host synchronisations - the device runs slower for a
+    # few hundred launches (tools/diag_ramp.py, diag_ramp2.py: 46 -> 60 us per step); without this a short timed window
+    # (K = 200) measures that transient, not the throughput.
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_a.record()
+    for _ in range(3):
+        fn()
+    ev_b.record()
+    ev_b.synchronize()
+    est_ms = max(ev_a.elapsed_time(ev_b) / 3, 1e-3)
+    for _ in range(min(4000, int(50.0 / est_ms) + 1)):
+        fn()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize(device)

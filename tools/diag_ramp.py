@@ -11,8 +11,9 @@ bs = [make_batch(64, 256, 256, seed=100 + k)[0].cuda() for k in range(4)]
 import gc
 gc.collect(); gc.disable()
 with torch.no_grad():
-    for idle_ms in (0, 0, 5, 50):
-        for k in range(40): net(bs[k % 4])
+    for idle_ms in (0, 0, 0, 0, 5, 0, 50, 0):
+        if idle_ms: 
+            for k in range(40): net(bs[k % 4])
         torch.cuda.synchronize()
         time.sleep(idle_ms / 1e3)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
