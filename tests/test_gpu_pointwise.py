@@ -182,3 +182,50 @@ def test_conditional_head_matches_reference_golden():
         inch = tuple(int(v) for v in g[tag + '_inch'])
         flat = torch.from_numpy(np.asarray(g[tag + '_flat'])).cuda()
         assert_close(F.conditional_fc(x, flat, inch + (nout,)), g[tag + '_fc'], what=tag)
+
+
+import os
+_FUZZ = int(os.environ.get('RISP_TEST_SEEDS', '8'))               # soak runs: RISP_TEST_SEEDS=64
+
+
+@pytest.mark.parametrize('seed', range(_FUZZ))
+def test_random_reductions(seed):
+    """Random shapes / value ranges for the reduction kernels: channel statistics (ties included), histograms with
+    torch.histc semantics (values outside [0,1] dropped, exactly 1.0 in the last bin), the slot mixture and its
+    gradients, the truncating uint8 PSNR."""
+    import reconfigisp_amd.functional as F
+    from reconfigisp_amd.codes.utils import util
+    rng = np.random.default_rng(800 + seed)
+    n, c = int(rng.integers(1, 5)), 3
+    h, w = int(rng.integers(2, 60)), 4 * int(rng.integers(1, 40))
+    x = torch.from_numpy(rng.uniform(-0.3, 1.3, size=(n, c, h, w)).astype(np.float32))
+    x.view(-1)[rng.integers(0, x.numel(), size=6)] = 1.0            # exact upper edge
+    x.view(-1)[rng.integers(0, x.numel(), size=6)] = 0.0
+    ties = x.view(n, c, -1)
+    ties[0, 0, rng.integers(0, h * w, size=3)] = -0.5                # tied minimum: the first index wins
+    stats, arg = F.channel_stats(x.cuda())
+    flat = x.view(n, c, -1)
+    assert torch.equal(stats[..., 0].cpu(), flat.min(dim=2)[0]) and torch.equal(stats[..., 2].cpu(), flat.max(dim=2)[0])
+    assert_close(stats[..., 1], flat.sum(dim=2), rtol=1e-5, what='sum')
+    first_min = (flat == flat.min(dim=2, keepdim=True)[0]).float().argmax(dim=2)
+    first_max = (flat == flat.max(dim=2, keepdim=True)[0]).float().argmax(dim=2)
+    assert torch.equal(arg[..., 0].cpu().long(), first_min) and torch.equal(arg[..., 1].cpu().long(), first_max)
+    bins = int(rng.integers(2, 40))
+    ref = torch.stack([torch.cat([torch.histc(ch, bins=bins, min=0, max=1) for ch in im]) for im in x])
+    assert torch.equal(F.hist_features(x.cuda(), bins).cpu(), ref), 'histc bins=%d' % bins
+    k = int(rng.integers(2, 9))
+    outs = [torch.from_numpy(rng.random((n, c, h, w), dtype=np.float32)) for _ in range(k)]
+    wts = torch.from_numpy(rng.random(k).astype(np.float32))
+    wts[rng.integers(0, k)] = 0.0
+    gy = torch.from_numpy(rng.uniform(-1, 1, size=(n, c, h, w)).astype(np.float32))
+    oc, wc = [o.clone().requires_grad_(True) for o in outs], wts.clone().requires_grad_(True)
+    gref = torch.autograd.grad(sum(o * wk for o, wk in zip(oc, wc)), [wc] + oc, gy)
+    og, wg = [o.cuda().requires_grad_(True) for o in outs], wts.cuda().requires_grad_(True)
+    yg = F.mix(wg, og)
+    gg = torch.autograd.grad(yg, [wg] + og, gy.cuda())
+    assert_close(yg, sum(o * wk for o, wk in zip(outs, wts)), what='mix')
+    for a, b in zip(gg, gref):
+        assert_close(a, b, rtol=2e-4, what='mix grad')
+    a, b = torch.from_numpy(rng.uniform(-0.1, 1.1, size=(n, 3, h, w)).astype(np.float32)), x
+    ref_psnr = O.psnr_uint8(np.clip(a.numpy() * 255, 0, 255).astype(np.uint8), np.clip(b.numpy() * 255, 0, 255).astype(np.uint8))
+    assert abs(util.psnr_tensors(a.cuda(), b.cuda()) - ref_psnr) < 1e-4
