@@ -229,3 +229,23 @@ def test_random_reductions(seed):
     a, b = torch.from_numpy(rng.uniform(-0.1, 1.1, size=(n, 3, h, w)).astype(np.float32)), x
     ref_psnr = O.psnr_uint8(np.clip(a.numpy() * 255, 0, 255).astype(np.uint8), np.clip(b.numpy() * 255, 0, 255).astype(np.uint8))
     assert abs(util.psnr_tensors(a.cuda(), b.cuda()) - ref_psnr) < 1e-4
+
+
+@pytest.mark.parametrize('seed', range(_FUZZ))
+def test_random_pointwise_ops_forward_and_gradients(F, seed):
+    """Random shapes, sample ranges and per-image parameters (full [0,1] range) for every differentiable element-wise
+    op: output, input gradient and parameter gradient against the oracle's autograd."""
+    rng = np.random.default_rng(900 + seed)
+    n, h, w = int(rng.integers(1, 5)), 2 * int(rng.integers(2, 40)), 4 * int(rng.integers(1, 40))
+    shape = (n, 3, h, w)
+    lo, hi = (-0.3, 1.4) if rng.random() < 0.5 else (0.0, 1.0)
+    x = rnd(*shape, seed=seed, lo=lo, hi=hi)
+    gy = rnd(*shape, seed=seed + 1, lo=-1.0, hi=1.0)
+    par = lambda k, a=0.02, b=0.98: torch.from_numpy(rng.uniform(a, b, size=(n, k)).astype(np.float32))
+    _fwd_bwd(lambda a, p: F.wb_manual(a, p * 5), O.wb_manual, x, par(3), gy, 'wb_manual', rtol=2e-4)
+    _fwd_bwd(F.gamma, O.gamma_manual, x, par(1, 0.05, 0.95), gy, 'gamma', rtol=2e-4)
+    _fwd_bwd(F.gtm_manual, O.gtm_manual, x, par(3), gy, 'gtm', rtol=2e-4)
+    _fwd_bwd(F.wb_quadratic, O.wb_quadratic, x, par(30, 0.3, 0.7), gy, 'wbq', rtol=2e-4)
+    _fwd_bwd(F.grayworld, O.grayworld, rnd(*shape, seed=seed + 2, lo=0.01, hi=1.0), None, gy, 'grayworld', rtol=2e-4)
+    bay = rnd(n, 1, h, w, seed=seed + 3)
+    assert torch.equal(F.demosaic_nearest(bay.cuda()).cpu(), O.demosaic_nearest(bay))
