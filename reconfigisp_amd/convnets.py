@@ -127,11 +127,12 @@ class PackedConv:
         L.call('risp_conv_pack_weights', _p(w), self.cin, self.cout, self.k, 0, _p(self.fwd), _stream())
         L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
         self.wino_fwd = self.wino_bwd = None
-        self.wino_entry = self.wino43_fwd = None
+        self.wino_entry = self.wino43_fwd = self.wino43_bwd = None
         if self.k == 3 and WINOGRAD:
             self.wino_fwd, self.wino_bwd, self.wino_entry = _wino3_pack(w, False), _wino3_pack(w, True), 'risp_conv2d_wino3'
-            if WINO_F43:                              # inference-only forward form (see conv())
-                self.wino43_fwd = wino43_weights(w, False, L.load().risp_conv_wino43_chunk())
+            if WINO_F43:                              # inference forward and every backward-data pass (see conv())
+                ck43 = L.load().risp_conv_wino43_chunk()
+                self.wino43_fwd, self.wino43_bwd = wino43_weights(w, False, ck43), wino43_weights(w, True, ck43)
         elif self.k == 5 and WINOGRAD:
             self.wino_fwd, self.wino_bwd, self.wino_entry = _wino5_pack(w, False), _wino5_pack(w, True), 'risp_conv2d_wino5'
 
@@ -176,10 +177,13 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
         shape = (n, cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, cout, h, w)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
     wino, entry = (pc.wino_bwd if transpose else pc.wino_fwd), pc.wino_entry
-    # F(4,3) has about twice the rounding error of F(2,3) (still ~2e-7 of max|y|): harmless for outputs, but in
-    # training it flips more ReLU masks relative to the reference's arithmetic, and gradients are discontinuous
-    # there - so it serves inference only, F(2,3) everything that feeds a backward pass.
-    if pc.wino43_fwd is not None and not transpose and infer:
+    # F(4,3) has about twice the rounding error of F(2,3) (still ~2e-7 of max|y|): harmless for outputs, but in a
+    # training FORWARD it flips more ReLU masks relative to the reference's arithmetic, and gradients are
+    # discontinuous there - so forward passes that feed a backward pass stay on F(2,3).  Backward-data passes take
+    # their masks from the saved forward activations: their own rounding only perturbs the gradient smoothly.
+    if transpose and pc.wino43_bwd is not None:
+        wino, entry = pc.wino43_bwd, 'risp_conv2d_wino43'
+    elif pc.wino43_fwd is not None and not transpose and infer:
         wino, entry = pc.wino43_fwd, 'risp_conv2d_wino43'
     use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
                 (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
