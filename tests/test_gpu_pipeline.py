@@ -221,3 +221,23 @@ def test_random_tiling_geometry_matches_oracle(seed):
     proc = p * 0.75 + 0.1
     assert_close(U.patch2whole(proc, q, c, (sh, sw)), O.patch2whole(proc, q_ref, c_ref, (sh, sw)), rtol=1e-6,
                  what='blend H%d W%d patch %dx%d stride %dx%d' % (H, W, ph, pw, sh, sw))
+
+
+def test_cnn_pipeline_crop_consistency_at_frame_scale():
+    """Size-independent property of the convolutional pipeline (translation equivariance): on a 768 x 1024 frame,
+    the pipeline applied to a crop equals the crop of the pipeline applied to the frame, wherever the receptive
+    field (< 64 px for Path-Restore + proxy demosaic + Path-Restore) stays inside the crop.  Exercises every tile
+    boundary of the Winograd / direct / small-cout kernels at a size no oracle run could cover."""
+    net = _pipeline('Bayer_01_Demosaic_02_sRGB_13_12', 1, 0)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randint(0, 1024, (1, 1, 768, 1024), generator=g).float() / 1023.).cuda()
+    with torch.no_grad():
+        full = net(x)
+        for (y0, x0, h, w) in ((0, 0, 256, 320), (130, 258, 384, 512), (768 - 200, 1024 - 264, 200, 264)):
+            part = net(x[:, :, y0:y0 + h, x0:x0 + w].contiguous())
+            t, l = (64 if y0 else 0), (64 if x0 else 0)
+            b, r = (64 if y0 + h < 768 else 0), (64 if x0 + w < 1024 else 0)
+            a = full[:, :, y0 + t:y0 + h - b, x0 + l:x0 + w - r]
+            c = part[:, :, t:h - b, l:w - r]
+            assert torch.isfinite(c).all()
+            assert_close(c, a, floor=1.0, rtol=1e-5, what='crop at (%d,%d)' % (y0, x0))
