@@ -49,25 +49,29 @@ int risp_demosaic_nearest_bwd(const float *g_bgr, float *g_bayer, int N, int H, 
 /* whitebalance.WhiteBalance().run(img,'manual',{'gain'}) - tools_origin.py:211-221.  p = the gain
  * itself, (N,3) in [0,5] (the wrapper's params * 5, :214); y_c = x_c * gain_c, no clipping. */
 int risp_wb_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
+/* All *_bwd of the element-wise ops: gp is fully written (no pre-zeroing); scratch holds
+ * risp_param_grad_scratch_floats(N) floats - one partial row per workgroup, added in index order by a second
+ * launch, so parameter gradients are bit-repeatable. */
+size_t risp_param_grad_scratch_floats(int N);
 int risp_wb_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
-                       int N, int HW, void *stream);
+        float *scratch, int N, int HW, void *stream);
 
 /* gamma.Gamma().run(img,'manual',{'gamma':g}) - tools_origin.py:59-69. P=1.
  * OPSPEC: y = x^g (x >= 1/1024), y = x * (1/1024)^(g-1) below. */
 int risp_gamma_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
 int risp_gamma_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
-                   int N, int HW, void *stream);
+        float *scratch, int N, int HW, void *stream);
 
 /* GtmManual(4).forward - tools_origin.py:414-440. P=3; knots come from p[0,:] only,
  * so gp[0,:] holds the whole-batch gradient and gp[1:,:] = 0. */
 int risp_gtm_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
 int risp_gtm_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
-                        int N, int HW, void *stream);
+        float *scratch, int N, int HW, void *stream);
 
 /* WbQuadratic.forward - tools_origin.py:317-359. P=30, coef[n,ch,j] = 10 p[n,10ch+j] - 5 */
 int risp_wb_quadratic_fwd(const float *x, const float *p, float *y, int N, int HW, void *stream);
 int risp_wb_quadratic_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp,
-                          int N, int HW, void *stream);
+        float *scratch, int N, int HW, void *stream);
 
 /* Per-image per-channel statistics of an (N,C,H,W) tensor (NC = N*C planes):
  * stats[plane*4+{0,1,2}] = {min, sum, max}; arg[plane*2+{0,1}] = first (row-major) index of
@@ -99,8 +103,8 @@ int risp_grayworld_gains_bwd(const float *stats, const float *g_gains, float *g_
                              void *stream);
 /* y[n,c] = clamp(x[n,c] * k[n,c], 0, 1); k is (N,3) */
 int risp_gain3_fwd(const float *x, const float *k, float *y, int N, int HW, void *stream);
-int risp_gain3_bwd(const float *x, const float *k, const float *gy, float *gx, float *gk, int N, int HW,
-                   void *stream);
+int risp_gain3_bwd(const float *x, const float *k, const float *gy, float *gx, float *gk, float *scratch, int N,
+                   int HW, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Fused element-wise segment of a fixed pipeline (isp_universal.py:210-232): one
@@ -130,8 +134,10 @@ int risp_chain_fwd(const float *in, int n_ops, const int *ops, const float *cons
  * ------------------------------------------------------------------------- */
 #define RISP_MAX_MIX 16
 int risp_mix_fwd(const float *const *outs, const float *w, int K, float *y, size_t numel, void *stream);
+/* scratch: risp_mix_scratch_floats() floats (one partial row per workgroup, added in index order: bit-repeatable) */
+size_t risp_mix_scratch_floats(void);
 int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *gy,
-                 float *const *go, float *gw, size_t numel, void *stream);
+                 float *const *go, float *gw, float *scratch, size_t numel, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Convolution layers of the learned proxies on fp32 MFMA

@@ -29,7 +29,7 @@ struct WbManualCtx {   // p = the per-image gain (N,3), i.e. what tools_origin.p
         return {g.b * k[0], g.g * k[1], g.r * k[2]};
     }
     __device__ static float pscale(int) { return 1.f; }
-    __device__ static int prow(int n) { return n; }
+    __host__ __device__ static int prow(int n) { return n; }
 };
 
 struct GammaCtx {
@@ -57,7 +57,7 @@ struct GammaCtx {
         return {b1(x.b, gy.b, acc), b1(x.g, gy.g, acc), b1(x.r, gy.r, acc)};
     }
     __device__ static float pscale(int) { return 1.f; }
-    __device__ static int prow(int n) { return n; }
+    __host__ __device__ static int prow(int n) { return n; }
 };
 
 struct GtmCtx {  // 4 segments; knots from row 0 of p only (tools_origin.py:423)
@@ -108,7 +108,7 @@ struct GtmCtx {  // 4 segments; knots from row 0 of p only (tools_origin.py:423)
         return {b1(x.b, gy.b, acc), b1(x.g, gy.g, acc), b1(x.r, gy.r, acc)};
     }
     __device__ static float pscale(int) { return 1.f; }
-    __device__ static int prow(int) { return 0; }
+    __host__ __device__ static int prow(int) { return 0; }
 };
 
 struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR B G R 1
@@ -152,7 +152,7 @@ struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR 
         return o;
     }
     __device__ static float pscale(int) { return 10.f; }
-    __device__ static int prow(int n) { return n; }
+    __host__ __device__ static int prow(int n) { return n; }
 };
 
 struct Gain3Ctx {  // y_c = clamp(x_c * p[n,c]) : gray-world apply with precomputed gains
@@ -173,7 +173,7 @@ struct Gain3Ctx {  // y_c = clamp(x_c * p[n,c]) : gray-world apply with precompu
         return {g.b * k[0], g.g * k[1], g.r * k[2]};
     }
     __device__ static float pscale(int) { return 1.f; }
-    __device__ static int prow(int n) { return n; }
+    __host__ __device__ static int prow(int n) { return n; }
 };
 
 template <class Ctx, int NPX>

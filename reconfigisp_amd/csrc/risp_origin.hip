@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void loglum_kernel(const float *__restrict__ x
         acc[0] += (L(b.x, g.x, r.x) + L(b.y, g.y, r.y)) + (L(b.z, g.z, r.z) + L(b.w, g.w, r.w));
     }
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(&out[n], acc[0]);
+    if (threadIdx.x == 0) out[n] = acc[0];               // one workgroup per image: bit-repeatable log-average
 }
 
 // raw per-image plugin parameters -> the constants tonemap_kernel consumes
@@ -352,7 +352,7 @@ int risp_origin_tonemap(const float *x, float *y, int mode, const float *a, cons
             risp_set_error("risp_origin_tonemap: memset failed");
             return 2;
         }
-        hipLaunchKernelGGL(loglum_kernel, dim3(bx > 32 ? 32 : bx, N), dim3(256), 0, s, x, lsum, hw4, in_scale);
+        hipLaunchKernelGGL(loglum_kernel, dim3(1, N), dim3(256), 0, s, x, lsum, hw4, in_scale);
         st = lsum;
     }
     hipLaunchKernelGGL(tonemap_prepare_kernel, dim3((N + 63) / 64), dim3(64), 0, s, mode, a, b, st, p, N, 1.0f / (float)HW,

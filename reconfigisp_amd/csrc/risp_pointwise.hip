@@ -60,10 +60,25 @@ __global__ __launch_bounds__(256) void bgr_bwd_kernel(const float *__restrict__ 
         ob[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
     }
     block_sum<Ctx::NP>(acc, red);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {      // one partial row per workgroup; param_finish_kernel adds them in index order
 #pragma unroll
-        for (int j = 0; j < Ctx::NP; ++j) atomicAdd(&gp[Ctx::prow(n) * Ctx::NP + j], acc[j] * Ctx::pscale(j));
+        for (int j = 0; j < Ctx::NP; ++j) gp[((size_t)n * gridDim.x + blockIdx.x) * Ctx::NP + j] = acc[j] * Ctx::pscale(j);
     }
+}
+
+// gp[row][j] = sum of the partial rows that map to `row` (Ctx::prow: the image itself, or row 0 for the whole batch),
+// images and workgroups in index order: bit-repeatable parameter gradients
+template <class Ctx>
+__global__ void param_finish_kernel(const float *__restrict__ part, float *__restrict__ gp, int N, int bx, int rows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * Ctx::NP) return;
+    const int row = t / Ctx::NP, j = t - row * Ctx::NP;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        if (Ctx::prow(n) != row) continue;
+        for (int b = 0; b < bx; ++b) s += part[((size_t)n * bx + b) * Ctx::NP + j];
+    }
+    gp[t] = s;
 }
 
 template <class Ctx>
@@ -78,18 +93,17 @@ int launch_fwd(const char *name, const float *x, const float *p, float *y, int N
 }
 
 template <class Ctx>
-int launch_bwd(const char *name, const float *x, const float *p, const float *gy, float *gx, float *gp, int N,
-               int HW, void *stream) {
-    RISP_CHECK_ARG(x && p && gy && gx && gp && N > 0 && HW > 0 && HW % 4 == 0, "%s: bad arguments", name);
+int launch_bwd(const char *name, const float *x, const float *p, const float *gy, float *gx, float *gp, float *scratch,
+               int N, int HW, void *stream) {
+    RISP_CHECK_ARG(x && p && gy && gx && gp && scratch && N > 0 && HW > 0 && HW % 4 == 0, "%s: bad arguments", name);
     const int hw4 = HW / 4;
     int bx = (hw4 + 1023) / 1024;  // >= 4 vectors per thread so the reduction amortises
     if (bx < 1) bx = 1;
     if (bx > 32) bx = 32;
-    if (hipMemsetAsync(gp, 0, sizeof(float) * N * Ctx::NP, (hipStream_t)stream) != hipSuccess) {
-        risp_set_error("%s: memset failed", name);
-        return 2;
-    }
-    hipLaunchKernelGGL(bgr_bwd_kernel<Ctx>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, p, gy, gx, gp, hw4);
+    hipLaunchKernelGGL(bgr_bwd_kernel<Ctx>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, p, gy, gx, scratch, hw4);
+    const int rows = N;                                // gp is (N, NP): rows no image maps to (GtmManual: all but row 0) get 0
+    hipLaunchKernelGGL(param_finish_kernel<Ctx>, dim3((rows * Ctx::NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch,
+                       gp, N, bx, rows);
     RISP_LAUNCH_CHECK(name);
     return 0;
 }
@@ -239,34 +253,41 @@ extern "C" {
 int risp_wb_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
     return launch_fwd<WbManualCtx>("risp_wb_manual_fwd", x, p, y, N, HW, s);
 }
-int risp_wb_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
-    return launch_bwd<WbManualCtx>("risp_wb_manual_bwd", x, p, gy, gx, gp, N, HW, s);
+int risp_wb_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, float *scratch, int N, int HW,
+                        void *s) {
+    return launch_bwd<WbManualCtx>("risp_wb_manual_bwd", x, p, gy, gx, gp, scratch, N, HW, s);
 }
 int risp_gamma_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
     return launch_fwd<GammaCtx>("risp_gamma_fwd", x, p, y, N, HW, s);
 }
-int risp_gamma_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
-    return launch_bwd<GammaCtx>("risp_gamma_bwd", x, p, gy, gx, gp, N, HW, s);
+int risp_gamma_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, float *scratch, int N, int HW,
+                    void *s) {
+    return launch_bwd<GammaCtx>("risp_gamma_bwd", x, p, gy, gx, gp, scratch, N, HW, s);
 }
 int risp_gtm_manual_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
     return launch_fwd<GtmCtx>("risp_gtm_manual_fwd", x, p, y, N, HW, s);
 }
-int risp_gtm_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
-    return launch_bwd<GtmCtx>("risp_gtm_manual_bwd", x, p, gy, gx, gp, N, HW, s);
+int risp_gtm_manual_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, float *scratch, int N, int HW,
+                         void *s) {
+    return launch_bwd<GtmCtx>("risp_gtm_manual_bwd", x, p, gy, gx, gp, scratch, N, HW, s);
 }
 int risp_wb_quadratic_fwd(const float *x, const float *p, float *y, int N, int HW, void *s) {
     return launch_fwd<WbqCtx>("risp_wb_quadratic_fwd", x, p, y, N, HW, s);
 }
-int risp_wb_quadratic_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, int N, int HW, void *s) {
-    return launch_bwd<WbqCtx>("risp_wb_quadratic_bwd", x, p, gy, gx, gp, N, HW, s);
+int risp_wb_quadratic_bwd(const float *x, const float *p, const float *gy, float *gx, float *gp, float *scratch, int N, int HW,
+                           void *s) {
+    return launch_bwd<WbqCtx>("risp_wb_quadratic_bwd", x, p, gy, gx, gp, scratch, N, HW, s);
 }
 
 int risp_gain3_fwd(const float *x, const float *k, float *y, int N, int HW, void *s) {
     return launch_fwd<Gain3Ctx>("risp_gain3_fwd", x, k, y, N, HW, s);
 }
-int risp_gain3_bwd(const float *x, const float *k, const float *gy, float *gx, float *gk, int N, int HW, void *s) {
-    return launch_bwd<Gain3Ctx>("risp_gain3_bwd", x, k, gy, gx, gk, N, HW, s);
+int risp_gain3_bwd(const float *x, const float *k, const float *gy, float *gx, float *gk, float *scratch, int N, int HW,
+                   void *s) {
+    return launch_bwd<Gain3Ctx>("risp_gain3_bwd", x, k, gy, gx, gk, scratch, N, HW, s);
 }
+
+size_t risp_param_grad_scratch_floats(int N) { return (size_t)(N > 0 ? N : 0) * 32 * 30; }
 
 static int chain_launch(const ChainArgs &a, void *stream) {
     const bool wide = (a.W % 4 == 0);

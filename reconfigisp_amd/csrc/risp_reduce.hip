@@ -225,11 +225,19 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const MixArgs a, const flo
         }
     }
     block_sum<RISP_MAX_MIX>(acc, red);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {      // one partial row per workgroup (gw = scratch here); mix_finish_kernel adds them in order
 #pragma unroll
         for (int k = 0; k < RISP_MAX_MIX; ++k)
-            if (k < a.K) atomicAdd(&gw[k], acc[k]);
+            if (k < a.K) gw[(size_t)blockIdx.x * RISP_MAX_MIX + k] = acc[k];
     }
+}
+
+__global__ void mix_finish_kernel(const float *__restrict__ part, float *__restrict__ gw, int K, int blocks) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * RISP_MAX_MIX + k];
+    gw[k] = s;
 }
 
 // ---- sum over H,W of selected channel planes
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void plane_sums_kernel(const float *__restrict
         acc[0] += (v.x + v.y) + (v.z + v.w);
     }
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(&out[n * nc + c], acc[0]);
+    if (threadIdx.x == 0) out[n * nc + c] = acc[0];      // one workgroup per plane: no atomics, bit-repeatable
 }
 
 __global__ __launch_bounds__(256) void plane_sums_scalar_kernel(const float *__restrict__ x, float *__restrict__ out,
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256) void plane_sums_scalar_kernel(const float *__r
     float acc[1] = {0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) acc[0] += xb[i];
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(&out[n * nc + c], acc[0]);
+    if (threadIdx.x == 0) out[n * nc + c] = acc[0];
 }
 
 // ---- truncating uint8 conversion + squared error (utils/util.py:130-131,141-154)
@@ -374,18 +382,17 @@ int risp_mix_fwd(const float *const *outs, const float *w, int K, float *y, size
     return 0;
 }
 
+size_t risp_mix_scratch_floats(void) { return (size_t)1024 * RISP_MAX_MIX; }
+
 int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *gy, float *const *go, float *gw,
-                 size_t numel, void *stream) {
+                 float *scratch, size_t numel, void *stream) {
     MixArgs a;
     if (int e = mix_args("risp_mix_bwd", outs, w, K, go, a, numel)) return e;
-    RISP_CHECK_ARG(gy && gw, "risp_mix_bwd: null argument");
-    if (hipMemsetAsync(gw, 0, sizeof(float) * K, (hipStream_t)stream) != hipSuccess) {
-        risp_set_error("risp_mix_bwd: memset failed");
-        return 2;
-    }
+    RISP_CHECK_ARG(gy && gw && scratch, "risp_mix_bwd: null argument");
     size_t b = (numel / 4 + 1023) / 1024;
     int grid = (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, gy, gw, numel / 4);
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, gy, scratch, numel / 4);
+    hipLaunchKernelGGL(mix_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, gw, K, grid);
     RISP_LAUNCH_CHECK("risp_mix_bwd");
     return 0;
 }
@@ -393,12 +400,7 @@ int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *g
 int risp_plane_sums(const float *x, float *out, int N, int C, int c0, int nc, int HW, void *stream) {
     RISP_CHECK_ARG(x && out && N > 0 && C > 0 && c0 >= 0 && nc > 0 && c0 + nc <= C && HW > 0 && N * nc <= 65535,
                    "risp_plane_sums: bad arguments");
-    if (hipMemsetAsync(out, 0, sizeof(float) * N * nc, (hipStream_t)stream) != hipSuccess) {
-        risp_set_error("risp_plane_sums: memset failed");
-        return 2;
-    }
-    int bx = (HW / 4 + 2047) / 2048;
-    bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
+    const int bx = 1;                                   // one workgroup per plane: deterministic, no atomics
     if (HW % 4 == 0)
         hipLaunchKernelGGL(plane_sums_kernel, dim3(bx, N * nc), dim3(256), 0, (hipStream_t)stream, x, out, C, c0, nc,
                            HW / 4);

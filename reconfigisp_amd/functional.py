@@ -43,6 +43,11 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _grad_scratch(n, device):
+    """workspace of the element-wise backward kernels (per-workgroup partial parameter gradients)"""
+    return torch.empty(L.load().risp_param_grad_scratch_floats(n), device=device, dtype=torch.float32)
+
+
 def _check_bgr(x):
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError('expected a (N,3,H,W) BGR tensor, got %s' % (tuple(x.shape),))
@@ -76,7 +81,7 @@ class _Pointwise(torch.autograd.Function):
         gy = _dev(gy, 'grad')
         gx, gp = torch.empty_like(x), torch.empty_like(p)
         n, hw = x.shape[0], x.shape[2] * x.shape[3]
-        L.call('risp_%s_bwd' % ctx.name, _p(x), _p(p), _p(gy), _p(gx), _p(gp), n, hw, _stream())
+        L.call('risp_%s_bwd' % ctx.name, _p(x), _p(p), _p(gy), _p(gx), _p(gp), _p(_grad_scratch(n, x.device)), n, hw, _stream())
         return gx, gp, None, None
 
 
@@ -176,7 +181,7 @@ class _Grayworld(torch.autograd.Function):
         gy = _dev(gy, 'grad')
         n, hw = x.shape[0], x.shape[2] * x.shape[3]
         gx, gk, gm = torch.empty_like(x), torch.empty_like(gains), torch.empty_like(gains)
-        L.call('risp_gain3_bwd', _p(x), _p(gains), _p(gy), _p(gx), _p(gk), n, hw, _stream())
+        L.call('risp_gain3_bwd', _p(x), _p(gains), _p(gy), _p(gx), _p(gk), _p(_grad_scratch(n, x.device)), n, hw, _stream())
         L.call('risp_grayworld_gains_bwd', _p(stats), _p(gk), _p(gm), n, hw, _stream())
         L.call('risp_stats_bwd', _p(gx), None, _p(gm), None, None, n * 3, hw, _stream())
         return gx
@@ -217,8 +222,9 @@ class _Mix(torch.autograd.Function):
         need = ctx.needs_input_grad[1:]
         gos = [torch.empty_like(o) if nd else None for o, nd in zip(outs, need)]
         gw = torch.empty(k, device=gy.device, dtype=torch.float32)
+        scratch = torch.empty(L.load().risp_mix_scratch_floats(), device=gy.device, dtype=torch.float32)
         L.call('risp_mix_bwd', L.ptr_array([o.data_ptr() for o in outs]), (C.c_float * k)(*ctx.w_host), k, _p(gy),
-               L.ptr_array([g.data_ptr() if g is not None else None for g in gos]), _p(gw), gy.numel(), _stream())
+               L.ptr_array([g.data_ptr() if g is not None else None for g in gos]), _p(gw), _p(scratch), gy.numel(), _stream())
         return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]),) + tuple(gos)
 
 

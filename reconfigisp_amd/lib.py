@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
 
 
 def _pw(n_extra=0):
+    # forward: (x, p, y, N, HW, stream); backward (n_extra = 3): (x, p, gy, gx, gp, scratch, N, HW, stream)
     return [_f] * (3 + n_extra) + [_i, _i, _s]
 
 
@@ -37,11 +38,11 @@ SIGNATURES = {
     'risp_last_error': (C.c_char_p, []),
     'risp_demosaic_nearest_fwd': (_i, [_f, _f, _i, _i, _i, _s]),
     'risp_demosaic_nearest_bwd': (_i, [_f, _f, _i, _i, _i, _s]),
-    'risp_wb_manual_fwd': (_i, _pw()), 'risp_wb_manual_bwd': (_i, _pw(2)),
-    'risp_gamma_fwd': (_i, _pw()), 'risp_gamma_bwd': (_i, _pw(2)),
-    'risp_gtm_manual_fwd': (_i, _pw()), 'risp_gtm_manual_bwd': (_i, _pw(2)),
-    'risp_wb_quadratic_fwd': (_i, _pw()), 'risp_wb_quadratic_bwd': (_i, _pw(2)),
-    'risp_gain3_fwd': (_i, _pw()), 'risp_gain3_bwd': (_i, _pw(2)),
+    'risp_wb_manual_fwd': (_i, _pw()), 'risp_wb_manual_bwd': (_i, _pw(3)),
+    'risp_gamma_fwd': (_i, _pw()), 'risp_gamma_bwd': (_i, _pw(3)),
+    'risp_gtm_manual_fwd': (_i, _pw()), 'risp_gtm_manual_bwd': (_i, _pw(3)),
+    'risp_wb_quadratic_fwd': (_i, _pw()), 'risp_wb_quadratic_bwd': (_i, _pw(3)),
+    'risp_gain3_fwd': (_i, _pw()), 'risp_gain3_bwd': (_i, _pw(3)),
     'risp_channel_stats_scratch_floats': (_z, [_i, _i]),
     'risp_channel_stats': (_i, [_f, _f, _f, _f, _i, _i, _s]),
     'risp_stats_bwd': (_i, [_f, _f, _f, _f, _f, _i, _i, _s]),
@@ -51,7 +52,9 @@ SIGNATURES = {
     'risp_grayworld_gains_bwd': (_i, [_f, _f, _f, _i, _i, _s]),
     'risp_chain_fwd': (_i, [_f, _i, C.POINTER(_i), _pp, _pp, _i, _i, _i, _s]),
     'risp_mix_fwd': (_i, [_pp, C.POINTER(C.c_float), _i, _f, _z, _s]),
-    'risp_mix_bwd': (_i, [_pp, C.POINTER(C.c_float), _i, _f, _pp, _f, _z, _s]),
+    'risp_mix_scratch_floats': (_z, []),
+    'risp_mix_bwd': (_i, [_pp, C.POINTER(C.c_float), _i, _f, _pp, _f, _f, _z, _s]),
+    'risp_param_grad_scratch_floats': (_z, [_i]),
     'risp_conv_wpack_floats': (_z, [_i, _i, _i]),
     'risp_conv_pack_weights': (_i, [_f, _i, _i, _i, _i, _f, _s]),
     'risp_conv2d': (_i, [C.POINTER(ConvDesc), _s]),
