@@ -4,6 +4,7 @@
 data-path collective: every image is independent).
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus N ...          # starts N fresh rank processes itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one forward of the pipeline over one batch of 64 synthetic 256x256 RGGB patches that is
@@ -17,12 +18,18 @@ already resident in HBM.  Workloads (SURVEY.md section 8d / BASELINE.md):
   cnn (`extra.cnn_*`)     Bayer_01_Demosaic_03_sRGB_01_13_11 (options/train/SID_isp.yml:28) =
                           Path-Restore-Bayer -> proxy demosaic -> Gamma -> WbQuadratic -> WbManual;
                           fp32-MFMA roofline
+  search (`extra.search_step`)  BASELINE config 4: one DARTS iteration (optimize_alphas + optimize_parameters,
+                          train.py:230-246, darts_model.py:159-324) of the 4-slot super-net (n_step 2) on a GLOBAL batch
+                          of 32 train + 32 val 256x256 patches, sharded 32/N per rank, gradients averaged over RCCL
+                          (strong scaling of a fixed job); the same job on one GPU is timed beside it
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -129,10 +136,11 @@ def kernel_time_ms(net, batches, reps, device, isp):
         else:       # skip | demosaic, wbmanual, gamma, gtmmanual (the kernel takes the gain = params * 5)
             plans.append(F.ChainPlan(bay, [F.OP_DEMOSAIC_NEAREST, F.OP_WB_MANUAL, F.OP_GAMMA, F.OP_GTM_MANUAL],
                                      [None, pars[2] * 5, pars[3], pars[4]]))
-    for k in range(2 * len(plans)):
+    # same untimed spin-up as timed(): ~50 ms of launches without intermediate synchronisation, then straight into
+    # the measured launches (no host synchronisation in between: it would re-introduce the clock transient)
+    for k in range(max(2 * len(plans), 1000)):
         plans[k % len(plans)].launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(device)
     e0.record()
     for k in range(reps):
         plans[k % len(plans)].launch()
@@ -190,6 +198,125 @@ def cpu_baseline(bay, arch, budget_s=10.0):
                       % (n, bay.shape[0], reps, arch, best, cores)}
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N FRESH rank processes (torch.distributed.run, one per
+    GPU, rendezvous on 127.0.0.1) as children of this process, which has not touched the GPU and never will; wait,
+    pass rank 0's JSON line through, exit with the children's code.  Nothing is exec'ed."""
+    have = torch.cuda.device_count()            # does not initialise HIP
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if have < n and env.get('RISP_BENCH_LAUNCH_ONLY') != '1':
+        if env.get('RISP_BENCH_ONE_DEVICE') != '1':
+            sys.stderr.write('bench.py: --gpus %d but %d GPU(s) visible.  (RISP_BENCH_ONE_DEVICE=1 RISP_BENCH_BACKEND=gloo runs '
+                             'all ranks on device 0 as a plumbing dry run; its numbers are not an N-GPU measurement.)\n' % (n, have))
+            return 2
+        env.setdefault('RISP_BENCH_BACKEND', 'gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    out, _ = child.communicate()
+    lines = [ln for ln in out.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    for ln in out.splitlines():
+        if ln not in lines:
+            sys.stderr.write(ln + '\n')
+    if lines:
+        print(lines[-1])
+    return child.returncode if child.returncode or lines else 1
+
+
+def search_opt(n_step, distributed):
+    from collections import OrderedDict
+    return OrderedDict(model='darts', gpu_ids=[0], dist=distributed, is_train=True,
+                       network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=n_step, n_modules=15,
+                                      prune_threshold=0.2, module_path=None),
+                       path=dict(pretrain_model_G=None, strict_load=True),
+                       train=dict(lr_G=1e-4, momentum_G=0.9, lr_meta=1e-4, beta1=0.9, beta2=0.99, pixel_criterion='l2',
+                                  lr_scheme='MultiStepLR', lr_steps=[100000], restarts=None, restart_weights=None,
+                                  lr_gamma=0.5, clear_state=False))
+
+
+def search_step_times(device, rank, world, distributed, global_batch, size, n_step, iters):
+    """Seconds per DARTS iteration (train.py's loop body: feed_data, update_learning_rate, optimize_alphas,
+    optimize_parameters) on this rank's shard of the global batch, and the seconds of it spent inside the gradient
+    all-reduces (a second set of iterations with the collectives bracketed by device synchronisations)."""
+    from reconfigisp_amd.codes.models import create_model
+    from reconfigisp_amd.codes.data.synthetic_raw import make_batch
+    torch.manual_seed(10)
+    model = create_model(search_opt(n_step, distributed))
+    a, ga = make_batch(global_batch, size, size, seed=1)
+    b, gb = make_batch(global_batch, size, size, seed=2)
+    shard = slice(rank, None, world) if distributed else slice(None)       # data_sampler.py:88-99: indices[rank::world]
+    data = tuple(t[shard].to(device) for t in (a, ga, b, gb))
+
+    def step(i):
+        model.feed_data(data)
+        model.update_learning_rate(i, warmup_iter=-1)
+        model.optimize_alphas()
+        model.optimize_parameters()
+
+    def run(k0):
+        torch.cuda.synchronize(device)
+        if distributed and world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            step(k0 + i)
+        torch.cuda.synchronize(device)
+        if distributed and world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if distributed and world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt / iters
+
+    step(0)
+    step(1)
+    sec = run(2)
+    comm = 0.0
+    if distributed and world > 1:
+        model.comm_seconds = 0.0
+        run(2 + iters)
+        comm, model.comm_seconds = model.comm_seconds / iters, None
+    loss = model.log_dict['loss']
+    per_rank = data[0].shape[0]
+    del model, data
+    torch.cuda.empty_cache()
+    return sec, comm, loss, per_rank
+
+
+def search_step_leg(device, rank, world, global_batch=32, size=256, n_step=2, iters=2):
+    """BASELINE config 4 (train.py DDP 4-slot search): a fixed global batch sharded over the ranks."""
+    pix = 2 * global_batch * size * size                       # train + val pixels of one iteration
+    out = {'workload': 'DARTS iteration (optimize_alphas + optimize_parameters: 5 forwards + 5 backwards of the %d-slot '
+                       'super-net, n_step %d), global batch %d train + %d val %dx%d patches, alpha = 0, nothing pruned'
+                       % (n_step + 2, n_step, global_batch, global_batch, size, size), 'scaling': 'strong'}
+    one = None
+    if rank == 0:                                              # the same job on ONE GPU (the ratio's denominator)
+        sec1, _, loss1, _ = search_step_times(device, 0, 1, False, global_batch, size, n_step, iters)
+        one = {'s_per_step': round(sec1, 4), 'MPix_s': round(pix / sec1 / 1e6, 2), 'loss': round(loss1, 6)}
+    if world > 1:
+        dist.barrier()
+        sec, comm, loss, per_rank = search_step_times(device, rank, world, True, global_batch, size, n_step, iters)
+        out.update(n_gpus=world, per_rank_batch=per_rank, s_per_step=round(sec, 4), steps_per_s=round(1.0 / sec, 3),
+                   MPix_s=round(pix / sec / 1e6, 2), allreduce_s_per_step=round(comm, 5),
+                   allreduce_calls_per_step=4, loss_rank0=round(loss, 6))
+        if one:
+            out.update(one_gpu=one, speedup_vs_one_gpu=round(one['s_per_step'] / sec, 3))
+    elif one:
+        out.update(n_gpus=1, per_rank_batch=global_batch, steps_per_s=round(1.0 / one['s_per_step'], 3), **one)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -208,17 +335,34 @@ def main():
                                                           'stage-output buffers; a step is ONE forward over ONE batch')
     ap.add_argument('--no-cnn', action='store_true', help='skip the MFMA-bound reference-YAML pipeline')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--no-search', action='store_true', help='skip the distributed search-step leg (BASELINE config 4)')
+    ap.add_argument('--search-batch', type=int, default=32, help='GLOBAL batch of the search-step leg')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    one_device = os.environ.get('RISP_BENCH_ONE_DEVICE') == '1'
+    if os.environ.get('RISP_BENCH_LAUNCH_ONLY') == '1':
+        # launcher self-test (tests/test_bench_launcher_cpu.py, no GPU needed): rendezvous, one collective, one line
+        dist.init_process_group(backend='gloo')
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'metric': 'launch-only self-test', 'value': None, 'n_gpus': world, 'launch_only': True,
+                              'rank_sum': t.item()}))
+        dist.destroy_process_group()
+        return
     if world > 1:
         # RCCL on ROCm.  RISP_BENCH_BACKEND=gloo + RISP_BENCH_ONE_DEVICE=1 is a dry-run mode for boxes with a
         # single GPU (every rank on device 0) used only to exercise this code path.
         dist.init_process_group(backend=os.environ.get('RISP_BENCH_BACKEND', 'nccl'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    if os.environ.get('RISP_BENCH_ONE_DEVICE') == '1':
+    if one_device:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -253,9 +397,15 @@ def main():
         else:
             wall, dev_ms = timed(rotating(net), args.steps, args.warmup, device, world)
         host_us = timed.host_us / (queue if graph else 1)
-        kernel_ms = kernel_time_ms(net, batches[:queue], max(args.steps, 100), device, True)
-        kernel_ms_cached = kernel_time_ms(net, batches[:1], max(args.steps, 100), device, True)
+        b2b_ms = kernel_time_ms(net, batches[:queue], max(args.steps, 100), device, True)
+        b2b_ms_cached = kernel_time_ms(net, batches[:1], max(args.steps, 100), device, True)
     value = world * pix_per_step * args.steps / wall / 1e6
+    ms_per_step = wall / args.steps * 1e3
+    # The dominant kernel's average launch duration = HIP events on the launch stream over the SAME timed region as
+    # `value` (a step is exactly one launch of it), i.e. an upper bound of the kernel's own duration that includes
+    # the launch boundary.  By construction it cannot exceed ms_per_step (the events sit inside the wall bracket).
+    kernel_ms = dev_ms
+    assert kernel_ms <= ms_per_step * 1.001, (kernel_ms, ms_per_step)
     achieved = BYTES_PER_PIX_ISP * pix_per_step / (kernel_ms * 1e-3) / 1e9
 
     pw = build_pipeline(ARCH_HBM, device)
@@ -264,36 +414,52 @@ def main():
         wall_p, dev_ms_p = timed(lambda: pstep(), args.steps, args.warmup, device, world)
         host_us_p = timed.host_us
         kernel_ms_p = kernel_time_ms(pw, batches[:queue], max(args.steps, 100), device, False)
-    extra = {'kernel_ms': round(kernel_ms, 5), 'stream_ms_per_step': round(dev_ms, 5),
+    hbm = lambda bpp, ms: bpp * pix_per_step / (ms * 1e-3) / 1e9          # GB/s
+    extra = {'kernel_ms': round(kernel_ms, 5), 'kernel_ms_source': 'HIP events on the launch stream around the timed region / steps',
              'host_issue_us_per_step': round(host_us, 1),
              'resident_batches': queue,
-             'kernel_ms_one_batch_cache_assisted': round(kernel_ms_cached, 5),
-             'hbm_frac_one_batch_cache_assisted': round(BYTES_PER_PIX_ISP * pix_per_step / (kernel_ms_cached * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             'kernel_ms_back_to_back_c_abi': round(b2b_ms, 5),
+             'hbm_frac_back_to_back_c_abi': round(hbm(BYTES_PER_PIX_ISP, b2b_ms) / HBM_PEAK_GBS, 4),
+             'kernel_ms_one_batch_cache_assisted': round(b2b_ms_cached, 5),
+             'hbm_frac_one_batch_cache_assisted': round(hbm(BYTES_PER_PIX_ISP, b2b_ms_cached) / HBM_PEAK_GBS, 4),
              'launch': ('hipGraph replay, %d resident batches (steps) per replay' % queue) if graph else
                        ('one Python forward() per step on the stream, rotating over %d resident batches' % queue),
              'pointwise_arch': ARCH_HBM,
              'pointwise_MPix_s': round(world * pix_per_step * args.steps / wall_p / 1e6, 1),
-             'pointwise_kernel_ms': round(kernel_ms_p, 5), 'pointwise_host_issue_us_per_step': round(host_us_p, 1), 'pointwise_host_issue_us_med_max': [round(timed.host_med_us, 1), round(timed.host_max_us, 1)],
-             'pointwise_hbm_GBs': round(BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms_p * 1e-3) / 1e9, 1),
-             'pointwise_hbm_frac': round(BYTES_PER_PIX_FUSED * pix_per_step / (kernel_ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+             'pointwise_kernel_ms': round(dev_ms_p, 5), 'pointwise_kernel_ms_back_to_back_c_abi': round(kernel_ms_p, 5),
+             'pointwise_host_issue_us_per_step': round(host_us_p, 1), 'pointwise_host_issue_us_med_max': [round(timed.host_med_us, 1), round(timed.host_max_us, 1)],
+             'pointwise_hbm_GBs': round(hbm(BYTES_PER_PIX_FUSED, dev_ms_p), 1),
+             'pointwise_hbm_frac': round(hbm(BYTES_PER_PIX_FUSED, dev_ms_p) / HBM_PEAK_GBS, 4)}
     if not args.no_cnn:
+        import reconfigisp_amd.convnets as CN
         cnn = build_pipeline(ARCH_CNN, device)
         steps_c = max(3, args.steps // 20)
         cstep = GraphedForward(cnn, bay) if graph else (lambda: cnn(bay))
         with torch.no_grad():
             wall_c, dev_ms_c = timed(lambda: cstep(), steps_c, 2, device, world)
+            CN.MFMA_ISSUED = [0.0]            # one more forward, counting the FLOPs its launches issue on the matrix cores
+            cnn(bay)
+            issued, CN.MFMA_ISSUED = CN.MFMA_ISSUED[0], None
         extra.update(cnn_arch=ARCH_CNN, cnn_MPix_s=round(world * pix_per_step * steps_c / wall_c / 1e6, 1),
                      cnn_ms_per_step=round(dev_ms_c, 3),
-                     cnn_mfma_TFLOPs=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12, 2),
-                     cnn_mfma_frac=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     cnn_note='algorithmic (direct-convolution) FLOPs / time; the 3x3 layers run a Winograd F(4,3) '
-                              'kernel that issues half of those FLOPs on the matrix cores')
+                     cnn_effective_TFLOPs=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12, 2),
+                     cnn_effective_frac=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                     cnn_mfma_issued_TFLOPs=round(issued / (dev_ms_c * 1e-3) / 1e12, 2),
+                     cnn_mfma_issued_frac=round(issued / (dev_ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                     cnn_note='effective = direct-convolution FLOPs (SURVEY 8d) / time; issued = FLOPs of the MFMA '
+                              'instructions the launches actually execute (Winograd F(4,3) halves the 3x3 layers, cout '
+                              'padded to 32; the small-cout layers run on vector FMAs and count 0) / time: the matrix-pipe '
+                              'utilisation is the ISSUED fraction')
+    if not args.no_search:
+        leg = search_step_leg(device, rank, world, global_batch=args.search_batch, size=args.size)
+        if rank == 0:
+            extra['search_step'] = leg
 
     if rank == 0:
         line = {
             'metric': 'MPix/s end-to-end 5-stage ISP forward, 256x256 Bayer', 'value': round(value, 1),
             'unit': 'MPix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(wall / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'batch=%d %dx%d Bayer per GPU, 5-stage fixed ISP forward %s (nearest demosaic, '
                                    'bilateral denoise, WbManual, Gamma, GtmManual; OriginUniversal), all stage '
@@ -305,6 +471,8 @@ def main():
                                    '%d B/pix algorithmic' % BYTES_PER_PIX_ISP},
             'extra': extra,
         }
+        if one_device and world > 1:
+            line['dry_run_all_ranks_on_one_device'] = True
         if not args.no_cpu and world == 1:
             line['cpu_baseline'] = cpu_baseline(bay_cpu, ARCH_DENOISE)
         print(json.dumps(line))

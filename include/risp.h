@@ -271,15 +271,17 @@ int risp_tile_blend(const float *patches, float *img, const int32_t *pos_dev, in
  * multiplied by the fp32 reciprocal of out_div last (how PyTorch divides a GPU tensor by a scalar) - (1,1) for the plugin boundary, which receives x255 images and divides the
  * result itself (tools_origin.py:455,471), (255,255) when the fused pipeline works on [0,1] tensors
  * directly (bit-identical: the same fp32 multiply and divide, minus two passes over the image).
+ * out_div < 0 (diagnostic): the clip-and-round is skipped and the unquantised value / |out_div| is stored, so that
+ * tests can compare the arithmetic in front of the 8-bit rounding at float tolerance (the median always returns codes).
  * ------------------------------------------------------------------------- */
 /* demosaic 'bilinear' (laplacian=0) / 'laplacian' (Malvar-He-Cutler, laplacian=1) - :457-468, :491-502 */
 int risp_origin_demosaic(const float *bayer, float *bgr, int laplacian, int N, int H, int W, float in_scale,
                          float out_div, void *stream);
-/* spatialnoisereduction 'bilateral' - :686-710.  window (N) odd <= 15, sigmas (N) in 0..255 units */
+/* spatialnoisereduction 'bilateral' - :686-710.  window (N) odd <= 17, sigmas (N) in 0..255 units */
 int risp_origin_bilateral(const float *x, float *y, const int32_t *window, const float *sigma_color,
                           const float *sigma_space, int max_window, int N, int H, int W, float in_scale,
                           float out_div, void *stream);
-/* 'median' - :734-751; one odd size <= 15 for the whole batch; works on 8-bit codes */
+/* 'median' - :734-751; one odd size <= 17 for the whole batch; works on 8-bit codes */
 int risp_origin_median(const float *x, float *y, int size, int N, int H, int W, float in_scale, float out_div,
                        void *stream);
 /* 'fastnlm' - :775-797; block_size / search_block (N) odd, decay (N) */

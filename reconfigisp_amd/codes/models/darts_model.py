@@ -14,6 +14,7 @@ also averages the three architecture-step gradient sets so that W ranks reproduc
 with a W-times larger batch (the reference leaves them rank-local).
 """
 import logging
+import time
 from collections import OrderedDict
 from functools import partial
 
@@ -52,15 +53,14 @@ class DartsModel(BaseModel):
         self.netG = networks.define_G(opt).to(self.device)
         self.netV = networks.define_G(opt).to(self.device)     # twin for the virtual step (not a deepcopy)
         self.netG_attr = self.netG
-        if self.distributed:                                      # replicas must start identical
-            for t in list(self.netG.parameters()) + list(self.netV.parameters()):
-                dist.broadcast(t.data, src=0)
+        self._sync_frozen_ops()
         if self.rank <= 0:
             self.print_network()
         self.load()
         self.img = self.gt = self.output = self.glb_flag = None
         self.val_img = self.val_gt = self.val_loss = self.val_glb_flag = None
         self.latency = self.latency_term = None
+        self.comm_seconds = None
 
         if self.is_train:
             t = opt['train']
@@ -84,6 +84,29 @@ class DartsModel(BaseModel):
         self.log_dict = OrderedDict()
 
     # ------------------------------------------------------------------ plumbing
+    def _sync_frozen_ops(self):
+        """The searched net, its virtual-step twin and every rank must evaluate the SAME frozen operators.  The
+        reference gets this from loading the same weight files into both nets (tools_proxy.py:28-39); with
+        ``module_path: None`` each constructor draws its own random proxies, so rank 0's netG is broadcast (every
+        registered parameter plus the proxies kept in plain lists, darts_model.py:31-44) and copied into netV."""
+        def ops(net):       # the operators sit in plain (nested) lists, not in the module tree
+            for entry in getattr(net, 'all_modules', []):
+                for m in (entry if isinstance(entry, (list, tuple)) else [entry]):
+                    yield m
+
+        if self.distributed:
+            tensors = list(self.netG.parameters())
+            for m in ops(self.netG):
+                tensors += list(m.parameters()) + list(m.buffers())
+            for t in tensors:
+                if t.numel():
+                    dist.broadcast(t.data, src=0)
+        with torch.no_grad():
+            for g, v in zip(ops(self.netG), ops(self.netV)):
+                v.load_state_dict(g.state_dict())
+            for g, v in zip(self.netG.parameters(), self.netV.parameters()):
+                v.copy_(g)
+
     def print_network(self):
         s, n = self.get_network_description(self.netG)
         logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))
@@ -129,7 +152,14 @@ class DartsModel(BaseModel):
         if not live:
             return tensors
         flat = torch.cat([t.reshape(-1) for t in live])
+        probe = self.comm_seconds is not None       # bench.py: seconds inside the collectives (synchronising)
+        if probe:
+            torch.cuda.synchronize(flat.device) if flat.is_cuda else None
+            t0 = time.perf_counter()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if probe:
+            torch.cuda.synchronize(flat.device) if flat.is_cuda else None
+            self.comm_seconds += time.perf_counter() - t0
         flat /= self.world
         at = 0
         for t in live:

@@ -102,7 +102,7 @@ def fused_forward(modules, param_tensors, x):
         if kind is T.DemosaicNearest:
             x = _flush(x, ops, params, results)
             seg_in, ops, params = x, [F.OP_DEMOSAIC_NEAREST], [None]
-        elif kind is T.OriginNoiseBilateral and x.shape[3] % 4 == 0:
+        elif kind is T.OriginNoiseBilateral and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and min(x.shape[2:]) > 8:
             from_bayer = ops == [F.OP_DEMOSAIC_NEAREST]
             if not from_bayer:
                 x = _flush(x, ops, params, results)

@@ -111,7 +111,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                 par_tensor = torch.sigmoid(par).repeat(n, 1) if par.nelement() > 0 else None
                 outs.append(op(x, par_tensor))
                 index.append(k)
-            y = F.mix(post[index], outs)
+            y = F.mix(post[index], outs, w_host=[weights[k] for k in index])
             if pruned_pars:
                 y = F.attach_zero_grad(y, pruned_pars)
             self.middle_results.append(y)

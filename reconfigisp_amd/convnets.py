@@ -166,6 +166,19 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
     return out
 
 
+# bench.py sets this to [0.0] to count the FLOPs the launches ISSUE on the matrix cores (diagnostic; None = off)
+MFMA_ISSUED = None
+_TAPS = {'risp_conv2d_wino3': (12, 2), 'risp_conv2d_wino43': (18, 4), 'risp_conv2d_wino5': (30, 2)}
+
+
+def _issued_flops(entry, cin, cout, k, pixels):
+    """2 x MACs of the MFMA instructions one launch executes, tile-edge padding not counted: the direct kernel
+    multiplies k*k taps per pixel, the Winograd-x kernels 12 / 18 / 30 transformed taps per 2 / 4 / 2 pixels; output
+    channels are padded to a multiple of 32 (the MFMA tile), input channels to the kernel's pair granularity."""
+    taps, per = _TAPS.get(entry, (k * k, 1))
+    return 2.0 * taps * (cin + cin % 2) * ((cout + 31) // 32 * 32) * pixels / per
+
+
 def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None, epi=0, add=None, add_c=0,
          mask=None, out=None, infer=False):
     """One fused convolution launch at resolution (h,w); returns the output tensor.  ``infer``: no backward pass
@@ -192,6 +205,8 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wino if use_wino else (pc.bwd if transpose else pc.fwd)),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
     L.call(entry if use_wino else 'risp_conv2d', C.byref(d), _stream())
+    if MFMA_ISSUED is not None:
+        MFMA_ISSUED[0] += _issued_flops(entry if use_wino else 'risp_conv2d', cin, cout, pc.k, n * h * w)
     return out
 
 

@@ -247,7 +247,7 @@ int risp_bilateral_chain_fwd(const float *in, int from_bayer, float *out_demosai
     RISP_CHECK_ARG(!from_bayer || out_demosaic, "risp_bilateral_chain_fwd: demosaic output buffer missing");
     RISP_CHECK_ARG(n_ops >= 0 && n_ops <= RISP_MAX_CHAIN && (n_ops == 0 || (ops && params && outs)),
                    "risp_bilateral_chain_fwd: bad op list");
-    RISP_CHECK_ARG(max_window >= 1 && max_window <= 15 && (max_window & 1), "risp_bilateral_chain_fwd: window %d", max_window);
+    RISP_CHECK_ARG(max_window >= 1 && max_window <= 17 && (max_window & 1), "risp_bilateral_chain_fwd: window %d", max_window);
     RISP_CHECK_ARG(N > 0 && N <= 65535 && H % 2 == 0 && W % 4 == 0 && H > max_window / 2 && W > max_window / 2,
                    "risp_bilateral_chain_fwd: bad shape N=%d H=%d W=%d (W must be a multiple of 4)", N, H, W);
     FusedArgs a;

@@ -17,6 +17,11 @@ constexpr int TX = 32, TY = 8;   // output pixels per 256-thread block
 __device__ __forceinline__ float q8(float v) {
     return floorf(__builtin_amdgcn_fmed3f(v, 0.f, 255.f) + 0.5f);   // clamp in one instruction (v is never NaN here)
 }
+// Store form of a result v in 0..255: the 8-bit code / out_div; out_div < 0 is the diagnostic form that skips the
+// clip-and-round (v / |out_div|), so that tests can compare the arithmetic BEFORE quantisation at float tolerance.
+__device__ __forceinline__ float emit(float v, float so) {
+    return so > 0.f ? q8(v) * (1.f / so) : v * (1.f / -so);
+}
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * n - 2 - i;
@@ -76,9 +81,9 @@ __global__ __launch_bounds__(256) void origin_demosaic_kernel(const float *__res
     else if (!er && ec) { G_ = c; R_ = rb_ver; B_ = rb_hor; }
     else { B_ = c; G_ = g_rb; R_ = rb_diag; }
     const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)py * W + px;
-    y[o] = q8(B_) * (1.f / so);
-    y[o + plane] = q8(G_) * (1.f / so);
-    y[o + 2 * plane] = q8(R_) * (1.f / so);
+    y[o] = emit(B_, so);
+    y[o + plane] = emit(G_, so);
+    y[o + 2 * plane] = emit(R_, so);
 }
 
 // ---------------------------------------------------------------- bilateral
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
         }
     const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)py * W + px;
     const float rden = 1.f / den;                       // OPSPEC: normalise by one reciprocal, not three divisions
-    y[o] = q8(nb * rden) * (1.f / so);
-    y[o + plane] = q8(ng * rden) * (1.f / so);
-    y[o + 2 * plane] = q8(nr * rden) * (1.f / so);
+    y[o] = emit(nb * rden, so);
+    y[o + plane] = emit(ng * rden, so);
+    y[o + 2 * plane] = emit(nr * rden, so);
 }
 
 // ---------------------------------------------------------------- median on 8-bit codes (bisection on the code)
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void median_kernel(const float *__restrict__ x
                 for (int dx = -R; dx <= R; ++dx) cnt += ctr[dy * tw + dx] <= fm ? 1 : 0;
             if (cnt >= need) hi = mid; else lo = mid + 1;
         }
-        y[o + c * plane] = (float)lo * (1.f / so);
+        y[o + c * plane] = (float)lo * (1.f / fabsf(so));
     }
 }
 
@@ -181,9 +186,9 @@ __global__ __launch_bounds__(256) void fastnlm_kernel(const float *__restrict__ 
         }
     const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)py * W + px;
     const float rden = 1.f / den;                       // OPSPEC: normalise by one reciprocal, not three divisions
-    y[o] = q8(nb * rden) * (1.f / so);
-    y[o + plane] = q8(ng * rden) * (1.f / so);
-    y[o + 2 * plane] = q8(nr * rden) * (1.f / so);
+    y[o] = emit(nb * rden, so);
+    y[o + plane] = emit(ng * rden, so);
+    y[o + 2 * plane] = emit(nr * rden, so);
 }
 
 // ---------------------------------------------------------------- global tone curves / white-world (plane streams)
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float *__restrict__ 
             } else {                             // per-channel gains p0,p1,p2 on the 0..255 values
                 b *= p0; g *= p1; r *= p2;
             }
-            e[k] = q8(b * 255.f) * (1.f / so); e[4 + k] = q8(g * 255.f) * (1.f / so); e[8 + k] = q8(r * 255.f) * (1.f / so);
+            e[k] = emit(b * 255.f, so); e[4 + k] = emit(g * 255.f, so); e[8 + k] = emit(r * 255.f, so);
         }
         yb[i] = v[0]; yb[hw4 + i] = v[1]; yb[2 * hw4 + i] = v[2];
     }
@@ -301,7 +306,7 @@ int risp_origin_bilateral(const float *x, float *y, const int32_t *window, const
                           const float *sigma_space, int max_window, int N, int H, int W, float in_scale,
                           float out_div, void *stream) {
     RISP_CHECK_ARG(x && y && window && sigma_color && sigma_space && N > 0 && N <= 65535 && max_window >= 1 &&
-                       max_window <= 15 && (max_window & 1) && H > max_window / 2 && W > max_window / 2,
+                       max_window <= 17 && (max_window & 1) && H > max_window / 2 && W > max_window / 2,
                    "risp_origin_bilateral: bad arguments (window %d, H=%d W=%d)", max_window, H, W);
     const int R = max_window / 2;
     hipLaunchKernelGGL(bilateral_kernel, tile_grid(N, H, W), dim3(256), tile_lds(3, R), (hipStream_t)stream, x, y, window,
@@ -312,7 +317,7 @@ int risp_origin_bilateral(const float *x, float *y, const int32_t *window, const
 
 int risp_origin_median(const float *x, float *y, int size, int N, int H, int W, float in_scale, float out_div,
                        void *stream) {
-    RISP_CHECK_ARG(x && y && N > 0 && N <= 65535 && size >= 1 && size <= 15 && (size & 1) && H > size / 2 && W > size / 2,
+    RISP_CHECK_ARG(x && y && N > 0 && N <= 65535 && size >= 1 && size <= 17 && (size & 1) && H > size / 2 && W > size / 2,
                    "risp_origin_median: bad arguments (size %d, H=%d W=%d)", size, H, W);
     hipLaunchKernelGGL(median_kernel, tile_grid(N, H, W), dim3(256), tile_lds(3, size / 2), (hipStream_t)stream, x, y, H, W,
                        size / 2, in_scale, out_div);
@@ -325,7 +330,7 @@ int risp_origin_fastnlm(const float *x, float *y, const int32_t *block_size, con
                         float out_div, void *stream) {
     const int R = max_block / 2 + max_search / 2;
     RISP_CHECK_ARG(x && y && block_size && search_block && decay && N > 0 && N <= 65535 && max_block >= 1 &&
-                       max_block <= 15 && max_search >= 1 && max_search <= 15 && H > R && W > R,
+                       max_block <= 17 && max_search >= 1 && max_search <= 17 && H > R && W > R,
                    "risp_origin_fastnlm: bad arguments (block %d search %d, H=%d W=%d)", max_block, max_search, H, W);
     RISP_CHECK_ARG(tile_lds(3, R) <= 64 * 1024, "risp_origin_fastnlm: window too large for the LDS tile");
     hipLaunchKernelGGL(fastnlm_kernel, tile_grid(N, H, W), dim3(256), tile_lds(3, R), (hipStream_t)stream, x, y, block_size,

@@ -202,10 +202,14 @@ class _Mix(torch.autograd.Function):
     """y = sum_k w[k] * o_k ; w is a 1-D tensor (gradient flows to it), o_k the op outputs."""
 
     @staticmethod
-    def forward(ctx, w, *outs):
+    def forward(ctx, w, w_host, *outs):
         outs = [_dev(o) for o in outs]
         k = len(outs)
-        w_host = [float(v) for v in w.detach().cpu().tolist()]
+        if w_host is None:                  # the caller usually has the values on the host already (no second D2H)
+            w_host = w.detach().cpu().tolist()
+        w_host = [float(v) for v in w_host]
+        if len(w_host) != k or w.numel() != k:
+            raise ValueError('mix: %d weights for %d operands' % (len(w_host), k))
         y = torch.empty_like(outs[0])
         L.call('risp_mix_fwd', L.ptr_array([o.data_ptr() for o in outs]), (C.c_float * k)(*w_host), k, _p(y),
                y.numel(), _stream())
@@ -219,13 +223,13 @@ class _Mix(torch.autograd.Function):
         outs = ctx.saved_tensors
         gy = _dev(gy, 'grad')
         k = len(outs)
-        need = ctx.needs_input_grad[1:]
+        need = ctx.needs_input_grad[2:]
         gos = [torch.empty_like(o) if nd else None for o, nd in zip(outs, need)]
         gw = torch.empty(k, device=gy.device, dtype=torch.float32)
         scratch = torch.empty(L.load().risp_mix_scratch_floats(), device=gy.device, dtype=torch.float32)
         L.call('risp_mix_bwd', L.ptr_array([o.data_ptr() for o in outs]), (C.c_float * k)(*ctx.w_host), k, _p(gy),
                L.ptr_array([g.data_ptr() if g is not None else None for g in gos]), _p(gw), _p(scratch), gy.numel(), _stream())
-        return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]),) + tuple(gos)
+        return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]), None) + tuple(gos)
 
 
 class _ZeroGrad(torch.autograd.Function):
@@ -355,8 +359,8 @@ class _HipImpl:
         return _DemosaicNearest.apply(x)
 
     @staticmethod
-    def mix(w, outs):
-        return _Mix.apply(w, *outs)
+    def mix(w, outs, w_host=None):
+        return _Mix.apply(w, w_host, *outs)
 
     @staticmethod
     def histc01(x, bins):
@@ -450,8 +454,9 @@ def demosaic_nearest(x, p=None):
     return _IMPL.demosaic_nearest(x, p)
 
 
-def mix(w, outs):
-    return _IMPL.mix(w, outs)
+def mix(w, outs, w_host=None):
+    """sum_k w[k] * outs[k]; ``w_host``: the same weights as Python floats when the caller already holds them."""
+    return _IMPL.mix(w, outs, w_host)
 
 
 def hist_features(x, bins):
@@ -494,8 +499,8 @@ def _vec(v, n, device, dtype=torch.float32):
 
 def _check_odd(name, v):
     v = int(v)
-    if v < 1 or v > 15 or v % 2 == 0:
-        raise ValueError('%s must be an odd size in 1..15, got %d' % (name, v))
+    if v < 1 or v > 17 or v % 2 == 0:     # 17 = (1 * 7) * 2 + 3: a saturated sigmoid parameter (tools_origin.py:698,746,787)
+        raise ValueError('%s must be an odd size in 1..17, got %d' % (name, v))
     return v
 
 

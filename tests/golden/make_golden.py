@@ -357,7 +357,53 @@ def gold_tiling():
     npz('metrics', t=t, u=u, t_u8=a, u_u8=b, psnr=np.array(UU.psnr(a, b), np.float64))
 
 
+# ---------------------------------------------------------------- 8. IspModel: fixed-pipeline training step
+def _isp_opt(which, arch, criterion):
+    from collections import OrderedDict
+    return OrderedDict(model='isp', gpu_ids=None, dist=False, is_train=True,
+                       network_G=dict(which_model_G=which, architecture=arch, individual_module_paths=[None] * 8),
+                       path=dict(pretrain_model_G=None, strict_load=True),
+                       train=dict(lr_G=1e-2, beta1=0.9, beta2=0.99, pixel_criterion=criterion, lr_scheme='MultiStepLR',
+                                  lr_steps=[1000], restarts=None, restart_weights=None, lr_gamma=0.5, clear_state=False))
+
+
+def gold_isp_model():
+    """models/isp_model.py:19-151: two optimize_parameters() (forward, MSE / L1, backward, Adam) and one test() of a
+    fixed pipeline.  Case A: OriginUniversal, differentiable element-wise stages (index 14 cannot be constructed by
+    the reference's OriginUniversal - its pool holds a GtmManual INSTANCE, origin_universal.py:61).  Case B:
+    IspUniversal with a proxy demosaic CNN and the piecewise tone curve, L1 loss."""
+    import models.isp_model as IM
+    cases = (('a', 'OriginUniversal', 'Bayer_02_Demosaic_01_sRGB_11_01_13', 'l2'),
+             ('b', 'IspUniversal', 'Bayer_02_Demosaic_02_sRGB_11_01_13_14', 'l1'))
+    out = {}
+    for tag, which, arch, crit in cases:
+        np.random.seed(5)
+        model = IM.IspModel(_isp_opt(which, arch, crit))
+        for k, m in enumerate(model.netG.all_modules):
+            seed_module(m, 4000 + k)
+        img, gt = rnd(2, 1, 16, 16, seed=60) * 0.5 + 0.05, rnd(2, 3, 16, 16, seed=61)
+        out.update({tag + '_img': img, tag + '_gt': gt, tag + '_arch': np.array(arch), tag + '_which': np.array(which),
+                    tag + '_criterion': np.array(crit),
+                    tag + '_state_keys': np.array(list(model.netG.state_dict().keys()))})
+        for it in range(2):
+            model.feed_data((img, gt))
+            model.update_learning_rate(it, warmup_iter=-1)
+            model.optimize_parameters()
+            out['%s_it%d_loss' % (tag, it)] = np.array(model.log_dict['loss'], np.float32)
+            out['%s_it%d_output' % (tag, it)] = model.output.detach().clone()
+            for k, v in model.netG.state_dict().items():
+                out['%s_it%d_%s' % (tag, it, k)] = v.detach().clone()
+            for k, v in model.netG.named_parameters():
+                if v.grad is not None:
+                    out['%s_it%d_grad_%s' % (tag, it, k)] = v.grad.detach().clone()
+        y, mids = model.test()
+        out[tag + '_test_y'] = y.detach().clone()
+        for i, m in enumerate(mids):
+            out['%s_test_mid%d' % (tag, i)] = m.detach().clone()
+    npz('isp_model', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling']
+    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model']
     for w in which:
         globals()['gold_' + w]()

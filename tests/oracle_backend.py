@@ -22,7 +22,7 @@ class OracleImpl:
     demosaic_nearest = staticmethod(lambda x, p=None: O.demosaic_nearest(x))
 
     @staticmethod
-    def mix(w, outs):
+    def mix(w, outs, w_host=None):
         y = 0
         for wk, o in zip(w, outs):
             y = y + o * wk

@@ -1,0 +1,51 @@
+"""GPU: bench.py end to end, including the self-launching N > 1 path (all ranks on device 0 over gloo: a plumbing
+dry run of what the driver's SCALE run does on an 8-GPU node; its numbers are not an N-GPU measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*argv, **env):
+    e = dict(os.environ, **env)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=e, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_is_self_consistent():
+    line = _bench('--steps', '400', '--warmup', '50', '--search-batch', '4')
+    assert line['n_gpus'] == 1 and line['unit'] == 'MPix/s' and line['vs_baseline'] is None
+    roof, extra = line['roofline'], line['extra']
+    assert extra['kernel_ms'] <= line['ms_per_step'] * 1.001                 # a kernel cannot outlast its step
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3 and 0 < roof['frac'] < 1
+    pix = 64 * 256 * 256
+    assert abs(roof['achieved'] - 64 * pix / (extra['kernel_ms'] * 1e-3) / 1e9) < 1.0
+    assert abs(line['value'] - pix / (line['ms_per_step'] * 1e-3) / 1e6) < 0.01 * line['value']
+    assert 0 < extra['cnn_mfma_issued_frac'] < extra['cnn_effective_frac'] < 1.5
+    assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['value'] > 0
+    s = extra['search_step']
+    assert s['n_gpus'] == 1 and s['per_rank_batch'] == 4 and s['s_per_step'] > 0
+
+
+def test_bench_gpus2_self_launch_dry_run():
+    line = _bench('--gpus', '2', '--steps', '100', '--warmup', '10', '--no-cnn', '--search-batch', '4',
+                  RISP_BENCH_ONE_DEVICE='1')
+    assert line['n_gpus'] == 2 and line['dry_run_all_ranks_on_one_device'] is True
+    assert line['config']['global_batch'] == 128 and 'cpu_baseline' not in line
+    s = line['extra']['search_step']
+    assert s['n_gpus'] == 2 and s['per_rank_batch'] == 2 and s['allreduce_calls_per_step'] == 4
+    assert s['allreduce_s_per_step'] > 0 and s['one_gpu']['s_per_step'] > 0
+    # two ranks with half of the batch each compute the same averaged gradients as one rank with the whole batch
+    assert abs(s['loss_rank0'] - s['one_gpu']['loss']) < 0.2 * abs(s['one_gpu']['loss']) + 1e-6

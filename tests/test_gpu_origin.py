@@ -177,3 +177,65 @@ def test_random_classical_kernels(seed):
     bay = torch.floor(torch.from_numpy(rng.random((n, 1, h, w)).astype(np.float32)) * 1023) / 1023 * 255
     for option in ('bilinear', 'laplacian'):
         codes_close(F.origin_demosaic(bay.cuda(), option), O.origin_demosaic(bay, option), '%s seed %d' % (option, seed))
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (66, 92)])
+def test_classical_kernels_before_quantisation_at_float_tolerance(hw):
+    """The 8-bit criterion above (<= 1 code, <= 0.2 % differ) cannot see a systematic sub-code bias.  The kernels'
+    diagnostic form (out_div < 0: no clip-and-round) exposes the float in FRONT of the rounding; it is compared
+    with the oracle's unquantised value at the 1e-4 bar of every other operator."""
+    import reconfigisp_amd.functional as F
+    from conftest import assert_close
+    RAW = (1.0, -1.0)
+    n = 3
+    x = rnd(n, 3, *hw, seed=11) * 255
+    bay = torch.floor(rnd(n, 1, *hw, seed=12) * 1023) / 1023 * 255
+    p = {'white_point': np.array([0.5, 0.9, 0.1], np.float32), 'middle_grey': np.array([0.5, 0.2, 0.8], np.float32),
+         'lum_adapted': np.array([0.5, 0.05, 0.95], np.float32), 'exposure_bias': np.array([5.5, 1.0, 10.0], np.float32)}
+    ratio = np.array([0.5, 0.0, 1.0], np.float32)
+    bp = {'window_length': torch.tensor([3, 5, 7]), 'sigma_color': torch.tensor([50.5, 12.0, 90.0]),
+          'sigma_space': torch.tensor([50.5, 1.5, 3.0])}
+    npar = {'block_size': torch.tensor([3, 3, 5]), 'search_block': torch.tensor([3, 5, 3]),
+            'decay_factor': torch.tensor([50.5, 8.0, 20.0])}
+    with O.unquantized():
+        for option in ('bilinear', 'laplacian'):
+            assert_close(F.origin_demosaic(bay.cuda(), option, RAW), O.origin_demosaic(bay, option), what=option)
+        for option in ('reinhard', 'crysisengine', 'filmic'):
+            assert_close(F.origin_tonemap(x.cuda(), option, p, RAW), O.origin_tonemap(x, option, p), what=option)
+        assert_close(F.origin_whiteworld(x.cuda(), ratio, RAW), O.origin_whiteworld(x, ratio), what='whiteworld')
+        assert_close(F.origin_denoise(x.cuda(), 'bilateral', bp, RAW), O.origin_denoise(x, 'bilateral', bp), what='bilateral')
+        assert_close(F.origin_denoise(x.cuda(), 'fastnlm', npar, RAW), O.origin_denoise(x, 'fastnlm', npar), what='fastnlm')
+    # and the quantised form is exactly the rounding of the diagnostic form
+    for fn in (lambda s: F.origin_denoise(x.cuda(), 'bilateral', bp, s), lambda s: F.origin_tonemap(x.cuda(), 'filmic', p, s)):
+        assert torch.equal(fn((1.0, 1.0)), torch.floor(fn(RAW).clamp(0, 255) + 0.5))
+
+
+def test_window_17_of_a_saturated_parameter():
+    """(p.int() * 7) * 2 + 3 and 2 * int(p * 7) + 3 reach 17 when a sigmoid saturates to exactly 1.0
+    (tools_origin.py:698, 746, 787): the stencils take radius 8."""
+    import reconfigisp_amd.functional as F
+    x = rnd(1, 3, 40, 48, seed=13) * 255
+    codes_close(F.origin_denoise(x.cuda(), 'median', {'size': 17}), O.origin_denoise(x, 'median', {'size': 17}),
+                'median 17', exact=True)
+    bp = {'window_length': torch.tensor([17]), 'sigma_color': torch.tensor([30.0]), 'sigma_space': torch.tensor([6.0])}
+    codes_close(F.origin_denoise(x.cuda(), 'bilateral', bp), O.origin_denoise(x, 'bilateral', bp), 'bilateral 17')
+    npar = {'block_size': torch.tensor([3]), 'search_block': torch.tensor([17]), 'decay_factor': torch.tensor([20.0])}
+    codes_close(F.origin_denoise(x.cuda(), 'fastnlm', npar), O.origin_denoise(x, 'fastnlm', npar), 'fastnlm search 17')
+    with pytest.raises(ValueError, match='odd size'):
+        F.origin_denoise(x.cuda(), 'median', {'size': 19})
+
+
+def test_bilateral_on_odd_height_takes_the_standalone_kernel():
+    """The fused stencil segment needs even H and W % 4 == 0; other shapes must fall back to risp_origin_bilateral
+    instead of raising (pipeline_fusion.py dispatch predicate)."""
+    from reconfigisp_amd.codes.models import networks
+    net = networks.define_G({'network_G': {'which_model_G': 'OriginUniversal', 'architecture': 'sRGB_07_11',
+                                           'module_path': None}}).cuda().eval()
+    for hw in ((15, 20), (6, 8)):
+        x = rnd(2, 3, *hw, seed=14)
+        with torch.no_grad():
+            y = net(x.cuda())
+        ref, _ = O.fixed_pipeline(x, ['bilateral', 'wbmanual'], [torch.tensor(O.PARAM_INIT[k]) for k in ('bilateral', 'wbmanual')],
+                                  [None, None], origin=True)
+        d = (y.cpu() - ref).abs()
+        assert d.max().item() <= 1.01 * 5 * 0.2 / 255 + 1e-6 and (d > 1e-5).float().mean().item() < 5e-3
