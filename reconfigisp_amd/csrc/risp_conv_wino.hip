@@ -23,6 +23,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Diagnostic build only (-DRISP_CONV_STAMPS, tools/conv_stamps.py wino): per-wave cycle shares written to the
 // (otherwise unused) mask buffer.  Never compiled into the product.
 #ifdef RISP_CONV_STAMPS
@@ -100,12 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
             const int v = tid + 256 * i;
-            if (v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];
+            if (256 * (i + 1) <= XN / 4 || v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];   // full rounds: no branch
         }
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int v = tid + 256 * i;
-            if (v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
+            if (256 * (i + 1) <= WN / 4 || v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
         }
     };
 
@@ -307,12 +309,12 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
             const int v = tid + 256 * i;
-            if (v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];
+            if (256 * (i + 1) <= XN / 4 || v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];   // full rounds: no branch
         }
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int v = tid + 256 * i;
-            if (v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
+            if (256 * (i + 1) <= WN / 4 || v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
         }
     };
 
@@ -481,12 +483,12 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
             const int v = tid + 256 * i;
-            if (v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];
+            if (256 * (i + 1) <= XN / 4 || v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];   // full rounds: no branch
         }
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int v = tid + 256 * i;
-            if (v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
+            if (256 * (i + 1) <= WN / 4 || v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
         }
     };
 
@@ -504,16 +506,20 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
 #pragma unroll
             for (int j = 0; j < NF; ++j) fetch_one(ch + 1, j);
         }
-        // d0 of quad q sits at staged column 4q + 3 (image x0 + 4q - 1)
-        const float *bx = sx + buf * XN + (half * WIH + wave) * W43WP + 3 + 4 * l31;
+        // d0 of quad q sits at staged column 4q + 3 (image x0 + 4q - 1), d1..d4 in the 16-byte slot 4q + 4, d5 at 4q + 8.
+        // The six operands come from THREE ds_read_b128 (slots q, q+1, q+2: conflict-free, 4 LDS cycles each) instead of
+        // six scalar reads at a 16-byte lane stride (4-way bank conflicts on (a/4) mod 32: 8 cycles each, r01 PMC:
+        // 53 % of the LDS-active cycles were conflict stalls).
+        const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + buf * XN + (half * WIH + wave) * W43WP) + l31;
         const float *aw = sw + buf * WN + half * CP + l31;
         constexpr int NG = 3 * (CK / 2);
-        float opa[2][6], opd[2][6];
+        float opa[2][6];
+        f32x4 opd[2][3];
         auto load_group = [&](int g, int slot) {
             const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
-            const float *dp = bx + (2 * cp * WIH + ky) * W43WP;
+            const f32x4 *dp = bx + (2 * cp * WIH + ky) * (W43WP / 4);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) opd[slot][j] = dp[j];
+            for (int j = 0; j < 3; ++j) opd[slot][j] = dp[j];
 #pragma unroll
             for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
         };
@@ -523,8 +529,11 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
             const int slot = g & 1;
             if (g + 1 < NG) load_group(g + 1, slot ^ 1);
             __builtin_amdgcn_sched_barrier(0);         // keep the reads above this group's MFMAs
-            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3], d4 = opd[slot][4],
-                        d5 = opd[slot][5];
+            // (the empty asm consumes whole 16-byte tuples: without it the compiler narrows the outer two reads to the
+            // single elements used and falls back to the conflicting scalar form)
+            asm volatile("" : "+v"(opd[slot][0]), "+v"(opd[slot][2]));
+            const float d0 = opd[slot][0].w, d1 = opd[slot][1].x, d2 = opd[slot][1].y, d3 = opd[slot][1].z,
+                        d4 = opd[slot][1].w, d5 = opd[slot][2].x;
             const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
             const float bv[6] = {4.f * d0 - 5.f * d2 + d4, 4.f * s12 - s34, m34 - 4.f * m12, -2.f * m13 - m24, 2.f * m13 - m24,
                                  4.f * d1 - 5.f * d3 + d5};

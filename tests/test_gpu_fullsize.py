@@ -119,18 +119,18 @@ def test_tiled_full_frame_4000x3000_path_restore(capsys):
     out63 = run_frame(model, frame, size, stride, 63)
     assert torch.equal(out63, out21)
 
-    # crop consistency: the tiled result equals the UNTILED network on a crop, away from the crop's borders by the
+    # crop consistency: where exactly ONE tile covers a pixel the blend is patch * mask / mask, and further than the
     # receptive field (Path-Restore-Bayer 13 3x3 layers at half resolution = 26 px, proxy demosaic 9+1+5 at half
-    # resolution = 14 px -> < 48 px) - wherever a single tile covers the pixel the blend is patch*mask/mask
-    for (y0, x0) in ((0, 0), (1244, 1736), (H - 640, W - 640)):
-        crop = frame[:, :, y0:y0 + 640, x0:x0 + 640].contiguous()
+    # resolution = 14 px -> < 64 px) from that tile's cut edges the tile's result equals the UNTILED network's.
+    # (rows, cols) regions: inside tile 0 (image corner: true zero padding on two sides), tile 31 (interior),
+    # tile 62 (bottom-right corner; its neighbours 2400 / 3360 overlap it by 424 px)
+    for (r0, r1, c0, c1) in ((0, 448, 0, 448), (1440 + 64, 1440 + 448, 1920 + 64, 1920 + 448), (2912, H, 3872, W)):
+        t, l, b, r = max(r0 - 64, 0), max(c0 - 64, 0), min(r1 + 64, H), min(c1 + 64, W)
+        crop = frame[:, :, t:b, l:r].contiguous()
         with torch.no_grad():
             ref = model.netG(crop)
-        m = 64
-        t, l = (m if y0 else 0), (m if x0 else 0)
-        b, r = (m if y0 + 640 < H else 0), (m if x0 + 640 < W else 0)
-        assert_close(out21[:, :, y0 + t:y0 + 640 - b, x0 + l:x0 + 640 - r], ref[:, :, t:640 - b, l:640 - r],
-                     floor=1.0, rtol=1e-5, atol=1e-6, what='tiled vs untiled crop at (%d,%d)' % (y0, x0))
+        assert_close(out21[:, :, r0:r1, c0:c1], ref[:, :, r0 - t:r1 - t, c0 - l:c1 - l], floor=1.0, rtol=1e-5, atol=1e-6,
+                     what='tiled vs untiled rows %d:%d cols %d:%d' % (r0, r1, c0, c1))
 
     # the oracle on ONE tile (interior tile 31), last stage
     ty, tx = (int(v) for v in pos[31])
