@@ -403,7 +403,86 @@ def gold_isp_model():
     npz('isp_model', **out)
 
 
+# ---------------------------------------------------------------- 9. what the reference wrappers hand the plugin
+def gold_plugin_calls():
+    """Every call site of the private plugin in tools_origin.py (33-41 ... 775-797), recorded: the wrapper classes of
+    the IMPORTED reference run on small inputs with spies in place of their ``self.kernel``; each spy stores the option
+    string, the image exactly as passed (values in storage order + shape + strides: the wrappers pass permuted NHWC
+    VIEWS, scaled x255 for the classical ops) and every params entry with its Python kind / dtype / shape.  No reference
+    code is stored - only these arguments.  tests/test_gpu_plugin_calls.py replays them into
+    reconfigisp_amd.isp_kernels.*.run and checks the results against the oracle."""
+    import json
+    calls = []
+
+    class Spy:
+        def __init__(self, site):
+            self.site = site
+
+        def run(self, img, option, params):
+            rec = {'site': self.site, 'option': option, 'img': img, 'params': params}
+            calls.append(rec)
+            if option in ('nearestneighbor', 'demosaicnet'):
+                return torch.zeros(img.shape[0], 3, img.shape[2], img.shape[3])        # NCHW in, NCHW out
+            c = 3
+            return torch.zeros(img.shape[0], img.shape[1], img.shape[2], c)            # NHWC in, NHWC out
+
+    sites = [('Grayworld', T.Grayworld(), 3, 0), ('Gamma', T.Gamma(), 3, 1),
+             ('ConditionalGamma', T.ConditionalGamma((12, 8)), 3, None), ('WbManual', T.WbManual(), 3, 3),
+             ('ConditionalWbManual', T.ConditionalWbManual((12, 8)), 3, None), ('DemosaicNearest', T.DemosaicNearest(), 1, 0),
+             ('DemosaicNet', T.DemosaicNet(), 1, 0), ('OriginDemosBilinear', T.OriginDemosBilinear(), 1, 0),
+             ('OriginDemosLaplacian', T.OriginDemosLaplacian(), 1, 0), ('OriginToneReinhard', T.OriginToneReinhard(), 3, 2),
+             ('OriginToneCrysis', T.OriginToneCrysis(), 3, 1), ('OriginToneFilmic', T.OriginToneFilmic(), 3, 2),
+             ('OriginWbWhiteworld', T.OriginWbWhiteworld(), 3, 1), ('OriginNoiseBilateral', T.OriginNoiseBilateral(), 3, 3),
+             ('OriginNoiseMedian', T.OriginNoiseMedian(), 3, 1), ('OriginNoiseFastnlm', T.OriginNoiseFastnlm(), 3, 3)]
+    out = {'n_calls': np.array(len(sites))}
+    for k, (site, mod, cin, npar) in enumerate(sites):
+        mod.kernel = Spy(site)
+        x = rnd(2, cin, 16, 24, seed=70 + k)
+        if npar is None:
+            par = torch.from_numpy(np.random.Generator(np.random.PCG64(90 + k)).standard_normal(mod.total_params).astype(np.float32) * 0.05)
+        elif npar == 0:
+            par = None
+        else:
+            par = torch.sigmoid(torch.from_numpy(np.random.Generator(np.random.PCG64(90 + k)).standard_normal(npar).astype(np.float32))).repeat(2, 1)
+        before = len(calls)
+        y = mod(x, par)
+        assert len(calls) == before + 1, site
+        rec = calls[-1]
+        img = rec['img']
+        pre = 'call%02d_' % k
+        out[pre + 'site'] = np.array(site)
+        out[pre + 'option'] = np.array(rec['option'])
+        out[pre + 'wrapper_in'] = x
+        out[pre + 'wrapper_par'] = par if par is not None else np.zeros(0, np.float32)
+        out[pre + 'wrapper_out_shape'] = np.array(y.shape)
+        # the image as passed: element (i0,i1,i2,i3) lives at storage offset sum(i*stride)
+        out[pre + 'img_shape'] = np.array(img.shape)
+        out[pre + 'img_strides'] = np.array(img.stride())
+        out[pre + 'img_dtype'] = np.array(str(img.dtype))
+        order = np.argsort(-np.array(img.stride()), kind='stable')
+        out[pre + 'img_storage'] = img.detach().permute(*order.tolist()).contiguous().numpy()    # values in storage order
+        out[pre + 'img_storage_perm'] = order
+        meta = {}
+        for key, v in rec['params'].items():
+            if isinstance(v, dict):
+                meta[key] = {'kind': 'dict', 'value': v}
+            elif isinstance(v, torch.Tensor):
+                meta[key] = {'kind': 'tensor', 'dtype': str(v.dtype), 'shape': list(v.shape), 'requires_grad': bool(v.requires_grad)}
+                out[pre + 'param_' + key] = v.detach().numpy()
+            elif isinstance(v, np.ndarray):
+                meta[key] = {'kind': 'ndarray', 'dtype': str(v.dtype), 'shape': list(v.shape)}
+                out[pre + 'param_' + key] = v
+            elif isinstance(v, (int, np.integer)):
+                meta[key] = {'kind': 'int', 'value': int(v)}
+            elif isinstance(v, (float, np.floating)):
+                meta[key] = {'kind': 'float', 'value': float(v)}
+            else:
+                raise TypeError('%s: params[%r] is a %s' % (site, key, type(v)))
+        out[pre + 'params_meta'] = np.array(json.dumps(meta, sort_keys=True))
+    npz('plugin_calls', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model']
+    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls']
     for w in which:
         globals()['gold_' + w]()

@@ -92,3 +92,62 @@ def test_samplers_split_and_shard():
     assert list(s) != a                                        # reshuffled per epoch, deterministic by seed
     s.set_epoch(0)
     assert list(s) == a
+
+
+# ---------------------------------------------------------------- tiles of a full frame sharded over the ranks
+def _cpu_gather(img, positions, size):
+    return torch.stack([img[:, y:y + size[0], x:x + size[1]] for y, x in positions])
+
+
+def _cpu_blend(patches, positions, full, stride):
+    import isp_oracle as O
+    h, w = patches.shape[2:]
+    mask = torch.from_numpy(O.create_patch_mask((h, w), ((h - stride[0]) // 2, (w - stride[1]) // 2)))
+    acc, cnt = torch.zeros((patches.shape[1],) + tuple(full)), torch.zeros(tuple(full))
+    for p, (y, x) in zip(patches, positions):
+        acc[:, y:y + h, x:x + w] += p * mask
+        cnt[y:y + h, x:x + w] += mask
+    return acc / cnt
+
+
+def _frame_job(rank, world):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import reconfigisp_amd.functional as F
+    from oracle_backend import OracleImpl
+    F._IMPL = OracleImpl
+    from collections import OrderedDict
+    from reconfigisp_amd.codes.models import create_model
+    from reconfigisp_amd.codes.test_split import run_frame
+    opt = OrderedDict(model='isp', gpu_ids=None, dist=world > 1, is_train=False,
+                      network_G=dict(which_model_G='IspUniversal', architecture='Bayer_02_Demosaic_01_sRGB_11_01_14',
+                                     individual_module_paths=[None] * 8, module_path=None),
+                      path=dict(pretrain_model_G=None, strict_load=True))
+    model = create_model(opt)
+    g = np.random.Generator(np.random.PCG64(5))
+    frame = torch.from_numpy(g.random((1, 1, 44, 62)).astype(np.float32))
+    return run_frame(model, frame, (16, 16), (12, 12), tile_batch=2, rank=rank, world=world, gather=_cpu_gather,
+                     blend=_cpu_blend)
+
+
+def _frame_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        y = _frame_job(rank, world)
+        torch.save(y, out + '.%d' % rank)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_frame_tiles_sharded_over_ranks_equal_one_process(tmp_path, world):
+    """test_split.py with the tiles of a frame dealt round-robin to the ranks: 15 tiles over 2 / 3
+    ranks (uneven shares: the tail ranks pad), one all_gather, every rank blends - bit-identical to one process."""
+    ref = _frame_job(0, 1)
+    assert ref.shape == (1, 3, 44, 62)
+    out = str(tmp_path / 'frame.pt')
+    mp.spawn(_frame_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.equal(torch.load(out + '.%d' % r), ref), 'rank %d' % r
