@@ -77,7 +77,8 @@ class _FixedPipeline(nn.Module):
 
     def forward(self, x):
         pars = self._stage_params(x.size(0))
-        if x.is_cuda and not wants_grad(x, self.all_params):
+        # segment fusion works on 2 x 4 pixel patches: odd sizes (sRGB-only pipelines may see them) go op by op
+        if x.is_cuda and not wants_grad(x, self.all_params) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
             with torch.no_grad():
                 x, self.intermediate_results = fused_forward(self.all_modules, pars, x)
             return x
