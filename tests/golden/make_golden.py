@@ -482,7 +482,108 @@ def gold_plugin_calls():
     npz('plugin_calls', **out)
 
 
+# ---------------------------------------------------------------- 10. the same graphs evaluated by the reference in fp64
+def _to_double(net):
+    """nn.Module.double() + the operators the reference keeps in plain lists (not registered, so .double() skips them)"""
+    net.double()
+    for entry in net.all_modules:
+        for m in (entry if isinstance(entry, (list, tuple)) else [entry]):
+            if isinstance(m, nn.Module):
+                m.double()
+    return net
+
+
+def gold_f64():
+    """The yardstick of the error-budget tests (tests/test_gpu_error_budget.py): the IMPORTED reference evaluating the
+    super-net golden, the two DARTS iterations and the IspModel steps in float64 on the very same inputs / weights /
+    parameters.  err(reference fp32, fp64) is then what fp32 arithmetic costs on each quantity, and the HIP path must
+    stay within twice that.  (The reference's CNNs call ``x.float()`` on their input - srcnn_res_arch.py:33,
+    path_14l_*_arch.py - so for this run only Tensor.float is made the identity, one more harness shim.)"""
+    torch.Tensor.float = lambda self, *a, **k: self
+    # ---- super-net (same construction as gold_supernet)
+    net = SP.SuperPruneFifteenDemosFourBayerTwo(n_step=2, threshold=0.2, module_path='/nonexistent/')
+    seed_supernet(net, 1000)
+    rng = np.random.Generator(np.random.PCG64(20))
+    with torch.no_grad():
+        for a in net.alphas:
+            a.copy_(torch.from_numpy(rng.standard_normal(a.shape).astype(np.float32)))
+        net.alpha_demosaic[3] = -20.0
+        net.alpha_step1[1] = -3.0
+        for p in net.trainable_parameters:
+            if p.numel():
+                p.add_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32)) * 0.2)
+    _to_double(net)
+    x = rnd(2, 1, 16, 16, seed=21).double()
+    y = net(x)
+    gy = (rnd(2, 3, 16, 16, seed=22) - 0.5).double()
+    named = dict(net.named_parameters())
+    keys = sorted(named)
+    grads = torch.autograd.grad(y, [named[k] for k in keys], gy, allow_unused=True)
+    out = {'y': y, 'pruned_paths': np.array(net.pruned_paths)}
+    for i, m in enumerate(net.intermediate_results):
+        out['mid%d' % i] = m
+    for k, g in zip(keys, grads):
+        out['g_' + k] = g if g is not None else torch.zeros_like(named[k])
+    npz('supernet_n2_f64', **out)
+
+    # ---- DARTS: two iterations (same construction as gold_darts)
+    import models.darts_model as DM
+    from collections import OrderedDict
+    opt = OrderedDict(model='darts', gpu_ids=None, dist=False, is_train=True,
+                      network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=2,
+                                     n_modules=15, prune_threshold=0.2),
+                      path=dict(pretrain_model_G=None, strict_load=True),
+                      train=dict(lr_G=1e-2, momentum_G=0.9, lr_meta=1e-2, beta1=0.9, beta2=0.99,
+                                 pixel_criterion='l2', lr_scheme='MultiStepLR', lr_steps=[1000],
+                                 restarts=None, restart_weights=None, lr_gamma=0.5, clear_state=False))
+    model = DM.DartsModel(opt)
+    for net in (model.netG, model.netV):
+        seed_supernet(net, 1000)
+        with torch.no_grad():
+            net.alpha_demosaic[3] = -20.0
+        _to_double(net)
+    data = tuple(t.double() for t in (rnd(2, 1, 16, 16, seed=40), rnd(2, 3, 16, 16, seed=41), rnd(2, 1, 16, 16, seed=42),
+                                      rnd(2, 3, 16, 16, seed=43)))
+    out = {}
+    for it in range(2):
+        model.feed_data(data)
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.optimize_alphas()
+        out['it%d_val_loss' % it] = model.val_loss.detach().clone()
+        for k, a in enumerate(model.netG.alphas):
+            out['it%d_alpha_grad%d' % (it, k)] = a.grad.clone()
+        model.optimize_parameters()
+        out['it%d_loss' % it] = np.array(model.log_dict['loss'], np.float64)
+        for k, v in model.netG.state_dict().items():
+            out['it%d_%s' % (it, k)] = v.detach().clone()
+    npz('darts_step_f64', **out)
+
+    # ---- IspModel (same construction as gold_isp_model)
+    import models.isp_model as IM
+    out = {}
+    for tag, which, arch, crit in (('a', 'OriginUniversal', 'Bayer_02_Demosaic_01_sRGB_11_01_13', 'l2'),
+                                   ('b', 'IspUniversal', 'Bayer_02_Demosaic_02_sRGB_11_01_13_14', 'l1')):
+        np.random.seed(5)
+        model = IM.IspModel(_isp_opt(which, arch, crit))
+        for k, m in enumerate(model.netG.all_modules):
+            seed_module(m, 4000 + k)
+        _to_double(model.netG)
+        img, gt = (rnd(2, 1, 16, 16, seed=60) * 0.5 + 0.05).double(), rnd(2, 3, 16, 16, seed=61).double()
+        for it in range(2):
+            model.feed_data((img, gt))
+            model.update_learning_rate(it, warmup_iter=-1)
+            model.optimize_parameters()
+            out['%s_it%d_loss' % (tag, it)] = np.array(model.log_dict['loss'], np.float64)
+            out['%s_it%d_output' % (tag, it)] = model.output.detach().clone()
+            for k, v in model.netG.state_dict().items():
+                out['%s_it%d_%s' % (tag, it, k)] = v.detach().clone()
+            for k, v in model.netG.named_parameters():
+                if v.grad is not None:
+                    out['%s_it%d_grad_%s' % (tag, it, k)] = v.grad.detach().clone()
+    npz('isp_model_f64', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls']
+    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls', 'f64']
     for w in which:
         globals()['gold_' + w]()

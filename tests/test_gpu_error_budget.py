@@ -1,0 +1,124 @@
+"""GPU: measured fp32 error budgets instead of loosened tolerances.
+
+For the multi-stage graphs (super-net golden, two DARTS iterations, IspModel steps, the reference-YAML CNN pipeline)
+the yardstick is a float64 evaluation of the same graph: tests/golden/*_f64.npz hold the IMPORTED REFERENCE run in
+float64 on the golden inputs (make_golden.py::gold_f64); for oracle-checked pipelines the oracle itself runs in
+float64.  The criterion is   |hip - fp64| <= 2 x |reference-or-oracle fp32 - fp64| + 1e-6 x scale,   i.e. the HIP path
+may cost at most twice what the reference's own fp32 arithmetic costs on that quantity.  RISP_BUDGET_REPORT=1 prints
+the measured pairs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import isp_oracle as O
+from conftest import assert_error_budget, load_golden
+from test_host_logic import T, build_supernet, darts_opt, isp_opt, seed_darts, seed_ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def report():
+    rows = []
+    yield rows
+    if os.environ.get('RISP_BUDGET_REPORT') == '1':
+        for what, e_got, e_ref, scale in rows:
+            print('BUDGET %-40s hip %.3e  ref32 %.3e  ratio %6.2f  scale %.3g' % (what, e_got, e_ref, e_got / max(e_ref, 1e-30), scale))
+
+
+def test_supernet_forward_and_gradients_within_budget(report):
+    g, f = load_golden('supernet_n2'), load_golden('supernet_n2_f64')
+    net = build_supernet(2, torch.device('cuda'))
+    with torch.no_grad():
+        for k, v in net.named_parameters():
+            v.copy_(T(g['p_' + k]))
+    y = net(T(g['x']).cuda())
+    assert net.pruned_paths == list(f['pruned_paths'])
+    for i, m in enumerate(net.intermediate_results):
+        assert_error_budget(m, g['mid%d' % i], f['mid%d' % i], 'slot %d' % i, report=report)
+    named = dict(net.named_parameters())
+    keys = sorted(named)
+    grads = torch.autograd.grad(y, [named[k] for k in keys], T(g['gy']).cuda(), allow_unused=True)
+    for k, gr in zip(keys, grads):
+        gr = torch.zeros_like(named[k]) if gr is None else gr
+        assert_error_budget(gr, g['g_' + k], f['g_' + k], 'grad ' + k, report=report)
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+def test_darts_iterations_within_budget(report):
+    from reconfigisp_amd.codes.models import create_model
+    g, f = load_golden('darts_step'), load_golden('darts_step_f64')
+    model = create_model(darts_opt(torch.device('cuda')))
+    seed_darts(model)
+    data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
+    for it in range(2):
+        model.feed_data(data)
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.optimize_alphas()
+        assert_error_budget(model.val_loss.reshape(1), g['it%d_val_loss' % it].reshape(1), f['it%d_val_loss' % it].reshape(1),
+                            'it%d val loss' % it, report=report)
+        for k, a in enumerate(model.netG.alphas):
+            key = 'it%d_alpha_grad%d' % (it, k)
+            assert_error_budget(a.grad, g[key], f[key], key, report=report)
+        model.optimize_parameters()
+        for k, v in model.netG.state_dict().items():
+            key = 'it%d_%s' % (it, k)
+            assert_error_budget(v, g[key], f[key], key, report=report)
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_isp_model_steps_within_budget(report, tag):
+    from reconfigisp_amd.codes.models import create_model
+    g, f = load_golden('isp_model'), load_golden('isp_model_f64')
+    model = create_model(isp_opt(torch.device('cuda'), str(g[tag + '_which']), str(g[tag + '_arch']), str(g[tag + '_criterion'])))
+    seed_ops(model.netG.all_modules, model.netG.step_names, 4000)
+    model.netG.cuda()
+    data = (T(g[tag + '_img']), T(g[tag + '_gt']))
+    for it in range(2):
+        model.feed_data(data)
+        model.update_learning_rate(it, warmup_iter=-1)
+        model.optimize_parameters()
+        key = '%s_it%d_output' % (tag, it)
+        assert_error_budget(model.output, g[key], f[key], key, report=report)
+        for k, v in model.netG.named_parameters():
+            key = '%s_it%d_grad_%s' % (tag, it, k)
+            if key in g:
+                assert_error_budget(v.grad, g[key], f[key], key, report=report)
+        for k, v in model.netG.state_dict().items():
+            key = '%s_it%d_%s' % (tag, it, k)
+            # Adam normalises the step to ~lr whatever the gradient's magnitude: its fp32 noise is relative to lr = 1e-2
+            assert_error_budget(v, g[key], f[key], key, atol=1e-6, report=report)
+
+
+def _double(w):
+    return {k: v.double() for k, v in w.items()} if w is not None else None
+
+
+def test_reference_yaml_cnn_pipeline_within_budget(report):
+    """options/train/SID_isp.yml:28 (Path-Restore-Bayer -> proxy demosaic -> Gamma -> WbQuadratic -> WbManual), every
+    stage started from the SAME input (the GPU's previous stage), judged against the oracle in fp64 / fp32."""
+    from reconfigisp_amd.codes.models import networks
+    arch = 'Bayer_01_Demosaic_03_sRGB_01_13_11'
+    for infer in (True, False):
+        net = networks.define_G({'network_G': {'which_model_G': 'IspUniversal', 'architecture': arch, 'module_path': None,
+                                               'individual_module_paths': [None] * 8}})
+        seed_ops(net.all_modules, net.step_names, 500)
+        net = net.cuda().eval()
+        bay, _ = O.synthetic_raw(2, 64, 64, seed=4)
+        names = O.parse_architecture(arch)
+        wts = [O.make_weights('path14l_bayer', 500), O.make_weights('srcnn_demosaic', 501), None, None, None]
+        if infer:
+            with torch.no_grad():
+                net(bay.cuda())                                   # fused inference path, F(4,3) convolutions
+        else:
+            net(bay.cuda().requires_grad_(True))                  # training dispatch, F(2,3) convolutions
+        x = bay
+        for k, (name, got) in enumerate(zip(names, net.intermediate_results)):
+            par = None if not O.PARAM_INIT[name] else torch.sigmoid(torch.tensor(O.PARAM_INIT[name])).repeat(2, 1)
+            ref32 = O.apply_op(name, x, par, wts[k])
+            ref64 = O.apply_op(name, x.double(), None if par is None else par.double(), _double(wts[k]))
+            assert_error_budget(got, ref32, ref64, '%s stage %s' % ('infer' if infer else 'train', name), report=report)
+            x = got.detach().cpu()
