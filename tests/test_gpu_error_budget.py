@@ -13,22 +13,20 @@ import pytest
 import torch
 
 import isp_oracle as O
-from conftest import assert_error_budget, load_golden
+from conftest import ErrorBudget, load_golden
 from test_host_logic import T, build_supernet, darts_opt, isp_opt, seed_darts, seed_ops
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture
-def report():
-    rows = []
-    yield rows
-    if os.environ.get('RISP_BUDGET_REPORT') == '1':
-        for what, e_got, e_ref, scale in rows:
-            print('BUDGET %-40s hip %.3e  ref32 %.3e  ratio %6.2f  scale %.3g' % (what, e_got, e_ref, e_got / max(e_ref, 1e-30), scale))
+def budget():
+    b = ErrorBudget()
+    yield b
+    b.finish()
 
 
-def test_supernet_forward_and_gradients_within_budget(report):
+def test_supernet_forward_and_gradients_within_budget(budget):
     g, f = load_golden('supernet_n2'), load_golden('supernet_n2_f64')
     net = build_supernet(2, torch.device('cuda'))
     with torch.no_grad():
@@ -37,17 +35,17 @@ def test_supernet_forward_and_gradients_within_budget(report):
     y = net(T(g['x']).cuda())
     assert net.pruned_paths == list(f['pruned_paths'])
     for i, m in enumerate(net.intermediate_results):
-        assert_error_budget(m, g['mid%d' % i], f['mid%d' % i], 'slot %d' % i, report=report)
+        budget(m, g['mid%d' % i], f['mid%d' % i], 'slot %d' % i)
     named = dict(net.named_parameters())
     keys = sorted(named)
     grads = torch.autograd.grad(y, [named[k] for k in keys], T(g['gy']).cuda(), allow_unused=True)
     for k, gr in zip(keys, grads):
         gr = torch.zeros_like(named[k]) if gr is None else gr
-        assert_error_budget(gr, g['g_' + k], f['g_' + k], 'grad ' + k, report=report)
+        budget(gr, g['g_' + k], f['g_' + k], 'grad ' + k)
 
 
 @pytest.mark.filterwarnings('ignore:Detected call of')
-def test_darts_iterations_within_budget(report):
+def test_darts_iterations_within_budget(budget):
     from reconfigisp_amd.codes.models import create_model
     g, f = load_golden('darts_step'), load_golden('darts_step_f64')
     model = create_model(darts_opt(torch.device('cuda')))
@@ -57,20 +55,20 @@ def test_darts_iterations_within_budget(report):
         model.feed_data(data)
         model.update_learning_rate(it, warmup_iter=-1)
         model.optimize_alphas()
-        assert_error_budget(model.val_loss.reshape(1), g['it%d_val_loss' % it].reshape(1), f['it%d_val_loss' % it].reshape(1),
-                            'it%d val loss' % it, report=report)
+        budget(model.val_loss.reshape(1), g['it%d_val_loss' % it].reshape(1), f['it%d_val_loss' % it].reshape(1),
+                            'it%d val loss' % it)
         for k, a in enumerate(model.netG.alphas):
             key = 'it%d_alpha_grad%d' % (it, k)
-            assert_error_budget(a.grad, g[key], f[key], key, report=report)
+            budget(a.grad, g[key], f[key], key)
         model.optimize_parameters()
         for k, v in model.netG.state_dict().items():
             key = 'it%d_%s' % (it, k)
-            assert_error_budget(v, g[key], f[key], key, report=report)
+            budget(v, g[key], f[key], key)
 
 
 @pytest.mark.filterwarnings('ignore:Detected call of')
 @pytest.mark.parametrize('tag', ['a', 'b'])
-def test_isp_model_steps_within_budget(report, tag):
+def test_isp_model_steps_within_budget(budget, tag):
     from reconfigisp_amd.codes.models import create_model
     g, f = load_golden('isp_model'), load_golden('isp_model_f64')
     model = create_model(isp_opt(torch.device('cuda'), str(g[tag + '_which']), str(g[tag + '_arch']), str(g[tag + '_criterion'])))
@@ -82,22 +80,22 @@ def test_isp_model_steps_within_budget(report, tag):
         model.update_learning_rate(it, warmup_iter=-1)
         model.optimize_parameters()
         key = '%s_it%d_output' % (tag, it)
-        assert_error_budget(model.output, g[key], f[key], key, report=report)
+        budget(model.output, g[key], f[key], key)
         for k, v in model.netG.named_parameters():
             key = '%s_it%d_grad_%s' % (tag, it, k)
             if key in g:
-                assert_error_budget(v.grad, g[key], f[key], key, report=report)
+                budget(v.grad, g[key], f[key], key)
         for k, v in model.netG.state_dict().items():
             key = '%s_it%d_%s' % (tag, it, k)
             # Adam normalises the step to ~lr whatever the gradient's magnitude: its fp32 noise is relative to lr = 1e-2
-            assert_error_budget(v, g[key], f[key], key, atol=1e-6, report=report)
+            budget(v, g[key], f[key], key)
 
 
 def _double(w):
     return {k: v.double() for k, v in w.items()} if w is not None else None
 
 
-def test_reference_yaml_cnn_pipeline_within_budget(report):
+def test_reference_yaml_cnn_pipeline_within_budget(budget):
     """options/train/SID_isp.yml:28 (Path-Restore-Bayer -> proxy demosaic -> Gamma -> WbQuadratic -> WbManual), every
     stage started from the SAME input (the GPU's previous stage), judged against the oracle in fp64 / fp32."""
     from reconfigisp_amd.codes.models import networks
@@ -120,5 +118,5 @@ def test_reference_yaml_cnn_pipeline_within_budget(report):
             par = None if not O.PARAM_INIT[name] else torch.sigmoid(torch.tensor(O.PARAM_INIT[name])).repeat(2, 1)
             ref32 = O.apply_op(name, x, par, wts[k])
             ref64 = O.apply_op(name, x.double(), None if par is None else par.double(), _double(wts[k]))
-            assert_error_budget(got, ref32, ref64, '%s stage %s' % ('infer' if infer else 'train', name), report=report)
+            budget(got, ref32, ref64, '%s stage %s' % ('infer' if infer else 'train', name))
             x = got.detach().cpu()
