@@ -48,15 +48,24 @@ def assert_close(a, b, rtol=1e-4, atol=1e-6, what='', floor=0.05):
 
 
 class ErrorBudget:
-    """Measured fp32 error budget: a float64 evaluation of the same graph is the truth, the reference's own float32
-    result shows what fp32 arithmetic costs on this quantity, and the HIP result may cost at most ``factor`` times
-    that (+ atol x max(1, max|truth|)):   max|got - ref64| <= factor * max|ref32 - ref64| + atol * scale.
+    """Measured fp32 error budget.  A float64 evaluation of the same graph is the truth; the reference's (or the
+    oracle's) own float32 result shows what fp32 arithmetic costs; the HIP result may cost at most ``factor`` times that:
+
+        max|hip - fp64| / scale  <=  factor * E_ref(family) + atol,      scale = max(1, max|fp64|)
+
+    E_ref(family) is the LARGEST relative fp32 error of the reference over the quantities of one family (slot outputs,
+    architecture gradients, parameter gradients, ...) in the test.  Per family, not per tensor, because everything
+    downstream of a ReLU mask is discontinuous in the pre-activations: a pre-activation within an ulp of zero is
+    clipped by one fp32 implementation and not by another, and which tensor that lands in is arbitrary (measured: the
+    reference is 1.2e-4 off on the second DARTS iteration's architecture gradients and 8e-7 on the first's; the HIP
+    path the other way round).  ``atol`` = 4e-6 (64 ulp of the tensor's magnitude) covers the hardware exp2 / log2
+    approximations and the fixed summation order of the reductions.  The north-star bar is 1e-4.
     Checks are collected; ``finish()`` fails with the full list (RISP_BUDGET_REPORT=1 prints every measured pair)."""
 
     def __init__(self, factor=2.0, atol=4e-6):
         self.factor, self.atol, self.rows = factor, atol, []
 
-    def __call__(self, got, ref32, ref64, what='', atol=None):
+    def __call__(self, got, ref32, ref64, what='', family=None):
         import torch
         tonp = lambda v: np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, np.float64)
         got, ref32, ref64 = tonp(got), tonp(ref32), tonp(ref64)
@@ -64,14 +73,19 @@ class ErrorBudget:
         if not got.size:
             return
         scale = max(1.0, np.abs(ref64).max())
-        e_got, e_ref = np.abs(got - ref64).max(), np.abs(ref32 - ref64).max()
-        bound = self.factor * e_ref + (self.atol if atol is None else atol) * scale
-        self.rows.append((what, e_got, e_ref, scale, e_got <= bound))
+        self.rows.append((what, np.abs(got - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale, family or what))
 
     def finish(self):
-        if os.environ.get('RISP_BUDGET_REPORT') == '1':
-            for what, e_got, e_ref, scale, ok in self.rows:
-                print('BUDGET %-40s hip %.3e  ref32 %.3e  ratio %7.2f  hip/scale %.2e %s' % (
-                    what, e_got, e_ref, e_got / max(e_ref, 1e-30), e_got / scale, '' if ok else '  <-- OVER'))
-        bad = ['%s: |hip - fp64| = %.3e, |reference fp32 - fp64| = %.3e, scale %.3g' % r[:4] for r in self.rows if not r[4]]
-        assert not bad, 'over the fp32 error budget (%.1f x reference + %.1e x scale):\n  ' % (self.factor, self.atol) + '\n  '.join(bad)
+        fam = {}
+        for _, _, e_ref, family in self.rows:
+            fam[family] = max(fam.get(family, 0.0), e_ref)
+        bad = []
+        for what, e_got, e_ref, family in self.rows:
+            ok = e_got <= self.factor * fam[family] + self.atol
+            if os.environ.get('RISP_BUDGET_REPORT') == '1':
+                print('BUDGET %-40s hip %.2e  ref32 %.2e  family %-12s %.2e %s' % (what, e_got, e_ref, family, fam[family],
+                                                                                  '' if ok else '  <-- OVER'))
+            if not ok:
+                bad.append('%s: |hip - fp64| = %.3e of scale; reference fp32: %.3e (family %s: %.3e)' % (
+                    what, e_got, e_ref, family, fam[family]))
+        assert not bad, 'over the fp32 error budget (%.1f x reference + %.1e):\n  ' % (self.factor, self.atol) + '\n  '.join(bad)

@@ -169,7 +169,9 @@ def test_darts_search_step_matches_reference(dev):
         model.optimize_alphas()
         assert_close(model.val_loss, g['it%d_val_loss' % it], rtol=2e-4, what='val loss')
         for k, a in enumerate(model.netG.alphas):
-            assert_close(a.grad, g['it%d_alpha_grad%d' % (it, k)], rtol=5e-3, atol=1e-7, what='alpha grad %d' % k)
+            # fp32 vs fp32: both sides carry up to ~1.2e-4 of fp32 error on these (tests/test_gpu_error_budget.py measures
+            # each against float64); 5e-4 of the gradient's magnitude bounds their sum
+            assert_close(a.grad, g['it%d_alpha_grad%d' % (it, k)], rtol=5e-4, atol=1e-7, what='alpha grad %d' % k)
         model.optimize_parameters()
         assert abs(model.log_dict['loss'] - float(g['it%d_loss' % it])) <= 2e-4 * abs(float(g['it%d_loss' % it]))
         for k, v in model.netG.state_dict().items():
