@@ -255,6 +255,41 @@ int risp_cond_fc_bwd(const float *flat, const int *widths, int n_layers, const f
                      float *deltas, float *dflat, int total_params, int N, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * One training step of an element-wise fixed pipeline in two launches - replaces the body of
+ * IspModel.optimize_parameters (models/isp_model.py:128-142: output = netG(img); l_pix = cri_pix(output, gt);
+ * zero_grad(); l_pix.backward(); optimizer_G.step()) when netG is [nearest demosaic ->] a chain of WbManual / Gamma /
+ * GtmManual / WbQuadratic stages (isp_universal.py:210-232), cri_pix is nn.MSELoss or nn.L1Loss (mean) and
+ * optimizer_G is torch.optim.Adam without weight decay / amsgrad.  Forward, loss, backward (stage inputs kept in
+ * registers), the parameter-gradient reduction (deterministic), the chain rule through sigmoid(raw).repeat(N,1)
+ * [* 5 for WbManual] and the Adam update all happen on the device; only in, gt and y touch HBM.
+ * ------------------------------------------------------------------------- */
+#define RISP_MAX_TRAIN_CHAIN 6
+typedef struct risp_train_desc {
+    const float *in;                              /* (N,1,H,W) RGGB mosaic if from_bayer, else (N,3,H,W) BGR */
+    const float *gt;                              /* (N,3,H,W) */
+    float *y;                                     /* (N,3,H,W) pipeline output (IspModel.output); may be NULL */
+    int from_bayer;                               /* a nearest-neighbour demosaic (tools_origin.py:278-284) in front */
+    int n_ops;                                    /* parametrised stages, 1..RISP_MAX_TRAIN_CHAIN */
+    int ops[RISP_MAX_TRAIN_CHAIN];                /* RISP_OP_WB_MANUAL / GAMMA / GTM_MANUAL / WB_QUADRATIC (at most one) */
+    float *blocks[RISP_MAX_TRAIN_CHAIN];          /* (N,P_k) per-image parameter blocks the stages read = sigmoid(raw)
+                                                     .repeat(N,1) (x 5 for WbManual); REWRITTEN for the next step */
+    float *raw[RISP_MAX_TRAIN_CHAIN];             /* (P_k) learnable vectors (param_step<k>_<name>): updated in place */
+    float *grad[RISP_MAX_TRAIN_CHAIN];            /* (P_k) d loss / d raw: what .grad holds after backward() */
+    float *exp_avg[RISP_MAX_TRAIN_CHAIN];         /* (P_k) Adam first moment, updated in place */
+    float *exp_avg_sq[RISP_MAX_TRAIN_CHAIN];      /* (P_k) Adam second moment, updated in place */
+    int loss_kind;                                /* 0 = nn.MSELoss, 1 = nn.L1Loss (mean reduction) */
+    int N, H, W;                                  /* H, W even */
+    float lr_step;                                /* lr / (1 - beta1^t), t = this step's number (1-based) */
+    float beta1, beta2;
+    float bias2_sqrt;                             /* sqrt(1 - beta2^t) */
+    float eps;
+    float *loss;                                  /* 1 float: the mean loss of this step */
+    float *scratch;                               /* risp_train_scratch_floats(N) floats */
+} risp_train_desc;
+size_t risp_train_scratch_floats(int N);
+int risp_chain_train_step(const risp_train_desc *d, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Overlapped tiling (utils/util_path_restore.py:47-134), NCHW on device.
  * positions: host int32 [T][2] (y,x).
  * ------------------------------------------------------------------------- */

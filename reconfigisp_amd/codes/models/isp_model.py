@@ -43,6 +43,7 @@ class IspModel(BaseModel):
         self.print_network()
         self.load()
         self.img = self.gt = self.output = self.val_img = self.val_gt = self.l_pix = self.meta = None
+        self._fused = None
         if self.is_train:
             train_opt = opt['train']
             self.netG.train()
@@ -87,7 +88,25 @@ class IspModel(BaseModel):
     def _forward(self):
         return self.netG(self.img) if self.meta is None else self.netG(self.img, self.meta)
 
+    def _fused_step(self):
+        """The two-launch training step (reconfigisp_amd/train_step.py) when the pipeline, the criterion and the
+        optimiser have a fused form; None -> the op-by-op autograd path below.  ``train.fused_step: false`` disables
+        it.  (The fused step does not materialise netG.intermediate_results; call test() for them.)"""
+        if self._fused is None:
+            from ...train_step import FusedIspStep
+            enabled = self.opt['train'].get('fused_step', True) if hasattr(self.opt['train'], 'get') else True
+            on_gpu = self.device.type == 'cuda'
+            self._fused = (FusedIspStep.build(self.netG, self.cri_pix, self.optimizer_G) if enabled and on_gpu else None) or False
+        return self._fused or None
+
     def optimize_parameters(self):
+        fused = self._fused_step() if self.meta is None else None
+        if fused is not None and fused.accepts(self.img, self.gt):
+            self.output, loss = fused(self.img, self.gt)
+            self.l_pix = loss
+            self.log_dict['loss'] = loss
+            self.netG.intermediate_results = []
+            return
         self.output = self._forward()
         self.l_pix = self.cri_pix(self.output, self.gt)
         self.optimizer_G.zero_grad()

@@ -611,14 +611,12 @@ int launch_wino(const risp_conv_desc &d, hipStream_t s) {
     if (lds < epi) lds = epi;
     dim3 grid((d.W + WTW - 1) / WTW, (d.H + WTH - 1) / WTH, d.N);
     if (lds > 64 * 1024) {                              // gfx950: 160 KB of LDS per CU, two workgroups share it
-        static bool raised = false;                     // benign race: the attribute is idempotent
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino3_kernel<CK, CB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-                risp_set_error("risp_conv2d_wino3: cannot raise the dynamic LDS limit to %zu bytes", lds);
-                return 2;
-            }
-            raised = true;
+        // set on every launch (idempotent, a host-side table update): the library keeps no mutable state of its own,
+        // as include/risp.h promises
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino3_kernel<CK, CB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            risp_set_error("risp_conv2d_wino3: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            return 2;
         }
     }
     hipLaunchKernelGGL((conv_wino3_kernel<CK, CB>), grid, dim3(256), lds, s, d);

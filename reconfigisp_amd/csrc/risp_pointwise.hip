@@ -3,7 +3,8 @@
 // All of these are HBM-bound: every thread moves 16-byte vectors (float4) of planar
 // NCHW data, consecutive lanes touch consecutive 16-byte slots (1 KiB per wave
 // instruction), per-image parameters are wave-uniform (scalar loads), and parameter
-// gradients are reduced wave -> LDS -> one atomic per block.
+// gradients are reduced registers -> 64-lane shuffles -> LDS -> one partial row per workgroup in a caller-provided
+// scratch buffer that a second launch adds in index order (bit-repeatable; no float atomics).
 //
 // Reference arithmetic (codes/models/modules/tools_origin.py): WbQuadratic :317-359,
 // GtmManual :414-440; plugin-backed ops follow the build-defined OPSPEC restated in

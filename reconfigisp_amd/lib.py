@@ -27,6 +27,18 @@ class ConvDesc(C.Structure):
                 ('y', _f)]
 
 
+TRAIN_MAX = 6
+
+
+class TrainDesc(C.Structure):
+    """mirror of risp_train_desc"""
+    _fields_ = [('in_', _f), ('gt', _f), ('y', _f), ('from_bayer', _i), ('n_ops', _i), ('ops', _i * TRAIN_MAX),
+                ('blocks', _f * TRAIN_MAX), ('raw', _f * TRAIN_MAX), ('grad', _f * TRAIN_MAX),
+                ('exp_avg', _f * TRAIN_MAX), ('exp_avg_sq', _f * TRAIN_MAX), ('loss_kind', _i),
+                ('N', _i), ('H', _i), ('W', _i), ('lr_step', _fl), ('beta1', _fl), ('beta2', _fl),
+                ('bias2_sqrt', _fl), ('eps', _fl), ('loss', _f), ('scratch', _f)]
+
+
 def _pw(n_extra=0):
     # forward: (x, p, y, N, HW, stream); backward (n_extra = 3): (x, p, gy, gx, gp, scratch, N, HW, stream)
     return [_f] * (3 + n_extra) + [_i, _i, _s]
@@ -91,6 +103,8 @@ SIGNATURES = {
     'risp_gt_crop': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _s]),
     'risp_resize_rggb': (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _s]),
     'risp_sse_uint8': (_i, [_f, _f, _f, _z, _s]),
+    'risp_train_scratch_floats': (_z, [_i]),
+    'risp_chain_train_step': (_i, [C.POINTER(TrainDesc), _s]),
 }
 
 _lib = None
