@@ -44,7 +44,10 @@ def test_fused_step_equals_autograd_step(arch, crit, shape):
             m.update_learning_rate(it, warmup_iter=-1)
             m.optimize_parameters()
         assert fused._fused and not plain._fused               # the fused model really took the fused path
-        assert torch.equal(fused.output, plain.output), 'it %d: outputs differ by %g' % (it, (fused.output - plain.output).abs().max())
+        diff = (fused.output - plain.output.detach()).abs().max().item()
+        # same per-pixel forward maps: bit-identical while the parameters are; afterwards the two Adam implementations
+        # have drifted apart by a few 1e-7 (checked below), and the outputs with them
+        assert diff == 0.0 if it == 0 else diff <= 1e-5, 'it %d: outputs differ by %g' % (it, diff)
         lf, lp = float(fused.log_dict['loss']), float(plain.log_dict['loss'])
         assert abs(lf - lp) <= 2e-6 * abs(lp), (lf, lp)
         for (k, a), b in zip(fused.netG.named_parameters(), plain.netG.parameters()):
