@@ -62,7 +62,8 @@ def test_fused_step_equals_autograd_step(arch, crit, shape):
             assert float(sa['state'][key]['step']) == float(sb['state'][key]['step']) == it + 1
             for name in ('exp_avg', 'exp_avg_sq'):
                 x, y = sa['state'][key][name], sb['state'][key][name]
-                assert (x - y).abs().max().item() <= 2e-6 * max(1e-6, y.abs().max().item()) + 1e-12, (it, key, name)
+                # gradients agree to ~2e-6 of their magnitude (above); the second moment squares them
+                assert (x - y).abs().max().item() <= 1e-5 * max(1e-6, y.abs().max().item()) + 1e-12, (it, key, name)
     # inference afterwards sees the updated parameters (the cached per-image blocks are keyed on the version counter)
     yf, _ = fused.test()
     yp, _ = plain.test()
