@@ -1,9 +1,10 @@
 """create_dataset / create_dataloader - mirror of the reference's data/__init__.py:9-53.
 
-Only the synthetic RAW source is built (mode 'Synthetic_RGGB2BGR'): the reference's six dataset
-classes read PNG / lmdb / memcached files through cv2 and are real-dataset I/O outside the hot path
-(SURVEY.md section 2 row 14).  The loader contract is theirs: train loaders shard ``batch_size`` over
-the ranks and drop the last batch, test loaders yield one image at a time."""
+Modes: 'Synthetic_RGGB2BGR' (no files needed) and the reference's four RGGB -> BGR datasets
+(SID_Sony_Ratio[_Test]_RGGB2BGR, S7ISP_RGGB2BGR[_Test]; data/rggb2bgr_datasets.py - .png / .npy frames read without
+cv2, lmdb when the module is present).  The two OnePlus_Rggb2Obj modes feed the YOLOv3 detection loss, which is
+outside the hot-path scope, and raise.  The loader contract is the reference's: train loaders
+shard ``batch_size`` over the ranks and drop the last batch, test loaders yield one image at a time."""
 import logging
 
 import torch
@@ -11,8 +12,8 @@ import torch.distributed as dist
 import torch.utils.data
 from torch.utils.data.dataloader import default_collate
 
-_FILE_BACKED = ('SID_Sony_Ratio_RGGB2BGR', 'SID_Sony_Ratio_Test_RGGB2BGR', 'S7ISP_RGGB2BGR', 'S7ISP_RGGB2BGR_Test',
-                'OnePlus_Rggb2Obj', 'OnePlus_Rggb2Obj_Test')
+_RGGB2BGR = ('SID_Sony_Ratio_RGGB2BGR', 'SID_Sony_Ratio_Test_RGGB2BGR', 'S7ISP_RGGB2BGR', 'S7ISP_RGGB2BGR_Test')
+_DETECTION = ('OnePlus_Rggb2Obj', 'OnePlus_Rggb2Obj_Test')
 
 
 def create_dataloader(dataset, dataset_opt, opt=None, sampler=None, collate_fn=None):
@@ -37,10 +38,12 @@ def create_dataset(dataset_opt):
     mode = dataset_opt['mode']
     if mode == 'Synthetic_RGGB2BGR':
         from .synthetic_raw import SyntheticRawDataset as D
-    elif mode in _FILE_BACKED:
+    elif mode in _RGGB2BGR:
+        from .rggb2bgr_datasets import Rggb2BgrDataset as D
+    elif mode in _DETECTION:
         raise NotImplementedError(
-            'Dataset [{:s}] reads image files through cv2/lmdb and is outside the scope of this build; use mode '
-            'Synthetic_RGGB2BGR (same tensor contract: noisy (1,H,W) in [0,1], gt (3,H,W)).'.format(mode))
+            'Dataset [{:s}] pairs RAW frames with detection labels for the YOLOv3 task loss, which is outside the scope '
+            'of this build; the RGGB2BGR modes and Synthetic_RGGB2BGR are available.'.format(mode))
     else:
         raise NotImplementedError('Dataset [{:s}] is not recognized.'.format(mode))
     dataset = D(dataset_opt)

@@ -35,7 +35,7 @@ def test_synthetic_raw_contract():
     with pytest.raises(NotImplementedError, match='not recognized'):
         create_dataset({'mode': 'nope'})
     with pytest.raises(NotImplementedError, match='outside the scope'):
-        create_dataset({'mode': 'OnePlus_Rggb2Obj'})
+        create_dataset({'mode': 'OnePlus_Rggb2Obj'})                 # detection labels for the YOLOv3 loss
 
 
 def test_test_driver_end_to_end(monkeypatch, tmp_path, capsys):
@@ -76,3 +76,93 @@ def test_alias_install():
         sys.modules.pop(name, None)
     for name in [k for k in sys.modules if k.split('.')[0] in ('models', 'options', 'utils', 'data')]:
         sys.modules.pop(name, None)
+
+
+def test_png_reader_round_trip_and_filters(tmp_path):
+    """data/image_io.py against hand-built files: every scan-line filter type, 8/16 bit, grey / RGB / RGBA."""
+    import struct, zlib
+    from reconfigisp_amd.codes.data.image_io import read_image, read_png, write_png
+    rng = np.random.default_rng(0)
+    g16 = rng.integers(0, 16384, size=(10, 14), dtype=np.uint16)
+    bgr = rng.integers(0, 256, size=(9, 7, 3), dtype=np.uint8)
+    write_png(str(tmp_path / 'g.png'), g16)
+    write_png(str(tmp_path / 'c.png'), bgr)
+    assert np.array_equal(read_image(str(tmp_path / 'g.png')), g16) and read_png(str(tmp_path / 'g.png')).dtype == np.uint16
+    assert np.array_equal(read_image(str(tmp_path / 'c.png')), bgr)              # BGR in, BGR out (file holds RGB)
+    np.save(str(tmp_path / 'f.npy'), g16)
+    assert np.array_equal(read_image(str(tmp_path / 'f.npy')), g16)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+    def encode(rows, bpp, ftypes):                   # the PNG specification's filters, applied forwards
+        out, prev = b'', [0] * len(rows[0])
+        for y, row in enumerate(rows):
+            ft, line = ftypes[y % len(ftypes)], []
+            for i, v in enumerate(row):
+                a = row[i - bpp] if i >= bpp else 0
+                b, c = prev[i], (prev[i - bpp] if i >= bpp else 0)
+                pred = {0: 0, 1: a, 2: b, 3: (a + b) >> 1, 4: paeth(a, b, c)}[ft]
+                line.append((v - pred) & 0xFF)
+            out += bytes([ft]) + bytes(line)
+            prev = row
+        return out
+
+    def chunk(kind, payload):
+        return struct.pack('>I', len(payload)) + kind + payload + struct.pack('>I', zlib.crc32(kind + payload) & 0xFFFFFFFF)
+
+    for ch, ctype, depth in ((1, 0, 16), (3, 2, 8), (4, 6, 8), (1, 0, 8)):
+        h, w = 11, 6
+        img = rng.integers(0, 2 ** depth, size=(h, w, ch)).astype(np.uint16 if depth == 16 else np.uint8)
+        raw = img.astype('>u2').view(np.uint8).reshape(h, -1) if depth == 16 else img.reshape(h, -1)
+        body = encode([r.tolist() for r in raw], ch * depth // 8, [0, 1, 2, 3, 4])
+        path = str(tmp_path / ('t%d_%d.png' % (ctype, depth)))
+        with open(path, 'wb') as f:
+            f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, depth, ctype, 0, 0, 0)) +
+                    chunk(b'IDAT', zlib.compress(body)) + chunk(b'IEND', b''))
+        got = read_png(path)
+        want = img[..., 0] if ch == 1 else img[..., [2, 1, 0] + ([3] if ch == 4 else [])]
+        assert got.dtype == img.dtype and np.array_equal(got, want), (ctype, depth)
+
+
+def test_file_backed_rggb2bgr_datasets(tmp_path):
+    """The reference's four RGGB2BGR dataset modes (data/*_rggb2bgr*_dataset.py) on a tiny on-disk dataset."""
+    import pickle, random
+    from reconfigisp_amd.codes.data import create_dataloader, create_dataset
+    from reconfigisp_amd.codes.data.image_io import write_png
+    rng = np.random.default_rng(1)
+    root = tmp_path / 'sid'
+    root.mkdir()
+    keys_n, keys_g, frames = [], [], {}
+    for i, (ein, egt) in enumerate((('0.1s', '10s'), ('0.04s', '10s'), ('0.1s', '30s'))):
+        kn, kg = 'n%d_%s.png' % (i, ein), 'g%d_%s.png' % (i, egt)
+        raw = rng.integers(0, 16384, size=(24, 24), dtype=np.uint16)
+        gt = rng.integers(0, 256, size=(24, 24, 3), dtype=np.uint8)
+        write_png(str(root / kn), raw)
+        write_png(str(root / kg), gt)
+        keys_n.append(kn); keys_g.append(kg); frames[kn] = (raw, gt)
+    with open(root / 'meta_info.pkl', 'wb') as f:
+        pickle.dump({'keys_ratio': keys_n, 'keys_noisy': keys_n, 'keys_gt': keys_g, 'resolution': 24}, f)
+    base = {'dataroot': str(root), 'data_type': 'img', 'data_size': 8, 'sid_expo_in': '0.1s', 'sid_expo_gt': '10s'}
+    ds = create_dataset(dict(base, mode='SID_Sony_Ratio_RGGB2BGR', phase='train'))
+    assert len(ds) == 1                                             # exposure filter keeps the (0.1s, 10s) pair only
+    random.seed(4)
+    item = ds[0]
+    random.seed(4)
+    r = (random.randint(0, 16) // 2) * 2
+    c = (random.randint(0, 16) // 2) * 2
+    raw, gt = frames[keys_n[0]]
+    assert item['noisy'].shape == (1, 8, 8) and item['noisy'].dtype == np.float32 and 'name' not in item
+    assert np.array_equal(item['noisy'][0], raw[r:r + 8, c:c + 8].astype(np.float32) / np.float32(16383.))
+    assert np.array_equal(item['gt'], np.transpose(gt[r:r + 8, c:c + 8], (2, 0, 1)).astype(np.float32) / np.float32(255.))
+    test = create_dataset(dict(base, mode='SID_Sony_Ratio_Test_RGGB2BGR', phase='test', sid_expo_in=None, sid_expo_gt=None))
+    assert len(test) == 3 and test[1]['name'] == 'n1_0.04s' and test[1]['noisy'].shape == (1, 8, 8)     # top-left corner
+    s7 = create_dataset(dict(base, mode='S7ISP_RGGB2BGR', phase='train'))
+    assert len(s7) == 3 and float(s7[2]['noisy'].max()) > 1.0       # /1023: the caller's data decides the range
+    s7t = create_dataset(dict(base, mode='S7ISP_RGGB2BGR_Test', phase='test'))
+    batch = next(iter(create_dataloader(s7t, {'phase': 'test'})))
+    assert batch['noisy'].shape == (1, 1, 24, 24) and batch['gt'].shape == (1, 3, 24, 24) and batch['name'] == ['n0_0.1s']
+    with pytest.raises(NotImplementedError, match='memcached'):
+        create_dataset(dict(base, mode='S7ISP_RGGB2BGR', data_type='mc'))
