@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int co = (lane >> 3) + 8 * i;
-            bq[i] = (!(epi & RISP_EPI_NOBIAS) && co < d.cout) ? pbias[co] : 0.f;
+            bq[i] = 0.f;
+            if (!(epi & RISP_EPI_NOBIAS)) bq[i] = pbias[co < d.cout ? co : d.cout - 1];      // uniform branch, clamped address
         }
         const int q4 = 4 * (lane & 7);
         // RISP_EPI_CASEBIAS: a (cout, KS, KS) table per image (d.cvals) indexed by how close the pixel is to the
@@ -317,17 +318,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
             __builtin_amdgcn_wave_barrier();
             const bool row_ok = oy < d.H && x0 + q4 < d.W;
             float4 v[NV], av[NV], mv[NV];
+            // Residual and mask values: unconditional loads from clamped (always valid) addresses inside wave-uniform
+            // branches, all NV issued before the first use.  Written as per-element "cond ? load : 0" hipcc branches
+            // around every load and waits vmcnt(0) behind each - and behind the previous row's stores.
+            const size_t pix = row_ok ? (size_t)oy * d.W + x0 + q4 : 0;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int co = (lane >> 3) + 8 * i;
-                v[i] = *reinterpret_cast<const float4 *>(tile + co * 32 + q4);
-                const size_t pix = (size_t)oy * d.W + x0 + q4;
-                av[i] = (row_ok && (epi & RISP_EPI_ADD) && co < d.add_c)
-                            ? *reinterpret_cast<const float4 *>(padd + ((size_t)n * d.add_c + co) * plane + pix)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-                mv[i] = (row_ok && (epi & RISP_EPI_MASK) && co < d.cout)
-                            ? *reinterpret_cast<const float4 *>(pmask + ((size_t)n * d.cout + co) * plane + pix)
-                            : make_float4(1.f, 1.f, 1.f, 1.f);
+                v[i] = *reinterpret_cast<const float4 *>(tile + ((lane >> 3) + 8 * i) * 32 + q4);
+                av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                mv[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+            if (epi & RISP_EPI_ADD) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int co = (lane >> 3) + 8 * i, cc = co < d.add_c ? co : d.add_c - 1;
+                    const float4 a = *reinterpret_cast<const float4 *>(padd + ((size_t)n * d.add_c + cc) * plane + pix);
+                    if (co < d.add_c) av[i] = a;
+                }
+            }
+            if (epi & RISP_EPI_MASK) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int co = (lane >> 3) + 8 * i, cc = co < d.cout ? co : d.cout - 1;
+                    mv[i] = *reinterpret_cast<const float4 *>(pmask + ((size_t)n * d.cout + cc) * plane + pix);
+                }
             }
 #pragma unroll
             for (int i = 0; i < NV; ++i) {

@@ -42,6 +42,66 @@ constexpr int WTW = 64, WTH = 4;               // output tile: 64 pixels (32 pai
 constexpr int WIH = WTH + 2, WIWP = WTW + 8;    // staged rows / row stride: column c <-> image x0 - 4 + c
 constexpr int WTAPS = 12;                       // 3 filter rows x 4 transform points
 
+
+// ---- store one 32-cout block of a wave's output row (64 pixels) from its private LDS transposition tile
+// [32 couts][64 pixels]: lane -> 4 consecutive pixels of cout rows (lane >> 4) + 4 i, i = 0..7.  Bias, residual and
+// mask values of four rows are loaded unconditionally (clamped addresses) inside wave-uniform branches, one batch
+// ahead of the arithmetic; per-element "if (epi & ADD) load" code makes hipcc wait vmcnt(0) after every load and
+// behind every earlier store (8 x 3 dependent round trips per block).
+__device__ __forceinline__ void store_block32(const risp_conv_desc &d, const float *tile, int lane, int n, int cbase, int oy,
+                                              int x0) {
+    const int q4 = 4 * (lane & 15);                    // this lane's 4 pixels inside the row
+    if (!(oy < d.H && x0 + q4 < d.W)) return;
+    const int epi = d.epilogue;
+    const size_t hw = (size_t)d.H * d.W, pix = (size_t)oy * d.W + x0 + q4;
+    const bool has_add = (epi & RISP_EPI_ADD) != 0, has_mask = (epi & RISP_EPI_MASK) != 0, has_bias = !(epi & RISP_EPI_NOBIAS);
+    float bias[2][4];
+    float4 av[2][4], mv[2][4];
+    auto load_batch = [&](int b, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = cbase + (lane >> 4) + 4 * (4 * b + i);
+            const int cc = co < d.cout ? co : d.cout - 1;                     // clamped: always a valid address
+            bias[slot][i] = has_bias ? d.bias[cc] : 0.f;
+            if (has_mask) mv[slot][i] = *reinterpret_cast<const float4 *>(d.mask + ((size_t)n * d.cout + cc) * hw + pix);
+            if (has_add) {
+                const int ca = co < d.add_c ? co : d.add_c - 1;
+                av[slot][i] = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + ca) * hw + pix);
+            }
+        }
+    };
+    load_batch(0, 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0) load_batch(1, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = (lane >> 4) + 4 * (4 * b + i), co = cbase + col;
+            float4 o = *reinterpret_cast<const float4 *>(tile + col * WTW + q4);
+            const float bb = bias[b][i];
+            o.x += bb; o.y += bb; o.z += bb; o.w += bb;
+            if (has_add && co < d.add_c) {
+                const float4 a = av[b][i];
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            if (epi & RISP_EPI_RELU) {
+                o.x = o.x > 0.f ? o.x : 0.f;
+                o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f;
+                o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            if (has_mask) {
+                const float4 m = mv[b][i];
+                o.x = m.x > 0.f ? o.x : 0.f;
+                o.y = m.y > 0.f ? o.y : 0.f;
+                o.z = m.z > 0.f ? o.z : 0.f;
+                o.w = m.w > 0.f ? o.w : 0.f;
+            }
+            if (co < d.cout) *reinterpret_cast<float4 *>(d.y + ((size_t)n * d.cout + co) * hw + pix) = o;
+        }
+    }
+}
+
 template <int CK, int CB>
 __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc d) {
     constexpr int CP = 32 * CB;
@@ -171,15 +231,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
     // ---- epilogue.  Lane holds m_t[cout = cb*32 + (e&3) + 8*(e>>2) + 4*half][pair = l31]; the output row of the
     // wave (CP couts x 64 pixels) is transposed through LDS one cout block at a time so that each lane owns 4
     // consecutive pixels of one cout plane: residual / mask loads and the stores are 16 bytes per lane.
-    const int epi = d.epilogue;
-    const float *__restrict__ pbias = d.bias;
-    const float *__restrict__ padd = d.add;
-    const float *__restrict__ pmask = d.mask;
-    float *__restrict__ py = d.y;
     const int oy = y0 + wave;
     __syncthreads();                                   // every wave is done with the staging tiles
     float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
-    const int q4 = 4 * (lane & 15);                    // this lane's 4 pixels inside the row
 #pragma unroll
     for (int c = 0; c < CB; ++c) {
 #pragma unroll
@@ -192,34 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc
             *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
         }
         __builtin_amdgcn_wave_barrier();               // private tile, in-order LDS: keep the compiler from reordering
-        const bool row_ok = oy < d.H && x0 + q4 < d.W;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {                  // 32 couts x 16 float4 = 512 float4 / 64 lanes
-            const int col = (lane >> 4) + 4 * i, co = c * 32 + col;
-            float4 o = *reinterpret_cast<const float4 *>(tile + col * WTW + q4);
-            if (!(row_ok && co < d.cout)) continue;
-            const size_t off = ((size_t)n * d.cout + co) * hw + (size_t)oy * d.W + x0 + q4;
-            const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : pbias[co];
-            o.x += b; o.y += b; o.z += b; o.w += b;
-            if ((epi & RISP_EPI_ADD) && co < d.add_c) {
-                const float4 a = *reinterpret_cast<const float4 *>(padd + ((size_t)n * d.add_c + co) * hw + (size_t)oy * d.W + x0 + q4);
-                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-            }
-            if (epi & RISP_EPI_RELU) {
-                o.x = o.x > 0.f ? o.x : 0.f;
-                o.y = o.y > 0.f ? o.y : 0.f;
-                o.z = o.z > 0.f ? o.z : 0.f;
-                o.w = o.w > 0.f ? o.w : 0.f;
-            }
-            if (epi & RISP_EPI_MASK) {
-                const float4 m = *reinterpret_cast<const float4 *>(pmask + off);
-                o.x = m.x > 0.f ? o.x : 0.f;
-                o.y = m.y > 0.f ? o.y : 0.f;
-                o.z = m.z > 0.f ? o.z : 0.f;
-                o.w = m.w > 0.f ? o.w : 0.f;
-            }
-            *reinterpret_cast<float4 *>(py + off) = o;
-        }
+        store_block32(d, tile, lane, n, c * 32, oy, x0);
         __builtin_amdgcn_wave_barrier();               // the tile is rewritten by the next cout block
     }
 #ifdef RISP_CONV_STAMPS
@@ -362,15 +389,9 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
     }
 
     // ---- epilogue (as conv_wino3_kernel, one cout block)
-    const int epi = d.epilogue;
-    const float *__restrict__ pbias = d.bias;
-    const float *__restrict__ padd = d.add;
-    const float *__restrict__ pmask = d.mask;
-    float *__restrict__ py = d.y;
     const int oy = y0 + wave;
     __syncthreads();                                   // every wave is done with the staging tiles
     float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
-    const int q4 = 4 * (lane & 15);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int col = (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -381,34 +402,7 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
         *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
     }
     __builtin_amdgcn_wave_barrier();
-    const bool row_ok = oy < d.H && x0 + q4 < d.W;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {                      // 32 couts x 16 float4 = 512 float4 / 64 lanes
-        const int col = (lane >> 4) + 4 * i, co = cb * 32 + col;
-        float4 o = *reinterpret_cast<const float4 *>(tile + col * WTW + q4);
-        if (!(row_ok && co < d.cout)) continue;
-        const size_t off = ((size_t)n * d.cout + co) * hw + (size_t)oy * d.W + x0 + q4;
-        const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : pbias[co];
-        o.x += b; o.y += b; o.z += b; o.w += b;
-        if ((epi & RISP_EPI_ADD) && co < d.add_c) {
-            const float4 a = *reinterpret_cast<const float4 *>(padd + ((size_t)n * d.add_c + co) * hw + (size_t)oy * d.W + x0 + q4);
-            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-        }
-        if (epi & RISP_EPI_RELU) {
-            o.x = o.x > 0.f ? o.x : 0.f;
-            o.y = o.y > 0.f ? o.y : 0.f;
-            o.z = o.z > 0.f ? o.z : 0.f;
-            o.w = o.w > 0.f ? o.w : 0.f;
-        }
-        if (epi & RISP_EPI_MASK) {
-            const float4 m = *reinterpret_cast<const float4 *>(pmask + off);
-            o.x = m.x > 0.f ? o.x : 0.f;
-            o.y = m.y > 0.f ? o.y : 0.f;
-            o.z = m.z > 0.f ? o.z : 0.f;
-            o.w = m.w > 0.f ? o.w : 0.f;
-        }
-        *reinterpret_cast<float4 *>(py + off) = o;
-    }
+    store_block32(d, tile, lane, n, cb * 32, oy, x0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -420,6 +414,82 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
 // (direct fp32: 1.5e-7).  Wave = one output row of 128 pixels (MFMA column = pixel quad) x one cout block of 32
 // (6 accumulator tiles); the lane's four pixels of a cout row leave as ONE 16-byte store, no LDS transposition.
 constexpr int W43TW = 128, W43WP = W43TW + 8, W43TAPS = 18;
+
+
+// ---- epilogue of the F(4,3) kernels: the lane owns 4 consecutive pixels of 16 cout rows - one 16-byte store each.
+// All loads of a batch (bias, residual, mask) are issued unconditionally inside wave-uniform branches, one batch ahead
+// of the arithmetic: written per element ("if (epi & ADD) load") hipcc branches around every load and waits
+// vmcnt(0) after each, i.e. 16 x 3 dependent memory round trips per wave (r01: 10 % of a wave's life).
+__device__ __forceinline__ void w43_epilogue(const risp_conv_desc &d, const f32x16 (&acc)[6], int n, int cb, int oy, int ox,
+                                             int half) {
+    if (!(oy < d.H && ox < d.W)) return;
+    const int epi = d.epilogue;
+    const size_t hw = (size_t)d.H * d.W, pix = (size_t)oy * d.W + ox;
+    const bool has_add = (epi & RISP_EPI_ADD) != 0, has_mask = (epi & RISP_EPI_MASK) != 0;
+    auto co_of = [&](int e) { return cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half; };
+    float bias[16];
+    if (!(epi & RISP_EPI_NOBIAS)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co_of(e);
+            bias[e] = d.bias[co < d.cout ? co : d.cout - 1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias[e] = 0.f;
+    }
+    float4 av[2][4], mv[2][4];
+    auto load_batch = [&](int b, int slot) {
+        if (has_add) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co_of(4 * b + i);
+                const int cc = co < d.add_c ? co : d.add_c - 1;               // clamped: always a valid address
+                av[slot][i] = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + cc) * hw + pix);
+            }
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co_of(4 * b + i);
+                const int cc = co < d.cout ? co : d.cout - 1;
+                mv[slot][i] = *reinterpret_cast<const float4 *>(d.mask + ((size_t)n * d.cout + cc) * hw + pix);
+            }
+        }
+    };
+    load_batch(0, 0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int slot = b & 1;
+        if (b + 1 < 4) load_batch(b + 1, slot ^ 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * b + i, co = co_of(e);
+            const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+            const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
+            const float bb = bias[e];
+            float4 o = make_float4(m0 + a12 + a34 + bb, s12 + 2.f * s34 + bb, a12 + 4.f * a34 + bb, s12 + 8.f * s34 + m5 + bb);
+            if (has_add && co < d.add_c) {
+                const float4 a = av[slot][i];
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            if (epi & RISP_EPI_RELU) {
+                o.x = o.x > 0.f ? o.x : 0.f;
+                o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f;
+                o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            if (has_mask) {
+                const float4 m = mv[slot][i];
+                o.x = m.x > 0.f ? o.x : 0.f;
+                o.y = m.y > 0.f ? o.y : 0.f;
+                o.z = m.z > 0.f ? o.z : 0.f;
+                o.w = m.w > 0.f ? o.w : 0.f;
+            }
+            if (co < d.cout) *reinterpret_cast<float4 *>(d.y + ((size_t)n * d.cout + co) * hw + pix) = o;
+        }
+    }
+}
 
 #ifndef RISP_W43_WAVES
 #define RISP_W43_WAVES 2
@@ -553,39 +623,7 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
     }
     WSTAMP(t_loop_end);
 
-    // ---- epilogue: the lane owns 4 consecutive pixels of 16 cout rows - one 16-byte store each
-    const int epi = d.epilogue;
-    const int oy = y0 + wave, ox = x0 + 4 * l31;
-    if (oy < d.H && ox < d.W) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (co >= d.cout) continue;
-        const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
-        const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
-        const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co];
-        float4 o = make_float4(m0 + a12 + a34 + b, s12 + 2.f * s34 + b, a12 + 4.f * a34 + b, s12 + 8.f * s34 + m5 + b);
-        const size_t off = ((size_t)n * d.cout + co) * hw + (size_t)oy * d.W + ox;
-        if ((epi & RISP_EPI_ADD) && co < d.add_c) {
-            const float4 a = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + co) * hw + (size_t)oy * d.W + ox);
-            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-        }
-        if (epi & RISP_EPI_RELU) {
-            o.x = o.x > 0.f ? o.x : 0.f;
-            o.y = o.y > 0.f ? o.y : 0.f;
-            o.z = o.z > 0.f ? o.z : 0.f;
-            o.w = o.w > 0.f ? o.w : 0.f;
-        }
-        if (epi & RISP_EPI_MASK) {
-            const float4 m = *reinterpret_cast<const float4 *>(d.mask + off);
-            o.x = m.x > 0.f ? o.x : 0.f;
-            o.y = m.y > 0.f ? o.y : 0.f;
-            o.z = m.z > 0.f ? o.z : 0.f;
-            o.w = m.w > 0.f ? o.w : 0.f;
-        }
-        *reinterpret_cast<float4 *>(d.y + off) = o;
-    }
-    }
+    w43_epilogue(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);
 #ifdef RISP_CONV_STAMPS
     if (lane == 0 && d.mask && !(d.epilogue & RISP_EPI_MASK)) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(d.mask)) +
@@ -688,8 +726,8 @@ int risp_conv2d_wino43(const risp_conv_desc *dp, void *stream) {
                    "risp_conv2d_wino43: tensors must be 16-byte aligned");
     const int ncb = (d.cout + 31) / 32;
     constexpr int XN = W43CK * WIH * W43WP, WN = W43TAPS * W43CK * 32;
-    const size_t lds = sizeof(float) * 2 * (XN + WN);
     dim3 grid((d.W + W43TW - 1) / W43TW, (d.H + WTH - 1) / WTH, d.N * ncb);
+    const size_t lds = sizeof(float) * 2 * (XN + WN);
     hipLaunchKernelGGL(conv_wino43_kernel<W43CK>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
     RISP_LAUNCH_CHECK("risp_conv2d_wino43");
     return 0;

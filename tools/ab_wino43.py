@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""GPU box: in-process A/B of builds of risp_conv_wino.hip with different -D flags (interleaved rounds) on one
+64 -> 64 3x3 layer through risp_conv2d_wino43 (F(4,3)).  python tools/ab_wino43.py "" "-DRISP_W43_GLDS=3" ...
+[env RISP_AB_SHAPE="n h w", RISP_AB_EPI=1 for the residual + ReLU epilogue of a Path-Restore block]"""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+variants = sys.argv[1:] or ['', '-DRISP_W43_GLDS=3']
+base = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off',
+        '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'reconfigisp_amd/csrc'), '-x', 'hip', '-shared']
+core = os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_core.cpp')
+src = os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_conv_wino.hip')
+import torch
+libs = {}
+for i, v in enumerate(variants):
+    so = '/tmp/wino43_%d.so' % i
+    parts = v.split(',') if v else []               # "-Dflags" or "other_source.hip[,-Dflags]"
+    srcf = src
+    if parts and parts[0].endswith('.hip'):
+        srcf, parts = os.path.join(ROOT, parts[0]), parts[1:]
+    subprocess.check_call(base + parts + ['-o', so, srcf, core])
+    libs[v or 'base'] = C.CDLL(so)
+from reconfigisp_amd import lib as L
+from reconfigisp_amd import convnets as CN
+n, h, w = (int(v) for v in os.environ.get('RISP_AB_SHAPE', '64 128 128').split())
+cin = cout = 64
+torch.manual_seed(0)
+wt = torch.randn(cout, cin, 3, 3, device='cuda') * 0.05
+b = torch.randn(cout, device='cuda') * 0.01
+x = torch.rand(n, cin, h, w, device='cuda')
+res_in = torch.rand(n, cout, h, w, device='cuda')
+y = torch.empty(n, cout, h, w, device='cuda')
+full_epi = os.environ.get('RISP_AB_EPI') == '1'
+ref = torch.nn.functional.conv2d(x[:2], wt, b, padding=1)
+ref = torch.relu(ref + res_in[:2]) if full_epi else torch.relu(ref)
+pack = CN.wino43_weights(wt, False, 4)
+res = {k: [] for k in libs}
+for name, l in libs.items():
+    l.risp_conv2d_wino43.restype, l.risp_conv2d_wino43.argtypes = L.SIGNATURES['risp_conv2d_wino43']
+    l.risp_last_error.restype = C.c_char_p
+    d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=3, load_mode=0, cin_img=0,
+                   epilogue=CN.EPI_RELU | (CN.EPI_ADD if full_epi else 0), add_c=cout if full_epi else 0,
+                   x=x.data_ptr(), wpack=pack.data_ptr(), bias=b.data_ptr(), cvals=None,
+                   add=res_in.data_ptr() if full_epi else None, mask=None, y=y.data_ptr())
+    libs[name] = (l, d)
+    y.zero_()
+    st = l.risp_conv2d_wino43(C.byref(d), None)
+    torch.cuda.synchronize()
+    full = torch.relu(torch.nn.functional.conv2d(x[-1:], wt, b, padding=1) + (res_in[-1:] if full_epi else 0))
+    print('%-40s status %d %s max|err| %.2e (last image %.2e)' % (name, st, l.risp_last_error(), (y[:2] - ref).abs().max().item(),
+                                                                (y[-1:] - full).abs().max().item()))
+for rnd in range(7):
+    for name, (l, d) in libs.items():
+        for _ in range(2): l.risp_conv2d_wino43(C.byref(d), None)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(10): l.risp_conv2d_wino43(C.byref(d), None)
+        e1.record(); e1.synchronize()
+        res[name].append(e0.elapsed_time(e1) / 10 * 1e3)
+flop = 2.0 * cin * cout * 9 * n * h * w
+for k, v in res.items():
+    m = sorted(v)[len(v) // 2]
+    print('%-40s median %.1f us  min %.1f   (%.1f algorithmic TFLOP/s, %.1f issued)' % (k, m, min(v), flop / m / 1e6, flop / 2 / m / 1e6))
