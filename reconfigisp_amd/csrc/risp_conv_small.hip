@@ -320,6 +320,14 @@ int launch_small(const risp_conv_desc &d, float *scratch, int groups, hipStream_
     if (groups <= 1 && (size_t)tiles_x * ((d.H + 31) / 32) * d.N >= 384) {          // enough 64 x 32 tiles for every CU
         const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (32 + 2 * P) * STW;
         hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N), dim3(256), lds, s, d, 1, nullptr);
+    } else if (groups > 1 && (size_t)tiles_x * ((d.H + 31) / 32) * d.N * groups >= 256) {
+        // channel groups on the 64 x 32 tile (two output rows per thread: each LDS row read feeds both rows' taps):
+        // 9x9 64 -> 3 on 4 x 256 x 256, 4 groups: 127 -> 118 us, 8 groups: 136 -> 114 us (tools/ab_small.py)
+        const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (32 + 2 * P) * STW;
+        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N * groups), dim3(256), lds, s, d, groups,
+                           scratch);
+        const size_t total = (size_t)d.N * d.cout * d.H * d.W;
+        hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d, groups, scratch);
     } else {
         if (groups < 1) groups = 1;
         const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (16 + 2 * P) * STW;
@@ -350,8 +358,9 @@ int risp_conv_small_groups(const risp_conv_desc *dp) {
     if (!dp || dp->cin < 32 || (dp->epilogue & RISP_EPI_SHUFFLE2)) return 1;
     const size_t tiles = (size_t)((dp->W + SX - 1) / SX) * ((dp->H + 15) / 16) * dp->N;
     if (tiles >= 768) return 1;
-    int g = (int)(1024 / (tiles ? tiles : 1));
-    if (g > 4) g = 4;
+    const size_t tiles32 = (size_t)((dp->W + SX - 1) / SX) * ((dp->H + 31) / 32) * dp->N;   // the split runs on 64 x 32 tiles
+    int g = (int)(1024 / (tiles32 ? tiles32 : 1));
+    if (g > 8) g = 8;
     while (g > 1 && dp->cin / g < 8) --g;
     return g < 1 ? 1 : g;
 }
