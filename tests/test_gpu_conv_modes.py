@@ -250,7 +250,7 @@ def test_small_cout_up_to_12(cout, hw):
 
 @pytest.mark.parametrize('cin,cout', [(64, 64), (4, 64), (64, 33), (3, 64), (64, 3)])
 @pytest.mark.parametrize('hw', SIZES + [(12, 128), (6, 260)])
-def test_inference_dispatch_f43(cin, cout, hw):
+def test_inference_dispatch_f43(cin, cout, hw, monkeypatch):
     """3x3 layers whose activations no backward pass reads go through risp_conv2d_wino43 (F(4,3)), the others
     through F(2,3).  Both against PyTorch, every epilogue the kernels share."""
     from reconfigisp_amd import convnets as CN
@@ -261,6 +261,7 @@ def test_inference_dispatch_f43(cin, cout, hw):
     assert pc.wino43_fwd is not None and pc.wino_fwd is not None
     x, add, mask = rnd(n, cin, h, w, seed=73), rnd(n, cout, h, w, seed=74), rnd(n, cout, h, w, seed=75)
     lin = TF.conv2d(x, wt, b, padding=1)
+    monkeypatch.setattr(CN, 'F43_MIN_GRID', 0)          # F(4,3) also on these small grids (the product switches at 2048 tiles)
     for infer in (True, False):
         assert_close(CN.conv(x, pc, n, h, w, infer=infer), lin, what='plain infer=%s' % infer)
         assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=cout, infer=infer),
@@ -276,8 +277,10 @@ _FUZZ = int(os.environ.get('RISP_TEST_SEEDS', '8')) * 6            # soak runs: 
 
 
 @pytest.mark.parametrize('seed', range(_FUZZ))
-def test_random_layer_shapes(seed):
+def test_random_layer_shapes(seed, monkeypatch):
     from reconfigisp_amd import convnets as CN
+    if seed % 2 == 0:
+        monkeypatch.setattr(CN, 'F43_MIN_GRID', 0)      # every other case: F(4,3) on the small grid too
     rng = np.random.default_rng(9000 + seed)
     k = int(rng.choice([1, 3, 3, 5, 5, 9]))
     cin, cout = int(rng.integers(1, 65)), int(rng.integers(1, 65))
