@@ -255,6 +255,32 @@ int risp_cond_fc_bwd(const float *flat, const int *widths, int n_layers, const f
                      float *deltas, float *dflat, int total_params, int N, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Bookkeeping of one super-net slot as single launches (models/modules/super_prune_fifteen_demos_four_bayer_two.py).
+ * ------------------------------------------------------------------------- */
+/* mixture weights, :185-193: prob = softmax(alpha) (entries flagged in `unavailable` get probability exactly 0);
+ * entries with prob < threshold * max(prob) (strict) are pruned; post = kept / sum(kept).  The mask and the sum are
+ * detached in the reference, so d post_k / d prob_k = coef_k (1 / sum for kept entries, 0 for pruned ones).
+ * K <= 64.  probs, coef, post: K floats each (probs and coef feed the backward). */
+int risp_prune_softmax_fwd(const float *alpha, const unsigned char *unavailable, float threshold, int K, float *probs,
+                           float *coef, float *post, void *stream);
+int risp_prune_softmax_bwd(const float *probs, const float *coef, const float *gpost, int K, float *galpha, void *stream);
+
+/* per-image parameter blocks of the ops of a slot, :204-209 / isp_universal.py:226-228:
+ * block[k] (N, width[k]) = sigmoid(raw[k]).repeat(N, 1); backward: graw[k] = sigmoid' * sum over the images of
+ * gblock[k] (NULL = no gradient arrived: zeros), images in index order (deterministic). */
+#define RISP_MAX_PARAM_OPS 16
+typedef struct risp_param_blocks_desc {
+    int n_ops, N;
+    int width[RISP_MAX_PARAM_OPS];                /* 1..64 */
+    const float *raw[RISP_MAX_PARAM_OPS];         /* (width) */
+    float *block[RISP_MAX_PARAM_OPS];             /* forward: (N, width) out */
+    const float *gblock[RISP_MAX_PARAM_OPS];      /* backward: (N, width) in, may be NULL */
+    float *graw[RISP_MAX_PARAM_OPS];              /* backward: (width) out */
+} risp_param_blocks_desc;
+int risp_param_blocks_fwd(const risp_param_blocks_desc *d, void *stream);
+int risp_param_blocks_bwd(const risp_param_blocks_desc *d, void *stream);
+
+/* ---------------------------------------------------------------------------
  * One training step of an element-wise fixed pipeline in two launches - replaces the body of
  * IspModel.optimize_parameters (models/isp_model.py:128-142: output = netG(img); l_pix = cri_pix(output, gt);
  * zero_grad(); l_pix.backward(); optimizer_G.step()) when netG is [nearest demosaic ->] a chain of WbManual / Gamma /

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .... import functional as F
 from . import registry as R
 from .pipeline_fusion import fused_forward, wants_grad
 
@@ -65,6 +66,8 @@ class _FixedPipeline(nn.Module):
         return self._build_stage_params(n)
 
     def _build_stage_params(self, n):
+        plain = [p for p, cond in zip(self.all_params, self.is_conditional) if p.numel() and not cond]
+        blocks = iter(F.param_blocks(plain, n))                # sigmoid(p).repeat(n, 1), (N, P) in [0,1]: one launch
         out = []
         for p, cond in zip(self.all_params, self.is_conditional):
             if p.numel() == 0:
@@ -72,7 +75,7 @@ class _FixedPipeline(nn.Module):
             elif cond:
                 out.append(p)                                  # raw flat vector, no sigmoid / repeat
             else:
-                out.append(torch.sigmoid(p).repeat(n, 1))      # (N, P) in [0,1]
+                out.append(next(blocks))
         return out
 
     def forward(self, x):

@@ -11,7 +11,6 @@ import logging
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as TF
 
 from .... import functional as F
 from ....isp_kernels import demosaic as _dm
@@ -71,11 +70,11 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                     p.data = fn(p.data)
         return self
 
-    def _unavailable(self, mods):
-        """Ops that cannot run in this build (DemosaicNet without a registered implementation): they are
-        left out of the softmax - probability exactly 0, zero alpha-gradient - instead of crashing the
-        search.  With an implementation registered (isp_kernels.demosaic.register_demosaicnet) the
-        reference behaviour applies unchanged."""
+    def _unavailable(self, mods, device):
+        """uint8 mask of ops that cannot run in this build (DemosaicNet without a registered implementation): they are
+        left out of the softmax - probability exactly 0, zero alpha-gradient - instead of crashing the search.  With an
+        implementation registered (isp_kernels.demosaic.register_demosaicnet) the reference behaviour applies
+        unchanged.  None when every op of the slot is available."""
         if _dm.demosaicnet_available():
             return None
         mask = [isinstance(m, T.DemosaicNet) for m in mods]
@@ -85,33 +84,34 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             logging.getLogger('base').warning('DemosaicNet has no implementation in this build; its mixing '
                                               'probability is fixed to 0')
             self._warned_unavailable = True
-        return mask
+        cache = self.__dict__.setdefault('_unavailable_masks', {})
+        key = (tuple(mask), str(device))
+        if key not in cache:
+            cache[key] = torch.tensor(mask, dtype=torch.uint8, device=device)
+        return cache[key]
 
     def forward(self, x):
         n = x.size(0)
         self.middle_results = []
         for slot, (mods, pars, alpha) in enumerate(zip(self.all_modules, self.all_params, self.all_alphas)):
-            missing = self._unavailable(mods)
-            if missing is not None:
-                alpha = alpha.masked_fill(torch.tensor(missing, device=alpha.device), float('-inf'))
-            probs = TF.softmax(alpha, dim=0)
-            keep_below = probs.detach() < self.threshold * probs.detach().max()
-            post = probs.clone()
-            post[keep_below] = 0
-            post = post / post.sum().detach()
+            # softmax -> strict-< prune against threshold * max (detached) -> renormalise by the detached sum: one launch
+            post = F.prune_softmax(alpha, self.threshold, self._unavailable(mods, alpha.device))
             weights = post.detach().cpu().tolist()       # one D2H per slot (the reference's .item())
             self.pruned_paths[slot] = sum(1 for w in weights if w == 0.0)
 
-            outs, index, pruned_pars = [], [], []
-            for k, (op, par) in enumerate(zip(mods, pars)):
+            index, pruned_pars, live_pars = [], [], []
+            for k, par in enumerate(pars):
                 if weights[k] < 1e-9:
                     if par.nelement() > 0:               # pruned, but must still receive a (zero) gradient
                         pruned_pars.append(par)
                     continue
-                par_tensor = torch.sigmoid(par).repeat(n, 1) if par.nelement() > 0 else None
-                outs.append(op(x, par_tensor))
                 index.append(k)
-            y = F.mix(post[index], outs, w_host=[weights[k] for k in index])
+                if par.nelement() > 0:
+                    live_pars.append(par)
+            blocks = iter(F.param_blocks(live_pars, n))  # sigmoid(par).repeat(n, 1) of every surviving op: one launch
+            outs = [mods[k](x, next(blocks) if pars[k].nelement() > 0 else None) for k in index]
+            sel = post if len(index) == len(weights) else post[index]
+            y = F.mix(sel, outs, w_host=[weights[k] for k in index])
             if pruned_pars:
                 y = F.attach_zero_grad(y, pruned_pars)
             self.middle_results.append(y)

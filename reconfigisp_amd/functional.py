@@ -232,6 +232,66 @@ class _Mix(torch.autograd.Function):
         return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]), None) + tuple(gos)
 
 
+class _PruneSoftmax(torch.autograd.Function):
+    """post = pruned, renormalised softmax(alpha) of one super-net slot (risp_prune_softmax_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, alpha, threshold, unavailable):
+        a = _dev(alpha, 'alpha')
+        k = a.numel()
+        buf = torch.empty((3, k), device=a.device, dtype=torch.float32)          # probs | coef | post
+        L.call('risp_prune_softmax_fwd', _p(a), _p(unavailable), float(threshold), k, _p(buf[0]), _p(buf[1]), _p(buf[2]),
+               _stream())
+        ctx.save_for_backward(buf)
+        return buf[2]
+
+    @staticmethod
+    def backward(ctx, gpost):
+        buf, = ctx.saved_tensors
+        k = buf.shape[1]
+        galpha = torch.empty(k, device=buf.device, dtype=torch.float32)
+        L.call('risp_prune_softmax_bwd', _p(buf[0]), _p(buf[1]), _p(_dev(gpost, 'grad')), k, _p(galpha), _stream())
+        return galpha, None, None
+
+
+class _ParamBlocks(torch.autograd.Function):
+    """blocks[k] = sigmoid(raw[k]).repeat(N, 1) for all parametrised ops of a slot in ONE launch each way."""
+
+    @staticmethod
+    def forward(ctx, n, *raws):
+        raws = [_dev(r, 'params') for r in raws]
+        d = L.ParamBlocksDesc()
+        d.n_ops, d.N = len(raws), n
+        flat = torch.empty(n * sum(r.numel() for r in raws), device=raws[0].device, dtype=torch.float32)
+        blocks, at = [], 0
+        for k, r in enumerate(raws):
+            w = r.numel()
+            blk = flat[at: at + n * w].view(n, w)
+            at += n * w
+            d.width[k], d.raw[k], d.block[k] = w, r.data_ptr(), blk.data_ptr()
+            blocks.append(blk)
+        L.call('risp_param_blocks_fwd', C.byref(d), _stream())
+        ctx.save_for_backward(*raws)
+        ctx.n = n
+        return tuple(blocks)
+
+    @staticmethod
+    def backward(ctx, *gblocks):
+        raws = ctx.saved_tensors
+        d = L.ParamBlocksDesc()
+        d.n_ops, d.N = len(raws), ctx.n
+        keep, grads = [], []
+        for k, (r, g) in enumerate(zip(raws, gblocks)):
+            g = _dev(g, 'grad') if g is not None else None
+            keep.append(g)
+            gr = torch.empty_like(r)
+            grads.append(gr)
+            d.width[k], d.raw[k], d.graw[k] = r.numel(), r.data_ptr(), gr.data_ptr()
+            d.gblock[k] = g.data_ptr() if g is not None else None
+        L.call('risp_param_blocks_bwd', C.byref(d), _stream())
+        return (None,) + tuple(grads)
+
+
 class _ZeroGrad(torch.autograd.Function):
     """y passes through untouched; the extra parameters join the graph with an all-zero gradient.
 
@@ -363,6 +423,17 @@ class _HipImpl:
         return _Mix.apply(w, w_host, *outs)
 
     @staticmethod
+    def prune_softmax(alpha, threshold, unavailable=None):
+        return _PruneSoftmax.apply(alpha, threshold, unavailable)
+
+    @staticmethod
+    def param_blocks(raws, n):
+        out = []
+        for at in range(0, len(raws), L.PARAM_OPS_MAX):
+            out += list(_ParamBlocks.apply(n, *raws[at: at + L.PARAM_OPS_MAX]))
+        return out
+
+    @staticmethod
     def histc01(x, bins):
         return histc01(x, bins)
 
@@ -457,6 +528,18 @@ def demosaic_nearest(x, p=None):
 def mix(w, outs, w_host=None):
     """sum_k w[k] * outs[k]; ``w_host``: the same weights as Python floats when the caller already holds them."""
     return _IMPL.mix(w, outs, w_host)
+
+
+def prune_softmax(alpha, threshold, unavailable=None):
+    """Mixture weights of a slot (super_prune_fifteen_demos_four_bayer_two.py:185-193): softmax, strict-< pruning
+    against threshold * max on detached values, renormalisation by the detached sum.  ``unavailable``: uint8 mask of
+    ops whose probability is forced to 0.  Returns post (K,), differentiable in alpha."""
+    return _IMPL.prune_softmax(alpha, threshold, unavailable)
+
+
+def param_blocks(raws, n):
+    """[sigmoid(r).repeat(n, 1) for r in raws] (:204-209), one launch for the whole list."""
+    return _IMPL.param_blocks(list(raws), n) if len(raws) else []
 
 
 def hist_features(x, bins):

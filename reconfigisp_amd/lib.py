@@ -39,6 +39,15 @@ class TrainDesc(C.Structure):
                 ('bias2_sqrt', _fl), ('eps', _fl), ('loss', _f), ('scratch', _f)]
 
 
+PARAM_OPS_MAX = 16
+
+
+class ParamBlocksDesc(C.Structure):
+    """mirror of risp_param_blocks_desc"""
+    _fields_ = [('n_ops', _i), ('N', _i), ('width', _i * PARAM_OPS_MAX), ('raw', _f * PARAM_OPS_MAX),
+                ('block', _f * PARAM_OPS_MAX), ('gblock', _f * PARAM_OPS_MAX), ('graw', _f * PARAM_OPS_MAX)]
+
+
 def _pw(n_extra=0):
     # forward: (x, p, y, N, HW, stream); backward (n_extra = 3): (x, p, gy, gx, gp, scratch, N, HW, stream)
     return [_f] * (3 + n_extra) + [_i, _i, _s]
@@ -103,6 +112,10 @@ SIGNATURES = {
     'risp_gt_crop': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _s]),
     'risp_resize_rggb': (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _s]),
     'risp_sse_uint8': (_i, [_f, _f, _f, _z, _s]),
+    'risp_prune_softmax_fwd': (_i, [_f, _f, _fl, _i, _f, _f, _f, _s]),
+    'risp_prune_softmax_bwd': (_i, [_f, _f, _f, _i, _f, _s]),
+    'risp_param_blocks_fwd': (_i, [C.POINTER(ParamBlocksDesc), _s]),
+    'risp_param_blocks_bwd': (_i, [C.POINTER(ParamBlocksDesc), _s]),
     'risp_train_scratch_floats': (_z, [_i]),
     'risp_chain_train_step': (_i, [C.POINTER(TrainDesc), _s]),
 }

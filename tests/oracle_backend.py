@@ -29,6 +29,21 @@ class OracleImpl:
         return y
 
     @staticmethod
+    def prune_softmax(alpha, threshold, unavailable=None):
+        # the reference's own sequence of tensor operations (super_prune_fifteen_demos_four_bayer_two.py:185-193)
+        if unavailable is not None:
+            alpha = alpha.masked_fill(unavailable.to(torch.bool), float('-inf'))
+        probs = torch.softmax(alpha, dim=0)
+        below = probs.detach() < threshold * probs.detach().max()
+        post = probs.clone()
+        post[below] = 0
+        return post / post.sum().detach()
+
+    @staticmethod
+    def param_blocks(raws, n):
+        return [torch.sigmoid(r).repeat(n, 1) for r in raws]
+
+    @staticmethod
     def histc01(x, bins):
         return torch.stack([torch.cat([torch.histc(ch.detach(), bins=bins, min=0, max=1) for ch in im]) for im in x])
 

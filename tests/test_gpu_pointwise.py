@@ -249,3 +249,58 @@ def test_random_pointwise_ops_forward_and_gradients(F, seed):
     _fwd_bwd(F.grayworld, O.grayworld, rnd(*shape, seed=seed + 2, lo=0.01, hi=1.0), None, gy, 'grayworld', rtol=2e-4)
     bay = rnd(n, 1, h, w, seed=seed + 3)
     assert torch.equal(F.demosaic_nearest(bay.cuda()).cpu(), O.demosaic_nearest(bay))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_prune_softmax_matches_the_reference_sequence(F, seed):
+    """risp_prune_softmax_fwd/_bwd against the reference's own tensor operations
+    (super_prune_fifteen_demos_four_bayer_two.py:185-193), values, prune mask and alpha-gradient."""
+    g = torch.Generator().manual_seed(seed)
+    k = [2, 4, 15, 15, 21, 64][seed]
+    alpha = (torch.randn(k, generator=g) * (0.3 if seed % 2 else 2.0))
+    unavailable = None
+    if seed in (1, 3):
+        unavailable = torch.zeros(k, dtype=torch.uint8)
+        unavailable[k - 1] = 1
+    thr = 0.2
+    a_ref = alpha.clone().requires_grad_(True)
+    am = a_ref if unavailable is None else a_ref.masked_fill(unavailable.bool(), float('-inf'))
+    probs = torch.softmax(am, dim=0)
+    below = probs.detach() < thr * probs.detach().max()
+    post = probs.clone()
+    post[below] = 0
+    post = post / post.sum().detach()
+    gpost = torch.randn(k, generator=g)
+    ga_ref, = torch.autograd.grad(post, a_ref, gpost)
+    a_gpu = alpha.cuda().requires_grad_(True)
+    got = F.prune_softmax(a_gpu, thr, None if unavailable is None else unavailable.cuda())
+    ga, = torch.autograd.grad(got, a_gpu, gpost.cuda())
+    assert torch.equal(got.cpu() == 0, post.detach() == 0)                    # the prune mask: exact
+    assert_close(got, post.detach(), atol=1e-7, what='post')
+    assert_close(ga, ga_ref, atol=1e-7, what='d post / d alpha')
+    if unavailable is not None:
+        assert got[k - 1].item() == 0.0 and ga[k - 1].item() == 0.0
+
+
+def test_param_blocks_match_sigmoid_repeat(F):
+    g = torch.Generator().manual_seed(3)
+    widths = [1, 3, 30, 2, 5, 3, 1, 1, 2, 3, 3, 30, 3, 5, 1, 2, 3, 1]              # 18 ops: two launches
+    raws = [(torch.randn(w, generator=g) * 2).requires_grad_(True) for w in widths]
+    n = 5
+    ref = [torch.sigmoid(r).repeat(n, 1) for r in raws]
+    gs = [torch.randn(n, w, generator=g) for w in widths]
+    gs[4] = None                                                                    # an op whose block nothing used
+    live = [(b, gb) for b, gb in zip(ref, gs) if gb is not None]
+    gref = torch.autograd.grad([b for b, _ in live], raws, [gb for _, gb in live], allow_unused=True)
+    raws_g = [r.detach().cuda().requires_grad_(True) for r in raws]
+    got = F.param_blocks(raws_g, n)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and a.is_contiguous()
+        assert_close(a, b.detach(), atol=1e-7, what='block')
+    live_g = [(b, gb.cuda()) for b, gb in zip(got, gs) if gb is not None]
+    ggot = torch.autograd.grad([b for b, _ in live_g], raws_g, [gb for _, gb in live_g], allow_unused=True)
+    for a, b in zip(ggot, gref):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0
+        else:
+            assert_close(a, b, atol=1e-7, what='d block / d raw')
