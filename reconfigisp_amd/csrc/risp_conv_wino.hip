@@ -378,8 +378,10 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
             const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3], d4 = opd[slot][4],
                         d5 = opd[slot][5];
             const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
-            const float bv[6] = {4.f * d0 - 5.f * d2 + d4, 4.f * s12 - s34, m34 - 4.f * m12, -2.f * m13 - m24, 2.f * m13 - m24,
-                                 4.f * d1 - 5.f * d3 + d5};
+            // fused multiply-adds (exact products, one rounding each): 14 vector instructions instead of 22
+            const float bv[6] = {__builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4)), __builtin_fmaf(4.f, s12, -s34),
+                                 __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
+                                 __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
 #pragma unroll
             for (int t = 0; t < 6; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
@@ -494,6 +496,9 @@ __device__ __forceinline__ void w43_epilogue(const risp_conv_desc &d, const f32x
 #ifndef RISP_W43_WAVES
 #define RISP_W43_WAVES 2
 #endif
+#ifndef RISP_W43_ABL
+#define RISP_W43_ABL 0     // diagnostic builds (tools/ab_wino43.py): 1 no epilogue, 2 no global loads after the first chunk, 3 no barriers, 4 no LDS operand reads after the first chunk
+#endif
 template <int CK>
 __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const risp_conv_desc d, int ncb) {
     constexpr int CP = 32;
@@ -548,18 +553,19 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // slot j of the staging registers (0 .. NXV-1 input tile, NXV .. NF-1 weight slab) -> LDS buffer `buf`
+    auto publish_one = [&](int buf, int j) {
+        if (j < NXV) {
+            const int v = tid + 256 * j;
+            if (256 * (j + 1) <= XN / 4 || v < XN / 4) reinterpret_cast<float4 *>(sx + buf * XN)[v] = xr[j];   // full rounds: no branch
+        } else if (j < NF) {
+            const int v = tid + 256 * (j - NXV);
+            if (256 * (j - NXV + 1) <= WN / 4 || v < WN / 4) reinterpret_cast<float4 *>(sw + buf * WN)[v] = wr[j - NXV];
+        }
+    };
     auto publish = [&](int buf) {
-        float *sxb = sx + buf * XN, *swb = sw + buf * WN;
 #pragma unroll
-        for (int i = 0; i < NXV; ++i) {
-            const int v = tid + 256 * i;
-            if (256 * (i + 1) <= XN / 4 || v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];   // full rounds: no branch
-        }
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int v = tid + 256 * i;
-            if (256 * (i + 1) <= WN / 4 || v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
-        }
+        for (int j = 0; j < NF; ++j) publish_one(buf, j);
     };
 
     WSTAMP(t_begin);
@@ -569,13 +575,17 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         WSTAMP(t0);
+#if RISP_W43_ABL != 3
         __syncthreads();                               // tile ch published, tile ch-1 no longer read
+#endif
         WSTAMP(t1);
         const bool more = ch + 1 < nchunks;
+#if RISP_W43_ABL != 2
         if (more) {
 #pragma unroll
             for (int j = 0; j < NF; ++j) fetch_one(ch + 1, j);
         }
+#endif
         // d0 of quad q sits at staged column 4q + 3 (image x0 + 4q - 1), d1..d4 in the 16-byte slot 4q + 4, d5 at 4q + 8.
         // The six operands come from THREE ds_read_b128 (slots q, q+1, q+2: conflict-free, 4 LDS cycles each) instead of
         // six scalar reads at a 16-byte lane stride (4-way bank conflicts on (a/4) mod 32: 8 cycles each, r01 PMC:
@@ -593,10 +603,16 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
 #pragma unroll
             for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
         };
+#if RISP_W43_ABL == 4 || RISP_W43_ABL == 6
+        if (ch == 0)
+#endif
         load_group(0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int slot = g & 1;
+#if RISP_W43_ABL == 4 || RISP_W43_ABL == 6
+            if (ch == 0)
+#endif
             if (g + 1 < NG) load_group(g + 1, slot ^ 1);
             __builtin_amdgcn_sched_barrier(0);         // keep the reads above this group's MFMAs
             // (the empty asm consumes whole 16-byte tuples: without it the compiler narrows the outer two reads to the
@@ -605,15 +621,24 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
             const float d0 = opd[slot][0].w, d1 = opd[slot][1].x, d2 = opd[slot][1].y, d3 = opd[slot][1].z,
                         d4 = opd[slot][1].w, d5 = opd[slot][2].x;
             const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
-            const float bv[6] = {4.f * d0 - 5.f * d2 + d4, 4.f * s12 - s34, m34 - 4.f * m12, -2.f * m13 - m24, 2.f * m13 - m24,
-                                 4.f * d1 - 5.f * d3 + d5};
+#if RISP_W43_ABL == 5 || RISP_W43_ABL == 6
+            const float bv[6] = {d0, d1, d2, d3, d4, d5};      // diagnostic: no input transform
+            (void)s12; (void)s34; (void)m12; (void)m34; (void)m13; (void)m24;
+#else
+            // fused multiply-adds (exact products, one rounding each): 14 vector instructions instead of 22
+            const float bv[6] = {__builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4)), __builtin_fmaf(4.f, s12, -s34),
+                                 __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
+                                 __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
+#endif
 #pragma unroll
             for (int t = 0; t < 6; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         WSTAMP(t2);
+#if RISP_W43_ABL != 7
         if (more) publish(buf ^ 1);
+#endif
         WSTAMP(t3);
 #ifdef RISP_CONV_STAMPS
         s_bar += t1 - t0;
@@ -623,6 +648,9 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
     }
     WSTAMP(t_loop_end);
 
+#if RISP_W43_ABL == 1
+    if (acc[0][0] == 123.456f)
+#endif
     w43_epilogue(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);
 #ifdef RISP_CONV_STAMPS
     if (lane == 0 && d.mask && !(d.epilogue & RISP_EPI_MASK)) {
