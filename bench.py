@@ -451,7 +451,14 @@ def main():
                               'padded to 32; the small-cout layers run on vector FMAs and count 0) / time: the matrix-pipe '
                               'utilisation is the ISSUED fraction')
     if not args.no_search:
-        leg = search_step_leg(device, rank, world, global_batch=args.search_batch, size=args.size)
+        # a secondary leg must never cost the headline line: on a failure it reports the error instead (the ranks stay
+        # in step: every rank runs the same code and a failure of one surfaces on all at the next collective)
+        try:
+            leg = search_step_leg(device, rank, world, global_batch=args.search_batch, size=args.size)
+        except Exception as e:                                  # noqa: BLE001
+            if world > 1:
+                raise
+            leg = {'error': '%s: %s' % (type(e).__name__, e)}
         if rank == 0:
             extra['search_step'] = leg
 
