@@ -59,3 +59,28 @@ def test_cpu_tensor_is_rejected_not_emulated():
         F.gamma(torch.rand(1, 3, 4, 4), torch.rand(1, 1))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         F.demosaic_nearest(torch.rand(1, 1, 4, 4))
+
+
+def _struct_fields(name):
+    """field names of `typedef struct <name> { ... } <name>;` in include/risp.h, in declaration order"""
+    text = open(os.path.join(ROOT, 'include', 'risp.h')).read()
+    body = text[text.index('typedef struct %s {' % name) + len('typedef struct %s {' % name): text.index('} %s;' % name)]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r'^(const\s+)?(float|int|unsigned char)\s*', '', decl)
+        for part in decl.split(','):
+            fields.append(re.sub(r'\[.*?\]', '', part).replace('*', '').strip())
+    return fields
+
+
+def test_training_and_mixture_descriptors_match_header():
+    from reconfigisp_amd import lib
+    assert [f.rstrip('_') for f, _ in lib.TrainDesc._fields_] == _struct_fields('risp_train_desc')
+    assert [f for f, _ in lib.ParamBlocksDesc._fields_] == _struct_fields('risp_param_blocks_desc')
+    assert lib.TRAIN_MAX == 6 and lib.PARAM_OPS_MAX == 16           # RISP_MAX_TRAIN_CHAIN / RISP_MAX_PARAM_OPS
+    text = open(os.path.join(ROOT, 'include', 'risp.h')).read()
+    assert '#define RISP_MAX_TRAIN_CHAIN 6' in text and '#define RISP_MAX_PARAM_OPS 16' in text
