@@ -27,6 +27,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         self.all_modules, self.all_params, self.all_alphas = [], [], []
         self.trainable_params = []
         self.slot_names = []
+        self._weight_cache = {}
 
         def empty():
             return nn.Parameter(torch.zeros(0))
@@ -95,8 +96,15 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         self.middle_results = []
         for slot, (mods, pars, alpha) in enumerate(zip(self.all_modules, self.all_params, self.all_alphas)):
             # softmax -> strict-< prune against threshold * max (detached) -> renormalise by the detached sum: one launch
-            post = F.prune_softmax(alpha, self.threshold, self._unavailable(mods, alpha.device))
-            weights = post.detach().cpu().tolist()       # one D2H per slot (the reference's .item())
+            unavailable = self._unavailable(mods, alpha.device)
+            post = F.prune_softmax(alpha, self.threshold, unavailable)
+            # host copy of the weights (the reference's .item(): a device synchronisation) - once per VALUE of alpha:
+            # four of the five forwards of a DARTS iteration see unchanged logits (in-place updates bump _version)
+            key = (alpha._version, alpha.data_ptr(), self.threshold, unavailable is None)
+            cached = self._weight_cache.get(slot)
+            if cached is None or cached[0] != key:
+                cached = self._weight_cache[slot] = (key, post.detach().cpu().tolist())
+            weights = cached[1]
             self.pruned_paths[slot] = sum(1 for w in weights if w == 0.0)
 
             index, pruned_pars, live_pars = [], [], []

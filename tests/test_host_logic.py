@@ -281,3 +281,23 @@ def test_virtual_net_evaluates_the_same_frozen_proxies(dev):
     assert torch.equal(a, b)
     for ma, mb in zip(model.netG.intermediate_results, model.netV.intermediate_results):
         assert torch.equal(ma, mb)
+
+
+def test_mixture_weight_cache_follows_in_place_updates(dev):
+    """The host copy of a slot's mixture weights is reused while alpha is unchanged (one device synchronisation per VALUE
+    of alpha, not per forward) and refreshed by any in-place update - an optimiser step, copy_, load_state_dict."""
+    net = build_supernet(1, dev)
+    x = T(load_golden('supernet_n2')['x']).to(dev)
+    with torch.no_grad():
+        net(x)
+        assert net.pruned_paths == [0, 1, 0]                         # alpha = 0: nothing pruned but the unavailable DemosaicNet
+        net(x)
+        assert net.pruned_paths == [0, 1, 0]
+        net.alpha_step1[3] = 5.0                                     # in-place: one op now dominates its slot
+        net(x)
+        assert net.pruned_paths[2] == 14
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        state['alpha_step1'] = torch.zeros_like(state['alpha_step1'])
+        net.load_state_dict(state)
+        net(x)
+        assert net.pruned_paths == [0, 1, 0]
