@@ -8,6 +8,7 @@ state-dict keys (alpha_bayer, alpha_demosaic, alpha_step<k>, param_step<k>_<name
 The weighted sum of a slot is one fused kernel (risp_mix_fwd/bwd) instead of K multiply-adds.
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -16,6 +17,11 @@ from .... import functional as F
 from ....isp_kernels import demosaic as _dm
 from . import registry as R
 from . import tools_origin as T
+
+
+# HIP streams the ops of a slot are spread over when the batch is small (1 = off), and what "small" means
+SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '3'))
+SLOT_STREAMS_MAX_PIXELS = int(os.environ.get('RISP_SLOT_STREAMS_MAX_PIXELS', str(8 * 256 * 256)))
 
 
 class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
@@ -91,6 +97,40 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             cache[key] = torch.tensor(mask, dtype=torch.uint8, device=device)
         return cache[key]
 
+    def _run_ops(self, ops, args, x):
+        """outs[i] = ops[i](x, args[i]).  The surviving ops of a slot are independent given the slot input, so on a small
+        batch (the per-GPU batch of the 8-GPU search is 4 images: every convolution launch is one or two rounds of
+        workgroups that run in lockstep and leave the matrix pipes idle through each prologue / drain) they are issued
+        round-robin on a few HIP streams: launches of different ops overlap and fill each other's gaps.  The backward
+        pass inherits the streams (autograd runs a node on the stream of its forward).  Same kernels, same arguments,
+        same summation order in the mixture: results are bit-identical to the single-stream order."""
+        pixels = x.shape[0] * x.shape[2] * x.shape[3]
+        n_streams = SLOT_STREAMS if (x.is_cuda and len(ops) > 2 and pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
+        if n_streams <= 1:
+            return [op(x, a) for op, a in zip(ops, args)]
+        main = torch.cuda.current_stream()
+        pool = self.__dict__.setdefault('_side_streams', {})
+        key = (x.device.index, n_streams)
+        if key not in pool:
+            pool[key] = [torch.cuda.Stream(device=x.device) for _ in range(n_streams - 1)]
+        streams = [main] + pool[key]
+        for s in streams[1:]:
+            s.wait_stream(main)                           # the slot input (and the parameter blocks) are ready
+            x.record_stream(s)
+        outs = []
+        for i, (op, a) in enumerate(zip(ops, args)):
+            s = streams[i % n_streams]
+            if a is not None and s is not main:
+                a.record_stream(s)
+            with torch.cuda.stream(s):
+                o = op(x, a)
+            if s is not main and o is not x:
+                o.record_stream(main)                     # consumed by the mixture kernel on the main stream
+            outs.append(o)
+        for s in streams[1:]:
+            main.wait_stream(s)
+        return outs
+
     def forward(self, x):
         n = x.size(0)
         self.middle_results = []
@@ -117,7 +157,8 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                 if par.nelement() > 0:
                     live_pars.append(par)
             blocks = iter(F.param_blocks(live_pars, n))  # sigmoid(par).repeat(n, 1) of every surviving op: one launch
-            outs = [mods[k](x, next(blocks) if pars[k].nelement() > 0 else None) for k in index]
+            args = [next(blocks) if pars[k].nelement() > 0 else None for k in index]
+            outs = self._run_ops([mods[k] for k in index], args, x)
             sel = post if len(index) == len(weights) else post[index]
             y = F.mix(sel, outs, w_host=[weights[k] for k in index])
             if pruned_pars:
