@@ -20,8 +20,8 @@ from . import tools_origin as T
 
 
 # HIP streams the ops of a slot are spread over when the batch is small (1 = off), and what "small" means
-SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '3'))
-SLOT_STREAMS_MAX_PIXELS = int(os.environ.get('RISP_SLOT_STREAMS_MAX_PIXELS', str(8 * 256 * 256)))
+SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '2'))
+SLOT_STREAMS_MAX_PIXELS = int(os.environ.get('RISP_SLOT_STREAMS_MAX_PIXELS', str(1 << 40)))
 
 
 class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
@@ -98,12 +98,14 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         return cache[key]
 
     def _run_ops(self, ops, args, x):
-        """outs[i] = ops[i](x, args[i]).  The surviving ops of a slot are independent given the slot input, so on a small
-        batch (the per-GPU batch of the 8-GPU search is 4 images: every convolution launch is one or two rounds of
-        workgroups that run in lockstep and leave the matrix pipes idle through each prologue / drain) they are issued
-        round-robin on a few HIP streams: launches of different ops overlap and fill each other's gaps.  The backward
-        pass inherits the streams (autograd runs a node on the stream of its forward).  Same kernels, same arguments,
-        same summation order in the mixture: results are bit-identical to the single-stream order."""
+        """outs[i] = ops[i](x, args[i]).  The surviving ops of a slot are independent given the slot input, so they are
+        issued round-robin on two HIP streams: launches of different ops overlap and fill each other's gaps - a
+        convolution launch runs its workgroups in lockstep rounds and leaves the matrix pipes idle through each
+        prologue / store drain, worst on a small batch (the per-GPU batch of the 8-GPU search is 4 images: one or two
+        rounds per launch).  The backward pass inherits the streams (autograd runs a node on the stream of its
+        forward).  Same kernels, same arguments, same summation order in the mixture: results are bit-identical to
+        the single-stream order.  Measured (tools/bench_darts.py, n_step 2): batch 4 0.113 -> 0.097 s per iteration,
+        batch 32 0.62 -> 0.60 s; 3 and 4 streams are no faster."""
         pixels = x.shape[0] * x.shape[2] * x.shape[3]
         n_streams = SLOT_STREAMS if (x.is_cuda and len(ops) > 2 and pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
         if n_streams <= 1:
