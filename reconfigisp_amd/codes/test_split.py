@@ -28,6 +28,10 @@ from .utils import util
 from .utils.util_path_restore import blend_tiles, gather_tiles, tile_grid
 
 
+TILE_STREAMS = int(os.environ.get('RISP_TILE_STREAMS', '2'))      # 1 = everything on the current stream
+_SIDE = {}
+
+
 def run_frame(model, frame, size, stride, tile_batch=16, rank=0, world=1, gather=gather_tiles, blend=blend_tiles):
     """frame: (1,C,H,W) tensor.  Returns the blended (1,3,H,W) output of the last pipeline stage.
 
@@ -44,11 +48,30 @@ def run_frame(model, frame, size, stride, tile_batch=16, rank=0, world=1, gather
     if rank <= 0:
         print('Split into {} patches'.format(len(positions)))
     outs = []
-    for at in range(0, len(mine), tile_batch):
+    # Tile batches are independent: consecutive batches alternate between two HIP streams, so the convolution launches of
+    # one batch fill the prologue / store-drain gaps of the other's (each launch runs its workgroups in lockstep
+    # rounds).  Same kernels on the same data: the result does not change.
+    main = torch.cuda.current_stream() if img.is_cuda else None
+    side = None
+    if main is not None and TILE_STREAMS > 1 and len(mine) > tile_batch:
+        side = _SIDE.setdefault(img.device.index, torch.cuda.Stream(device=img.device))
+        side.wait_stream(main)
+        tiles.record_stream(side)
+    for k, at in enumerate(range(0, len(mine), tile_batch)):
         chunk = tiles[at: at + tile_batch]
-        model.feed_data((chunk, chunk))            # dummy ground truth, as in the reference (:93)
-        _, mids = model.test()
+        stream = side if (side is not None and k % 2) else main
+        if stream is None:
+            model.feed_data((chunk, chunk))        # dummy ground truth, as in the reference (:93)
+            _, mids = model.test()
+        else:
+            with torch.cuda.stream(stream):
+                model.feed_data((chunk, chunk))
+                _, mids = model.test()
+            if stream is side:
+                mids[-1].record_stream(main)
         outs.append(mids[-1])
+    if side is not None:
+        main.wait_stream(side)
     local = torch.cat(outs, dim=0)
     if world > 1:
         import torch.distributed as dist
