@@ -200,15 +200,16 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     # step is 7 % faster (0.912 -> 0.848 s) - so F(4,3) now serves training forwards too (RISP_F43_TRAIN=0 restores
     # F(2,3)).  Backward-data passes take their masks from the saved forward activations: their own rounding only
     # perturbs the gradient smoothly.
-    # Backward-data passes on small grids (the per-GPU batch of the 8-GPU search is 4 images): F(4,3)'s 128-pixel-wide tiles then give the chip
+    # Training passes (forward and backward-data) on small grids (the per-GPU batch of the 8-GPU search is 4 images): F(4,3)'s 128-pixel-wide tiles then give the chip
     # only one or two rounds of workgroups, which run in lockstep and expose every prologue and epilogue; F(2,3)'s
     # 64-wide tiles with both cout blocks in one workgroup is faster there despite issuing 4/3 of the MFMAs
     # (4 x 64 x 256 x 256: 97 us against 110 us).
     big_grid = n * ((h + 3) // 4) * ((w + 127) // 128) * ((cout + 31) // 32) >= F43_MIN_GRID
     if transpose and pc.wino43_bwd is not None and big_grid:
         wino, entry = pc.wino43_bwd, 'risp_conv2d_wino43'
-    elif pc.wino43_fwd is not None and not transpose and (infer or F43_TRAIN):      # inference: always F(4,3), so that a tile's
-        wino, entry = pc.wino43_fwd, 'risp_conv2d_wino43'             # result never depends on the batch it travels in
+    elif pc.wino43_fwd is not None and not transpose and (infer or (F43_TRAIN and big_grid)):
+        # (inference: always F(4,3), so that a tile's result never depends on the batch it travels in)
+        wino, entry = pc.wino43_fwd, 'risp_conv2d_wino43'
     use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
                 (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
                  (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
