@@ -27,7 +27,7 @@ WINOGRAD = os.environ.get('RISP_WINOGRAD', '1') != '0'
 WINO_F43 = os.environ.get('RISP_WINO_F43', '1') != '0'       # 3x3: F(4,3) (default) or F(2,3)
 _WINO_EPI = EPI_RELU | EPI_ADD | EPI_MASK | EPI_NOBIAS
 F43_TRAIN = os.environ.get('RISP_F43_TRAIN', '1') == '1'       # F(4,3) also for training forwards (0: F(2,3) there, as in round 1)
-F43_MIN_GRID = int(os.environ.get('RISP_F43_MIN_GRID', '2048'))   # workgroups below which F(2,3) replaces F(4,3) (see conv())
+F43_MIN_GRID = int(os.environ.get('RISP_F43_MIN_GRID', '0'))      # workgroups below which backward-data passes take F(2,3) (see conv())
 
 
 def wino3_weights(w, transpose, ck):
@@ -200,14 +200,14 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     # step is 7 % faster (0.912 -> 0.848 s) - so F(4,3) now serves training forwards too (RISP_F43_TRAIN=0 restores
     # F(2,3)).  Backward-data passes take their masks from the saved forward activations: their own rounding only
     # perturbs the gradient smoothly.
-    # Training passes (forward and backward-data) on small grids (the per-GPU batch of the 8-GPU search is 4 images): F(4,3)'s 128-pixel-wide tiles then give the chip
-    # only one or two rounds of workgroups, which run in lockstep and expose every prologue and epilogue; F(2,3)'s
-    # 64-wide tiles with both cout blocks in one workgroup is faster there despite issuing 4/3 of the MFMAs
-    # (4 x 64 x 256 x 256: 97 us against 110 us).
+    # Small grids (the per-GPU batch of the 8-GPU search is 4 images): F(4,3)'s 128-pixel-wide tiles then give the chip only
+    # one or two lockstep rounds of workgroups and a lone launch is slower than F(2,3) (4 x 64 x 256 x 256: 110 us
+    # against 97 us) - but with the ops of a slot on two streams (section 5.1 of DESIGN.md) launches overlap and F(4,3)
+    # wins again (DARTS iteration at batch 4: 0.090 s against 0.094 s), so the switch F43_MIN_GRID defaults to off.
     big_grid = n * ((h + 3) // 4) * ((w + 127) // 128) * ((cout + 31) // 32) >= F43_MIN_GRID
     if transpose and pc.wino43_bwd is not None and big_grid:
         wino, entry = pc.wino43_bwd, 'risp_conv2d_wino43'
-    elif pc.wino43_fwd is not None and not transpose and (infer or (F43_TRAIN and big_grid)):
+    elif pc.wino43_fwd is not None and not transpose and (infer or F43_TRAIN):
         # (inference: always F(4,3), so that a tile's result never depends on the batch it travels in)
         wino, entry = pc.wino43_fwd, 'risp_conv2d_wino43'
     use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
