@@ -261,7 +261,8 @@ def test_inference_dispatch_f43(cin, cout, hw, monkeypatch):
     assert pc.wino43_fwd is not None and pc.wino_fwd is not None
     x, add, mask = rnd(n, cin, h, w, seed=73), rnd(n, cout, h, w, seed=74), rnd(n, cout, h, w, seed=75)
     lin = TF.conv2d(x, wt, b, padding=1)
-    monkeypatch.setattr(CN, 'F43_MIN_GRID', 0)          # F(4,3) also on these small grids (the product switches at 2048 tiles)
+    monkeypatch.setattr(CN, 'F43_MIN_GRID', 0)
+    monkeypatch.setattr(CN, 'F43_TRAIN', False)         # infer=False -> F(2,3) (the RISP_F43_TRAIN=0 form), infer=True -> F(4,3)
     for infer in (True, False):
         assert_close(CN.conv(x, pc, n, h, w, infer=infer), lin, what='plain infer=%s' % infer)
         assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=cout, infer=infer),
@@ -279,8 +280,8 @@ _FUZZ = int(os.environ.get('RISP_TEST_SEEDS', '8')) * 6            # soak runs: 
 @pytest.mark.parametrize('seed', range(_FUZZ))
 def test_random_layer_shapes(seed, monkeypatch):
     from reconfigisp_amd import convnets as CN
-    if seed % 2 == 0:
-        monkeypatch.setattr(CN, 'F43_MIN_GRID', 0)      # every other case: F(4,3) on the small grid too
+    monkeypatch.setattr(CN, 'F43_TRAIN', seed % 2 == 0)             # every other case: F(2,3) for the infer=False passes
+    monkeypatch.setattr(CN, 'F43_MIN_GRID', 0 if seed % 4 < 2 else 1 << 30)   # ... and for the backward-data pass
     rng = np.random.default_rng(9000 + seed)
     k = int(rng.choice([1, 3, 3, 5, 5, 9]))
     cin, cout = int(rng.integers(1, 65)), int(rng.integers(1, 65))
