@@ -31,7 +31,7 @@ def test_bench_line_is_self_consistent():
     assert extra['kernel_ms'] <= line['ms_per_step'] * 1.001                 # a kernel cannot outlast its step
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3 and 0 < roof['frac'] < 1
     pix = 64 * 256 * 256
-    assert abs(roof['achieved'] - 64 * pix / (extra['kernel_ms'] * 1e-3) / 1e9) < 1.0
+    assert abs(roof['achieved'] - 64 * pix / (extra['kernel_ms'] * 1e-3) / 1e9) < 5.0      # kernel_ms is rounded to 0.01 us
     assert abs(line['value'] - pix / (line['ms_per_step'] * 1e-3) / 1e6) < 0.01 * line['value']
     assert 0 < extra['cnn_mfma_issued_frac'] < extra['cnn_effective_frac'] < 1.5
     assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['value'] > 0
