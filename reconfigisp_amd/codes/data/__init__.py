@@ -30,6 +30,11 @@ def create_dataloader(dataset, dataset_opt, opt=None, sampler=None, collate_fn=N
         batch = dataset_opt['batch_size']
         workers = dataset_opt['n_workers'] * len(opt['gpu_ids'] or [0])
         shuffle = sampler is None
+    if dataset_opt.get('device_resident') and hasattr(dataset, '_frames') and torch.cuda.is_available():
+        # frames stay in HBM, a batch is two gather kernels (data/device_loader.py); the sampler only says WHICH frames
+        from .device_loader import DeviceCropLoader
+        frames = list(sampler) if sampler is not None else list(range(len(dataset)))
+        return DeviceCropLoader(dataset, batch, frames, torch.device('cuda'))
     return torch.utils.data.DataLoader(dataset, batch_size=batch, shuffle=shuffle, num_workers=workers, sampler=sampler,
                                        drop_last=True, pin_memory=False, collate_fn=collate_fn or default_collate)
 

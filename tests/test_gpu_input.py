@@ -66,3 +66,38 @@ def test_random_input_geometry_bit_exact(seed):
     if lw > lh + 8:        # a portrait frame would need negative padding (oneplus_rggb2obj_dataset.py:127-133 fails too)
         with pytest.raises(RuntimeError):
             G.resize_rggb_letterbox(torch.from_numpy(np.ascontiguousarray(img.T)).cuda(), desired)
+
+
+def test_device_resident_loader_matches_the_host_dataset(tmp_path):
+    """`device_resident: true`: the frames of an RGGB2BGR dataset live in HBM and a batch is two gather kernels - the
+    crops must be what the host path (data/rggb2bgr_datasets.py, the reference's formula) computes for the same
+    (frame, row, col) selection, bit for bit."""
+    import pickle
+    from reconfigisp_amd.codes.data import create_dataloader, create_dataset
+    from reconfigisp_amd.codes.data.device_loader import DeviceCropLoader
+    from reconfigisp_amd.codes.data.image_io import write_png
+    rng = np.random.default_rng(2)
+    keys_n, keys_g, frames = [], [], []
+    for i in range(5):
+        raw = rng.integers(0, 16384, size=(40, 40), dtype=np.uint16)
+        gt = rng.integers(0, 256, size=(40, 40, 3), dtype=np.uint8)
+        write_png(str(tmp_path / ('n%d.png' % i)), raw)
+        write_png(str(tmp_path / ('g%d.png' % i)), gt)
+        keys_n.append('n%d.png' % i); keys_g.append('g%d.png' % i); frames.append((raw, gt))
+    with open(tmp_path / 'meta_info.pkl', 'wb') as f:
+        pickle.dump({'keys_ratio': keys_n, 'keys_gt': keys_g, 'resolution': 40}, f)
+    dopt = {'mode': 'SID_Sony_Ratio_RGGB2BGR', 'phase': 'train', 'dataroot': str(tmp_path), 'data_type': 'img', 'data_size': 16,
+            'sid_expo_in': None, 'sid_expo_gt': None, 'batch_size': 6, 'n_workers': 0, 'device_resident': True}
+    ds = create_dataset(dopt)
+    loader = create_dataloader(ds, dopt, {'dist': False, 'gpu_ids': [0]}, sampler=[0, 2, 3])
+    assert isinstance(loader, DeviceCropLoader) and loader.raw.shape == (3, 40, 40) and loader.gt.shape == (3, 40, 40, 3)
+    for batch in loader:
+        sel = loader.last_selection.tolist()
+        assert batch['noisy'].shape == (6, 1, 16, 16) and batch['gt'].shape == (6, 3, 16, 16) and batch['noisy'].is_cuda
+        for b, (f, r, c) in enumerate(sel):
+            raw, gt = frames[[0, 2, 3][f]]
+            assert r % 2 == 0 and c % 2 == 0
+            want_n = raw[r:r + 16, c:c + 16].astype(np.float32) / np.float32(16383.)
+            want_g = np.transpose(gt[r:r + 16, c:c + 16], (2, 0, 1)).astype(np.float32) / np.float32(255.)
+            assert np.array_equal(batch['noisy'][b, 0].cpu().numpy(), want_n)
+            assert np.array_equal(batch['gt'][b].cpu().numpy(), want_g)
