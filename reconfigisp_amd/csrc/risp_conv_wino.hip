@@ -422,6 +422,7 @@ constexpr int W43TW = 128, W43WP = W43TW + 8, W43TAPS = 18;
 // All loads of a batch (bias, residual, mask) are issued unconditionally inside wave-uniform branches, one batch ahead
 // of the arithmetic: written per element ("if (epi & ADD) load") hipcc branches around every load and waits
 // vmcnt(0) after each, i.e. 16 x 3 dependent memory round trips per wave (r01: 10 % of a wave's life).
+template <int EB = 4>
 __device__ __forceinline__ void w43_epilogue(const risp_conv_desc &d, const f32x16 (&acc)[6], int n, int cb, int oy, int ox,
                                              int half) {
     if (!(oy < d.H && ox < d.W)) return;
@@ -440,20 +441,20 @@ __device__ __forceinline__ void w43_epilogue(const risp_conv_desc &d, const f32x
 #pragma unroll
         for (int e = 0; e < 16; ++e) bias[e] = 0.f;
     }
-    float4 av[2][4], mv[2][4];
+    float4 av[2][EB], mv[2][EB];
     auto load_batch = [&](int b, int slot) {
         if (has_add) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = co_of(4 * b + i);
+            for (int i = 0; i < EB; ++i) {
+                const int co = co_of(EB * b + i);
                 const int cc = co < d.add_c ? co : d.add_c - 1;               // clamped: always a valid address
                 av[slot][i] = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + cc) * hw + pix);
             }
         }
         if (has_mask) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = co_of(4 * b + i);
+            for (int i = 0; i < EB; ++i) {
+                const int co = co_of(EB * b + i);
                 const int cc = co < d.cout ? co : d.cout - 1;
                 mv[slot][i] = *reinterpret_cast<const float4 *>(d.mask + ((size_t)n * d.cout + cc) * hw + pix);
             }
@@ -461,12 +462,12 @@ __device__ __forceinline__ void w43_epilogue(const risp_conv_desc &d, const f32x
     };
     load_batch(0, 0);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < 16 / EB; ++b) {
         const int slot = b & 1;
-        if (b + 1 < 4) load_batch(b + 1, slot ^ 1);
+        if (b + 1 < 16 / EB) load_batch(b + 1, slot ^ 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = 4 * b + i, co = co_of(e);
+        for (int i = 0; i < EB; ++i) {
+            const int e = EB * b + i, co = co_of(e);
             const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
             const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
             const float bb = bias[e];
@@ -669,6 +670,132 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// F(4,3) with LDS-DMA staging (global_load_lds_dwordx4): the form risp_conv2d_wino43 launches whenever cin % 4 == 0.
+// Same tile, operand reads, MFMA stream and epilogue as conv_wino43_kernel; the input tile and the weight slab of a
+// chunk go global -> LDS directly: no staging registers and no ds_write pass, which (with a one-deep epilogue
+// prefetch) brings the kernel to 166 registers = THREE workgroups per CU on 2 x 24.5 KB of LDS each.  The staging
+// area is zeroed once; lanes whose element lies outside the image - the same lanes in every chunk, hence the
+// cin % 4 == 0 requirement - are masked out of the DMA by EXEC (inside the asm statement, so every wave issues
+// exactly 6 DMA instructions per chunk: 24 wave-instructions of 64 x 16 bytes, 14 for the 896-float4 padded input
+// tile, 10 for the 640-float4 padded weight slab) and keep their zeros.  (Pointing such lanes at 16 zero bytes in
+// global memory instead costs 60 %: every CU then hammers one cache line.)  The DMA is inline asm: with the builtin
+// hipcc degrades the counted lgkmcnt waits of the operand reads to lgkmcnt(0).
+// Measured (tools/ab_wino43.py, 64 -> 64 on 64 x 128 x 128): 397 us register-staged, 384 us this form at 2 workgroups
+// per CU, **368 us** at 3 (3 LDS stages with the transfer two chunks ahead: 392 us); residual + ReLU layer 422 -> 396 us.
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int STAGES, int WGS>
+__global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_conv_desc d, int ncb) {
+    constexpr int CK = 4, CP = 32;
+    constexpr int XN = CK * WIH * W43WP, WN = W43TAPS * CK * CP;       // floats: 3264, 2304
+    constexpr int XI = 14, WI = 10, PER_WAVE = (XI + WI) / 4;            // wave-instructions per chunk
+    constexpr int XPAD = XI * 64 * 4, STAGE = (XI + WI) * 64 * 4;        // floats per padded input tile / per stage
+    static_assert(XN <= XPAD && WN <= WI * 64 * 4 && (XI + WI) % 4 == 0, "staging layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // [STAGES][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * W43TW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const int nchunks = d.cin / CK;
+    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // zero the whole staging area once (masked lanes never write their slots)
+    for (int v = tid; v < STAGES * STAGE / 4; v += 256) reinterpret_cast<float4 *>(smem)[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // this wave's 6 DMA slots: id = wave + 4 j; ids 0..13 input tile, 14..23 weight slab
+    const float *src0[PER_WAVE];
+    unsigned long long mask[PER_WAVE];
+    int step[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int id = wave + 4 * j;
+        bool ok;
+        if (id < XI) {
+            const int v = id * 64 + lane;
+            const int cl = v / (WIH * (W43WP / 4)), rem = v - cl * (WIH * (W43WP / 4));
+            const int iy = rem / (W43WP / 4), q = rem - iy * (W43WP / 4);
+            const int gy = y0 + iy - 1, gx = x0 - 4 + 4 * q;
+            ok = v < XN / 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            src0[j] = xn + ((size_t)cl * d.H + gy) * d.W + gx;
+            step[j] = CK * (int)hw;
+        } else {
+            const int v = (id - XI) * 64 + lane;
+            ok = v < WN / 4;
+            src0[j] = wpack + 4 * v;
+            step[j] = WN;
+        }
+        mask[j] = __builtin_amdgcn_ballot_w64(ok);
+    }
+    auto issue = [&](int ch, int buf) {
+        float *stage = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int id = wave + 4 * j;
+            const float *src = src0[j] + (size_t)ch * step[j];
+            float *dst = stage + (id < XI ? id * 256 : XPAD + (id - XI) * 256);      // wave-uniform; the lane's slot is +16 B * lane
+            const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)dst);
+            unsigned long long keep_exec;
+            unsigned keep_m0;
+            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+                         : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(src), "s"(lds_dst), "s"(mask[j]) : "memory");
+        }
+    };
+
+    __syncthreads();                                   // zeros in place before the first DMA lands
+#pragma unroll
+    for (int c = 0; c < STAGES - 1; ++c)
+        if (c < nchunks) issue(c, c);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch % STAGES;
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): every DMA this wave has issued (chunks <= ch + STAGES - 2) has landed
+        __builtin_amdgcn_s_barrier();                  // ... for every wave; buffer (ch-1) % STAGES is free
+        if (ch + STAGES - 1 < nchunks) issue(ch + STAGES - 1, (ch + STAGES - 1) % STAGES);
+        const float *sx = smem + buf * STAGE, *sw = sx + XPAD;
+        const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (half * WIH + wave) * W43WP) + l31;
+        const float *aw = sw + half * CP + l31;
+        constexpr int NG = 3 * (CK / 2);
+        float opa[2][6];
+        f32x4 opd[2][3];
+        auto load_group = [&](int g, int slot) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+            const f32x4 *dp = bx + (2 * cp * WIH + ky) * (W43WP / 4);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) opd[slot][j] = dp[j];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot = g & 1;
+            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(opd[slot][0]), "+v"(opd[slot][2]));
+            const float d0 = opd[slot][0].w, d1 = opd[slot][1].x, d2 = opd[slot][1].y, d3 = opd[slot][1].z,
+                        d4 = opd[slot][1].w, d5 = opd[slot][2].x;
+            const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
+            const float bv[6] = {__builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4)), __builtin_fmaf(4.f, s12, -s34),
+                                 __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
+                                 __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    w43_epilogue<WGS == 3 ? 1 : 4>(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);   // 3 workgroups per CU: 168 registers
+}
+
 template <int CK, int CB>
 int launch_wino(const risp_conv_desc &d, hipStream_t s) {
     constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * 32 * CB;
@@ -755,6 +882,27 @@ int risp_conv2d_wino43(const risp_conv_desc *dp, void *stream) {
     const int ncb = (d.cout + 31) / 32;
     constexpr int XN = W43CK * WIH * W43WP, WN = W43TAPS * W43CK * 32;
     dim3 grid((d.W + W43TW - 1) / W43TW, (d.H + WTH - 1) / WTH, d.N * ncb);
+#ifndef RISP_W43_NO_GLDS
+    if (d.cin % 4 == 0) {                              // LDS-DMA staging, 2 LDS stages, 3 workgroups per CU (see the kernel)
+#ifndef RISP_W43_GLDS
+#define RISP_W43_GLDS 2
+#endif
+#ifndef RISP_W43_GLDS_WGS
+#define RISP_W43_GLDS_WGS 3
+#endif
+        constexpr int ST = RISP_W43_GLDS;
+        const size_t lds_g = sizeof(float) * ST * 24 * 64 * 4;
+        if (lds_g > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino43_glds_kernel<ST, RISP_W43_GLDS_WGS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g) != hipSuccess) {
+            risp_set_error("risp_conv2d_wino43: cannot raise the dynamic LDS limit to %zu bytes", lds_g);
+            return 2;
+        }
+        hipLaunchKernelGGL((conv_wino43_glds_kernel<ST, RISP_W43_GLDS_WGS>), grid, dim3(256), lds_g, (hipStream_t)stream, d, ncb);
+        RISP_LAUNCH_CHECK("risp_conv2d_wino43");
+        return 0;
+    }
+#endif
     const size_t lds = sizeof(float) * 2 * (XN + WN);
     hipLaunchKernelGGL(conv_wino43_kernel<W43CK>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
     RISP_LAUNCH_CHECK("risp_conv2d_wino43");
