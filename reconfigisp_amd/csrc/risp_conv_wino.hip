@@ -25,6 +25,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lptr_t;
 // Diagnostic build only (-DRISP_CONV_STAMPS, tools/conv_stamps.py wino): per-wave cycle shares written to the
 // (otherwise unused) mask buffer.  Never compiled into the product.
 #ifdef RISP_CONV_STAMPS
@@ -38,6 +39,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #else
 #define WSTAMP(var) do { } while (0)
 #endif
+// One LDS-DMA wave-instruction: lanes whose bit is set in `mask` copy 16 bytes from their `src` to LDS byte address
+// lds_dst + 16 * lane; the others are switched off by EXEC inside the statement (no compiler branch around it, so
+// every wave issues the same number of DMAs) and leave their slot untouched.  M0 and EXEC are saved and restored in
+// the same statement.  Inline asm rather than __builtin_amdgcn_global_load_lds: beside the builtin hipcc turns the
+// counted lgkmcnt(N) waits of the following operand reads into lgkmcnt(0).
+__device__ __forceinline__ void lds_dma16(const float *src, float *dst_wave_base, unsigned long long mask) {
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)dst_wave_base);
+    unsigned long long keep_exec;
+    unsigned keep_m0;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(src), "s"(lds_dst), "s"(mask) : "memory");
+}
+
 constexpr int WTW = 64, WTH = 4;               // output tile: 64 pixels (32 pairs) x 4 rows
 constexpr int WIH = WTH + 2, WIWP = WTW + 8;    // staged rows / row stride: column c <-> image x0 - 4 + c
 constexpr int WTAPS = 12;                       // 3 filter rows x 4 transform points
@@ -408,6 +423,123 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// F(2,5) with LDS-DMA staging: conv_wino5_kernel's tile, operand reads, MFMA stream and epilogue with the staging of
+// conv_wino43_glds_kernel (see there).  The raw tile (4 x 8 x 72 floats = 9 wave-instructions of 64 x 16 bytes) and
+// the weight slab (30 x 4 x 32 floats = 15) make exactly 24 = 6 per wave; 2 LDS stages of 24 KB, 3 workgroups per CU.
+template <int WGS>
+__global__ __launch_bounds__(256, WGS) void conv_wino5_glds_kernel(const risp_conv_desc d, int ncb) {
+    constexpr int CK = 4, CP = 32;
+    constexpr int XN = CK * W5IH * WIWP, WN = W5TAPS * CK * CP;          // floats: 2304, 3840
+    constexpr int XI = XN / 256, WI = WN / 256, PER_WAVE = (XI + WI) / 4;
+    constexpr int STAGE = XN + WN;
+    static_assert(XN % 256 == 0 && WN % 256 == 0 && (XI + WI) % 4 == 0, "staging layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];         // [2][STAGE]; the epilogue reuses it
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const int nchunks = d.cin / CK;
+    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    for (int v = tid; v < 2 * STAGE / 4; v += 256) reinterpret_cast<float4 *>(smem)[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float *src0[PER_WAVE];
+    unsigned long long mask[PER_WAVE];
+    int step[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int id = wave + 4 * j;
+        bool ok;
+        if (id < XI) {
+            const int v = id * 64 + lane;
+            const int cl = v / (W5IH * (WIWP / 4)), rem = v - cl * (W5IH * (WIWP / 4));
+            const int iy = rem / (WIWP / 4), q = rem - iy * (WIWP / 4);
+            const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * q;
+            ok = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            src0[j] = xn + ((size_t)cl * d.H + gy) * d.W + gx;
+            step[j] = CK * (int)hw;
+        } else {
+            ok = true;
+            src0[j] = wpack + 4 * ((id - XI) * 64 + lane);
+            step[j] = WN;
+        }
+        mask[j] = __builtin_amdgcn_ballot_w64(ok);
+    }
+    auto issue = [&](int ch, int buf) {
+        float *stage = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int id = wave + 4 * j;
+            lds_dma16(src0[j] + (size_t)ch * step[j], stage + id * 256, mask[j]);      // ids 0..8 tile, 9..23 slab: contiguous
+        }
+    };
+
+    __syncthreads();                                   // zeros in place before the first DMA lands
+    issue(0, 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's part of chunk ch has landed
+        __builtin_amdgcn_s_barrier();                  // ... every wave's; the other buffer is free
+        if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
+        const float *sx = smem + buf * STAGE, *sw = sx + XN;
+        // d0 of pair p sits at staged column 2p + 2 (image x0 + 2p - 2): 8-byte aligned
+        const float *bx = sx + (half * W5IH + wave) * WIWP + 2 + 2 * l31;
+        const float *aw = sw + half * CP + l31;
+        constexpr int NG = 5 * (CK / 2);
+        float opa[2][6], opd[2][6];
+        auto load_group = [&](int g, int slot) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+            const float *dp = bx + (2 * cp * W5IH + ky) * WIWP;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) opd[slot][j] = dp[j];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot = g & 1;
+            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3], d4 = opd[slot][4],
+                        d5 = opd[slot][5];
+            const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
+            const float bv[6] = {__builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4)), __builtin_fmaf(4.f, s12, -s34),
+                                 __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
+                                 __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue (as conv_wino5_kernel)
+    const int oy = y0 + wave;
+    __syncthreads();                                   // every wave is done with the staging tiles
+    float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int col = (e & 3) + 8 * (e >> 2) + 4 * half;
+        const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+        float2 y2;
+        y2.x = m0 + m1 + m2 + m3 + m4;
+        y2.y = m1 - m2 + 2.f * m3 - 2.f * m4 + m5;
+        *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    store_block32(d, tile, lane, n, cb * 32, oy, x0);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3x3 layers, F(4,3) along x: FOUR adjacent outputs of a filter row from 6 multiplications - 18 "taps" per output
 // quad where F(2,3) above needs 24 and the direct kernel 36 (half its MFMA work).  Same interpolation points and
 // scaled input transform as F(2,5); U_t = (G g)_t with G rows (1/4,0,0) (1/6,1/6,1/6) (1/6,-1/6,1/6)
@@ -683,8 +815,6 @@ __global__ __launch_bounds__(256, RISP_W43_WAVES) void conv_wino43_kernel(const 
 // hipcc degrades the counted lgkmcnt waits of the operand reads to lgkmcnt(0).
 // Measured (tools/ab_wino43.py, 64 -> 64 on 64 x 128 x 128): 397 us register-staged, 384 us this form at 2 workgroups
 // per CU, **368 us** at 3 (3 LDS stages with the transfer two chunks ahead: 392 us); residual + ReLU layer 422 -> 396 us.
-typedef __attribute__((address_space(3))) void lptr_t;
-
 template <int STAGES, int WGS>
 __global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_conv_desc d, int ncb) {
     constexpr int CK = 4, CP = 32;
@@ -742,12 +872,7 @@ __global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_c
             const int id = wave + 4 * j;
             const float *src = src0[j] + (size_t)ch * step[j];
             float *dst = stage + (id < XI ? id * 256 : XPAD + (id - XI) * 256);      // wave-uniform; the lane's slot is +16 B * lane
-            const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)dst);
-            unsigned long long keep_exec;
-            unsigned keep_m0;
-            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
-                         : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(src), "s"(lds_dst), "s"(mask[j]) : "memory");
+            lds_dma16(src, dst, mask[j]);
         }
     };
 
@@ -939,6 +1064,16 @@ int risp_conv2d_wino5(const risp_conv_desc *dp, void *stream) {
     const size_t epi = sizeof(float) * 4 * 32 * WTW;
     if (lds < epi) lds = epi;
     dim3 grid((d.W + WTW - 1) / WTW, (d.H + WTH - 1) / WTH, d.N * ncb);
+#ifndef RISP_W5_NO_GLDS
+    if (d.cin % 4 == 0) {                              // LDS-DMA staging, 3 workgroups per CU
+#ifndef RISP_W5_GLDS_WGS
+#define RISP_W5_GLDS_WGS 3
+#endif
+        hipLaunchKernelGGL(conv_wino5_glds_kernel<RISP_W5_GLDS_WGS>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
+        RISP_LAUNCH_CHECK("risp_conv2d_wino5");
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(conv_wino5_kernel<W5CK>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
     RISP_LAUNCH_CHECK("risp_conv2d_wino5");
     return 0;
