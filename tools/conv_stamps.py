@@ -12,7 +12,8 @@ so = '/tmp/librisp_stamps.so'
 import glob
 src = glob.glob(os.path.join(ROOT, 'reconfigisp_amd/csrc', '*.hip')) + [os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_core.cpp')]
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off',
-                       '-DRISP_CONV_STAMPS', '-I' + os.path.join(ROOT, 'include'),
+                       '-DRISP_CONV_STAMPS', '-DRISP_W43_NO_GLDS', '-DRISP_W5_NO_GLDS',      # the stamps live in the register-staged kernels
+                       '-I' + os.path.join(ROOT, 'include'),
                        '-I' + os.path.join(ROOT, 'reconfigisp_amd/csrc'), '-x', 'hip', '-shared', '-o', so] + src)
 import torch
 from reconfigisp_amd import lib as L
