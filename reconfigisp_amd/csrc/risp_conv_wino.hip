@@ -491,15 +491,30 @@ __global__ __launch_bounds__(256, WGS) void conv_wino5_glds_kernel(const risp_co
         if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
         const float *sx = smem + buf * STAGE, *sw = sx + XN;
         // d0 of pair p sits at staged column 2p + 2 (image x0 + 2p - 2): 8-byte aligned
+#ifndef RISP_W5_FUSED_READS
+        // three separate 8-byte reads (the second and third base made opaque): from one base + constant offsets hipcc
+        // fuses them into ds_read2_b64, 8 LDS cycles where two ds_read_b64 take 2 + 2 (1075 -> 1060 us on 64 -> 32, 32 x 256 x 256)
+        typedef __attribute__((address_space(3))) const f32x2 lds_pair;
+        const unsigned b0 = (unsigned)(size_t)(lds_pair *)(sx + (half * W5IH + wave) * WIWP + 2 + 2 * l31);
+        unsigned b1 = b0 + 8, b2 = b0 + 16;
+        asm volatile("" : "+v"(b1), "+v"(b2));
+#else
         const float *bx = sx + (half * W5IH + wave) * WIWP + 2 + 2 * l31;
+#endif
         const float *aw = sw + half * CP + l31;
         constexpr int NG = 5 * (CK / 2);
         float opa[2][6], opd[2][6];
         auto load_group = [&](int g, int slot) {
             const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+#ifndef RISP_W5_FUSED_READS
+            const unsigned go = (2 * cp * W5IH + ky) * WIWP * 4;
+            const f32x2 p0 = *(lds_pair *)(size_t)(b0 + go), p1 = *(lds_pair *)(size_t)(b1 + go), p2 = *(lds_pair *)(size_t)(b2 + go);
+            opd[slot][0] = p0.x; opd[slot][1] = p0.y; opd[slot][2] = p1.x; opd[slot][3] = p1.y; opd[slot][4] = p2.x; opd[slot][5] = p2.y;
+#else
             const float *dp = bx + (2 * cp * W5IH + ky) * WIWP;
 #pragma unroll
             for (int j = 0; j < 6; ++j) opd[slot][j] = dp[j];
+#endif
 #pragma unroll
             for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
         };
