@@ -84,6 +84,11 @@ int risp_channel_stats(const float *x, float *stats, int32_t *arg, float *scratc
  * gx[argmin] += g_min[plane], gx[argmax] += g_max[plane]; any of the three may be NULL. */
 int risp_stats_bwd(float *gx, const float *g_min, const float *g_mean, const float *g_max,
                    const int32_t *arg, int NC, int HW, void *stream);
+/* the same with the three gradients as column ranges of a row-major (N, row_stride) matrix - plane n * C + c reads
+ * g_*[n * row_stride + c] - so that SRCNNRes' folded backward (srcnn_res_arch.py:36-46) passes slices of its
+ * (N, 9+P) constant-plane gradient without copying them out. */
+int risp_stats_bwd_rows(float *gx, const float *g_min, const float *g_mean, const float *g_max,
+                        const int32_t *arg, int N, int C, int HW, int row_stride, void *stream);
 
 /* Per-plane histogram with torch.histc(x, bins, min=0, max=1) semantics (raw counts as fp32;
  * out-of-range values ignored; x == 1 in the last bin) - the conditional heads' feature,
@@ -276,6 +281,7 @@ typedef struct risp_param_blocks_desc {
     float *block[RISP_MAX_PARAM_OPS];             /* forward: (N, width) out */
     const float *gblock[RISP_MAX_PARAM_OPS];      /* backward: (N, width) in, may be NULL */
     float *graw[RISP_MAX_PARAM_OPS];              /* backward: (width) out */
+    int gstride[RISP_MAX_PARAM_OPS];              /* backward: floats between the rows of gblock[k] (0 = width: packed) */
 } risp_param_blocks_desc;
 int risp_param_blocks_fwd(const risp_param_blocks_desc *d, void *stream);
 int risp_param_blocks_bwd(const risp_param_blocks_desc *d, void *stream);

@@ -150,8 +150,10 @@ class SmallConv:
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 
-def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
-    """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 4)."""
+def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False):
+    """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 12).  ``infer``: never split the input
+    channels over workgroups - the split depends on the grid, and an inference result must not depend on the batch a
+    tile travels in (test_split.py batches tiles)."""
     if sc.bias is None:
         epi |= EPI_NOBIAS
     shape = (n, sc.cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, sc.cout, h, w)
@@ -159,7 +161,7 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None):
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
-    groups = L.load().risp_conv_small_groups(C.byref(d))
+    groups = 1 if infer else L.load().risp_conv_small_groups(C.byref(d))
     if groups > 1:                                  # small grid: split the input channels over several workgroups per tile
         scratch = torch.empty((groups,) + tuple(out.shape), device=x.device, dtype=torch.float32)
         L.call('risp_conv2d_small_split', C.byref(d), _p(scratch), groups, _stream())
@@ -263,7 +265,7 @@ class _Path14l(torch.autograd.Function):
             r = conv(u, c2, n, h, w, epi=EPI_ADD | EPI_RELU, add=r, add_c=64, infer=infer)
             saved += [u, r]
         # the 64 -> 4 / 3 tail runs on the direct small-cout kernel (the matrix-core kernel pads cout to 32)
-        y = conv_small(r, last.small, n, h, w, epi=EPI_SHUFFLE2 if bayer else 0)
+        y = conv_small(r, last.small, n, h, w, epi=EPI_SHUFFLE2 if bayer else 0, infer=infer)
         ctx.save_for_backward(*saved)
         ctx.packs, ctx.bayer, ctx.dims = packs, bayer, (n, h, w)
         return y
@@ -382,7 +384,7 @@ class _SrcnnResFolded(torch.autograd.Function):
     over 3 channels instead of 12+P, its backward-data over 3 output channels instead of 32 padded ones."""
 
     @staticmethod
-    def forward(ctx, x, pv, packs):
+    def forward(ctx, x, pv, packs, infer=False):
         x = _dev(x, 'img')
         n, _, h, w = x.shape
         c1, c2, c3 = packs
@@ -395,7 +397,7 @@ class _SrcnnResFolded(torch.autograd.Function):
         table = torch.mm(cvals, fold.rcase)                              # (N, 64*81) border-case constants
         t1 = conv(x, fold.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table)
         t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
-        y = conv_small(t2, fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3)
+        y = conv_small(t2, fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, infer=infer)
         ctx.save_for_backward(t1, t2, arg)
         ctx.packs, ctx.dims = packs, (n, h, w, P)
         return y
@@ -413,9 +415,11 @@ class _SrcnnResFolded(torch.autograd.Function):
         rs = torch.empty((n, c1.cout * fold.k * fold.k), device=gy.device, dtype=torch.float32)
         L.call('risp_rect_sums', _p(g1), _p(rs), n * c1.cout, h, w, fold.k, _stream())
         gconst = torch.mm(rs, fold.wconst)                              # (N, 9+P): min, mean, max planes, then params
-        smin, smean, smax = (gconst[:, 0:3].contiguous(), gconst[:, 3:6].contiguous(), gconst[:, 6:9].contiguous())
-        L.call('risp_stats_bwd', _p(gx), _p(smin), _p(smean), _p(smax), _p(arg), n * 3, h * w, _stream())
-        return gx, (gconst[:, 9:].contiguous() if P else None), None
+        row = gconst.shape[1]                                           # columns 0-2 / 3-5 / 6-8 of each row, read in place
+        gb = gconst.data_ptr()
+        L.call('risp_stats_bwd_rows', _p(gx), C.c_void_p(gb), C.c_void_p(gb + 12), C.c_void_p(gb + 24), _p(arg), n, 3, h * w,
+               row, _stream())
+        return gx, (gconst[:, 9:] if P else None), None, None
 
 
 class _SrcnnResTrain(torch.autograd.Function):
@@ -473,21 +477,21 @@ def srcnn_res(x, pv, packs, train_module=None):
         return _SrcnnResTrain.apply(x, pv, packs, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias,
                                     seq[4].weight, seq[4].bias)
     if getattr(packs[0], 'fold', None) is not None and _srcnn_fold_ok(x.shape[2], x.shape[3]):
-        return _SrcnnResFolded.apply(x, pv, packs)
+        return _SrcnnResFolded.apply(x, pv, packs, not torch.is_grad_enabled())
     return _SrcnnRes.apply(x, pv, packs)
 
 
 # --------------------------------------------------------------------------- SRCNN demosaic proxy
 class _SrcnnDemosaic(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, packs):
+    def forward(ctx, x, packs, infer=False):
         x = _dev(x, 'img')
         n, h, w = x.shape[0], x.shape[2] // 2, x.shape[3] // 2
         c1, c2, c3 = packs
         t1 = conv(x, c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU)
         t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
         if getattr(c3, 'small', None) is not None:           # 5x5 32 -> 12 + PixelShuffle: direct small-cout kernel
-            y = conv_small(t2, c3.small, n, h, w, epi=EPI_SHUFFLE2)
+            y = conv_small(t2, c3.small, n, h, w, epi=EPI_SHUFFLE2, infer=infer)
         else:
             y = conv(t2, c3, n, h, w, epi=EPI_SHUFFLE2)
         ctx.save_for_backward(t1, t2)
@@ -506,11 +510,11 @@ class _SrcnnDemosaic(torch.autograd.Function):
             gx = conv_small(g1, c1.small_bwd, n, h, w, epi=EPI_SHUFFLE2)
         else:
             gx = conv(g1, c1, n, h, w, transpose=True, epi=EPI_SHUFFLE2)
-        return gx, None
+        return gx, None, None
 
 
 def srcnn_demosaic(x, packs):
-    return _SrcnnDemosaic.apply(x, packs)
+    return _SrcnnDemosaic.apply(x, packs, not torch.is_grad_enabled())
 
 
 def build_srcnn_packs(seq, residual=False):

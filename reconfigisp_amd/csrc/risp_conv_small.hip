@@ -307,6 +307,11 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(const risp_conv_desc 
     for (int g = 1; g < groups; ++g) v += partial[(size_t)g * total + i];
     const int epi = d.epilogue;
     if (!(epi & RISP_EPI_NOBIAS)) v += d.bias[co];
+    if (epi & RISP_EPI_SHUFFLE2) {          // PixelShuffle(2): cout 4g + 2i + j -> plane g, pixel (2y + i, 2x + j)
+        const size_t oy = pix / d.W, ox = pix - oy * d.W;
+        d.y[((n * (d.cout >> 2) + (co >> 2)) * 2 * d.H + 2 * oy + ((co >> 1) & 1)) * (2 * (size_t)d.W) + 2 * ox + (co & 1)] = v;
+        return;
+    }
     if ((epi & RISP_EPI_ADD) && co < d.add_c) v += d.add[(n * d.add_c + co) * plane + pix];
     if (epi & RISP_EPI_RELU) v = v > 0.f ? v : 0.f;
     if (epi & RISP_EPI_MASK) v = d.mask[i] > 0.f ? v : 0.f;
@@ -355,7 +360,7 @@ size_t risp_conv_small_wpack_floats(int cin, int cout, int ksize) {
 // Channel groups worth using for this layer on this grid (1 = none): small grids with many input channels, where one
 // workgroup per tile leaves most of the chip idle and a lone wave per SIMD cannot hide its scalar-load latency.
 int risp_conv_small_groups(const risp_conv_desc *dp) {
-    if (!dp || dp->cin < 32 || (dp->epilogue & RISP_EPI_SHUFFLE2)) return 1;
+    if (!dp || dp->cin < 32) return 1;
     const size_t tiles = (size_t)((dp->W + SX - 1) / SX) * ((dp->H + 15) / 16) * dp->N;
     if (tiles >= 768) return 1;
     const size_t tiles32 = (size_t)((dp->W + SX - 1) / SX) * ((dp->H + 31) / 32) * dp->N;   // the split runs on 64 x 32 tiles
@@ -376,8 +381,8 @@ int risp_conv2d_small_split(const risp_conv_desc *dp, float *scratch, int groups
 
 static int conv2d_small_impl(const risp_conv_desc *dp, float *scratch, int groups, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_small: null descriptor");
-    RISP_CHECK_ARG(groups <= 1 || (scratch && groups <= 16 && !(dp->epilogue & RISP_EPI_SHUFFLE2) && (size_t)dp->N * groups <= 65535),
-                   "risp_conv2d_small_split: %d groups need a scratch buffer, no PixelShuffle store and N * groups <= 65535", groups);
+    RISP_CHECK_ARG(groups <= 1 || (scratch && groups <= 16 && (size_t)dp->N * groups <= 65535),
+                   "risp_conv2d_small_split: %d groups need a scratch buffer and N * groups <= 65535", groups);
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_small: null tensor");
     RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 12,

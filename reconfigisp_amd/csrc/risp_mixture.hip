@@ -66,8 +66,10 @@ __global__ __launch_bounds__(64) void param_blocks_bwd_kernel(const risp_param_b
     const int k = blockIdx.x, w = d.width[k], j = threadIdx.x;
     if (j >= w) return;
     float s = 0.f;
-    if (d.gblock[k])
-        for (int n = 0; n < d.N; ++n) s += d.gblock[k][n * w + j];
+    if (d.gblock[k]) {
+        const int row = d.gstride[k] ? d.gstride[k] : w;
+        for (int n = 0; n < d.N; ++n) s += d.gblock[k][n * row + j];
+    }
     const float y = sigmoid_acc(d.raw[k][j]);
     d.graw[k][j] = s * ((1.f - y) * y);
 }
@@ -112,7 +114,9 @@ int risp_param_blocks_fwd(const risp_param_blocks_desc *d, void *stream) {
 
 int risp_param_blocks_bwd(const risp_param_blocks_desc *d, void *stream) {
     if (check_blocks(d, "risp_param_blocks_bwd")) return 1;
-    for (int k = 0; k < d->n_ops; ++k) RISP_CHECK_ARG(d->graw[k], "risp_param_blocks_bwd: gradient buffer %d missing", k);
+    for (int k = 0; k < d->n_ops; ++k)
+        RISP_CHECK_ARG(d->graw[k] && (d->gstride[k] == 0 || d->gstride[k] >= d->width[k]),
+                       "risp_param_blocks_bwd: op %d: gradient buffer missing or row stride %d < width", k, d->gstride[k]);
     hipLaunchKernelGGL(param_blocks_bwd_kernel, dim3(d->n_ops), dim3(64), 0, (hipStream_t)stream, *d);
     RISP_LAUNCH_CHECK("risp_param_blocks_bwd");
     return 0;

@@ -124,16 +124,18 @@ __global__ void gray_gains_bwd_kernel(const float *__restrict__ stats, const flo
     }
 }
 
-// gx[plane] += g_mean[plane]/HW everywhere; gx[plane][argmin] += g_min; gx[plane][argmax] += g_max
+// gx[plane] += g_mean[plane]/HW everywhere; gx[plane][argmin] += g_min; gx[plane][argmax] += g_max.  The gradient of
+// plane n * C + c sits at g_*[n * gstride + c] (packed vectors: C = gstride = 1).
 __global__ __launch_bounds__(256) void stats_bwd_kernel(float *__restrict__ gx, const float *__restrict__ g_min,
                                                         const float *__restrict__ g_mean,
                                                         const float *__restrict__ g_max,
-                                                        const int32_t *__restrict__ arg, int hw4, float inv_hw) {
-    const int plane = blockIdx.y;
+                                                        const int32_t *__restrict__ arg, int hw4, float inv_hw, int C,
+                                                        int gstride) {
+    const int plane = blockIdx.y, gi = (plane / C) * gstride + plane % C;
     float4 *gb = reinterpret_cast<float4 *>(gx) + (size_t)plane * hw4;
-    const float add = g_mean ? g_mean[plane] * inv_hw : 0.f;
+    const float add = g_mean ? g_mean[gi] * inv_hw : 0.f;
     const int imn = (g_min && arg) ? arg[plane * 2] : -1, imx = (g_max && arg) ? arg[plane * 2 + 1] : -1;
-    const float vmn = g_min ? g_min[plane] : 0.f, vmx = g_max ? g_max[plane] : 0.f;
+    const float vmn = g_min ? g_min[gi] : 0.f, vmx = g_max ? g_max[gi] : 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
         float4 v = gb[i];
         float *e = reinterpret_cast<float *>(&v);
@@ -326,16 +328,27 @@ int risp_histc(const float *x, float *hist, int NC, int HW, int bins, void *stre
     return 0;
 }
 
-int risp_stats_bwd(float *gx, const float *g_min, const float *g_mean, const float *g_max, const int32_t *arg, int NC,
-                   int HW, void *stream) {
-    RISP_CHECK_ARG(gx && NC > 0 && NC <= 65535 && HW > 0 && HW % 4 == 0, "risp_stats_bwd: bad arguments");
-    RISP_CHECK_ARG(arg || (!g_min && !g_max), "risp_stats_bwd: arg indices required for min/max gradients");
+static int stats_bwd_launch(const char *name, float *gx, const float *g_min, const float *g_mean, const float *g_max,
+                            const int32_t *arg, int NC, int HW, int C, int gstride, void *stream) {
+    RISP_CHECK_ARG(gx && NC > 0 && NC <= 65535 && HW > 0 && HW % 4 == 0, "%s: bad arguments", name);
+    RISP_CHECK_ARG(arg || (!g_min && !g_max), "%s: arg indices required for min/max gradients", name);
     int bx = (HW / 4 + 255) / 256;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(stats_bwd_kernel, dim3(bx, NC), dim3(256), 0, (hipStream_t)stream, gx, g_min, g_mean, g_max,
-                       arg, HW / 4, 1.0f / (float)HW);
-    RISP_LAUNCH_CHECK("risp_stats_bwd");
+                       arg, HW / 4, 1.0f / (float)HW, C, gstride);
+    RISP_LAUNCH_CHECK(name);
     return 0;
+}
+
+int risp_stats_bwd(float *gx, const float *g_min, const float *g_mean, const float *g_max, const int32_t *arg, int NC,
+                   int HW, void *stream) {
+    return stats_bwd_launch("risp_stats_bwd", gx, g_min, g_mean, g_max, arg, NC, HW, 1, 1, stream);
+}
+
+int risp_stats_bwd_rows(float *gx, const float *g_min, const float *g_mean, const float *g_max, const int32_t *arg, int N,
+                        int C, int HW, int row_stride, void *stream) {
+    RISP_CHECK_ARG(N > 0 && C > 0 && row_stride >= C, "risp_stats_bwd_rows: bad shape N=%d C=%d row_stride=%d", N, C, row_stride);
+    return stats_bwd_launch("risp_stats_bwd_rows", gx, g_min, g_mean, g_max, arg, N * C, HW, C, row_stride, stream);
 }
 
 int risp_grayworld_gains_fwd(const float *stats, float *gains, int N, int HW, void *stream) {

@@ -282,12 +282,15 @@ class _ParamBlocks(torch.autograd.Function):
         d.n_ops, d.N = len(raws), ctx.n
         keep, grads = [], []
         for k, (r, g) in enumerate(zip(raws, gblocks)):
-            g = _dev(g, 'grad') if g is not None else None
+            if g is not None and not (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1
+                                      and g.stride(0) >= g.shape[1]):
+                g = _dev(g, 'grad')               # (a column range of a wider matrix is read in place: SRCNNRes' folded backward)
             keep.append(g)
             gr = torch.empty_like(r)
             grads.append(gr)
             d.width[k], d.raw[k], d.graw[k] = r.numel(), r.data_ptr(), gr.data_ptr()
             d.gblock[k] = g.data_ptr() if g is not None else None
+            d.gstride[k] = g.stride(0) if g is not None else 0
         L.call('risp_param_blocks_bwd', C.byref(d), _stream())
         return (None,) + tuple(grads)
 

@@ -45,7 +45,8 @@ PARAM_OPS_MAX = 16
 class ParamBlocksDesc(C.Structure):
     """mirror of risp_param_blocks_desc"""
     _fields_ = [('n_ops', _i), ('N', _i), ('width', _i * PARAM_OPS_MAX), ('raw', _f * PARAM_OPS_MAX),
-                ('block', _f * PARAM_OPS_MAX), ('gblock', _f * PARAM_OPS_MAX), ('graw', _f * PARAM_OPS_MAX)]
+                ('block', _f * PARAM_OPS_MAX), ('gblock', _f * PARAM_OPS_MAX), ('graw', _f * PARAM_OPS_MAX),
+                ('gstride', _i * PARAM_OPS_MAX)]
 
 
 def _pw(n_extra=0):
@@ -67,6 +68,7 @@ SIGNATURES = {
     'risp_channel_stats_scratch_floats': (_z, [_i, _i]),
     'risp_channel_stats': (_i, [_f, _f, _f, _f, _i, _i, _s]),
     'risp_stats_bwd': (_i, [_f, _f, _f, _f, _f, _i, _i, _s]),
+    'risp_stats_bwd_rows': (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),
     'risp_histc': (_i, [_f, _f, _i, _i, _i, _s]),
     'risp_srcnn_cvals': (_i, [_f, _f, _f, _i, _i, _i, _s]),
     'risp_grayworld_gains_fwd': (_i, [_f, _f, _i, _i, _s]),

@@ -130,3 +130,20 @@ def test_repack_on_weight_update():
     assert (y0 - y1).abs().max() > 1e-4
     m.load_state_dict(O.make_weights('srcnn_demosaic', 1))
     assert_close(m.cuda()(x, None), y0)
+
+
+@pytest.mark.parametrize('kind,P,cin', [('srcnn_res', 2, 3), ('srcnn_demosaic', 0, 1), ('path14l_bayer', 0, 1), ('path14l_bgr', 0, 3)])
+def test_inference_result_independent_of_batch(kind, P, cin):
+    """test_split.py batches tiles (test_split.py:100-121): without autograd an image's output must be the same bits
+    whether it travels alone or in a batch - no grid-dependent kernel form (channel-group split of the direct kernel,
+    F(2,3) / F(4,3) switch) may be taken on the inference path."""
+    m = _build(kind, 5, P)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(6, cin, 64, 96, generator=g).cuda()
+    pv = torch.rand(6, P, generator=g).cuda() if P else None
+    with torch.no_grad():
+        full = m(x, pv)
+        for k in (0, 5):
+            alone = m(x[k:k + 1].contiguous(), pv[k:k + 1].contiguous() if P else None)
+            assert torch.equal(alone, full[k:k + 1]), '%s: image %d differs between batch 1 and batch 6 (max %g)' % (
+                kind, k, (alone - full[k:k + 1]).abs().max().item())

@@ -248,6 +248,31 @@ def test_small_cout_up_to_12(cout, hw):
         assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_SHUFFLE2), TF.pixel_shuffle(lin, 2), what='small shuffle2 groups')
 
 
+@pytest.mark.parametrize('cin,cout,k', [(64, 4, 9), (32, 12, 5), (64, 4, 3)])
+@pytest.mark.parametrize('groups', [2, 5, 8])
+def test_small_split_pixelshuffle_store(cin, cout, k, groups):
+    """Channel-group split of the direct kernel with the PixelShuffle store (first-layer backward and tail of
+    SRCNNDemosaic at small batches): against PyTorch and against the single-launch form."""
+    import ctypes as C
+    from reconfigisp_amd import convnets as CN, lib as L
+    n, h, w = 2, 20, 36
+    wt, b = rnd(cout, cin, k, k, seed=81) * 0.1, rnd(cout, seed=82) * 0.1
+    x = rnd(n, cin, h, w, seed=83)
+    ref = TF.pixel_shuffle(TF.conv2d(x, wt, b, padding=k // 2), 2)
+    sc = CN.SmallConv(wt, b)
+    outs = []
+    for g in (1, groups):
+        y = torch.zeros_like(ref)
+        scratch = torch.empty((g, n, cout, h, w), device=x.device)
+        d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=CN.LOAD_PLAIN, cin_img=0, epilogue=CN.EPI_SHUFFLE2,
+                       add_c=0, x=x.data_ptr(), wpack=sc.wpack.data_ptr(), bias=sc.bias.data_ptr(), cvals=None, add=None,
+                       mask=None, y=y.data_ptr())
+        L.call('risp_conv2d_small_split', C.byref(d), scratch.data_ptr(), g, None)
+        assert_close(y, ref, what='%d groups' % g)
+        outs.append(y)
+    assert_close(outs[1], outs[0], what='split vs single launch')      # summation order differs: fp32 noise only
+
+
 @pytest.mark.parametrize('cin,cout', [(64, 64), (4, 64), (64, 33), (3, 64), (64, 3)])
 @pytest.mark.parametrize('hw', SIZES + [(12, 128), (6, 260)])
 def test_inference_dispatch_f43(cin, cout, hw, monkeypatch):

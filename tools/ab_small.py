@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: in-process A/B of builds of risp_conv_small.hip (-D flags) and channel-group counts on the 9x9 64 -> 3
 backward-data layer of SRCNNRes at a small batch.  python tools/ab_small.py "" "-DRISP_SMALL_SPLIT_SPY2=512"
-[env RISP_AB_SHAPE="n h w", RISP_AB_GROUPS="1 2 4 8"]"""
+[env RISP_AB_SHAPE="n h w", RISP_AB_GROUPS="1 2 4 8", RISP_AB_LAYER="cin cout k shuffle(0|1)"]"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,18 +19,20 @@ for i, v in enumerate(variants):
 from reconfigisp_amd import lib as L
 from reconfigisp_amd import convnets as CN
 n, h, w = (int(v) for v in os.environ.get('RISP_AB_SHAPE', '4 256 256').split())
-cin, cout, k = 64, 3, 9
+cin, cout, k, shuf = (int(v) for v in os.environ.get('RISP_AB_LAYER', '64 3 9 0').split())
 torch.manual_seed(0)
 wt = torch.randn(cout, cin, k, k, device='cuda') * 0.02
 x = torch.rand(n, cin, h, w, device='cuda')
-y = torch.empty(n, cout, h, w, device='cuda')
+y = torch.empty((n, cout // 4, 2 * h, 2 * w) if shuf else (n, cout, h, w), device='cuda')
 pack, _ = CN.small_weights(wt)
 ref = torch.nn.functional.conv2d(x[:1], wt, None, padding=k // 2)
+if shuf:
+    ref = torch.nn.functional.pixel_shuffle(ref, 2)
 for name, l in libs.items():
     l.risp_conv2d_small_split.restype, l.risp_conv2d_small_split.argtypes = L.SIGNATURES['risp_conv2d_small_split']
 for groups in (int(g) for g in os.environ.get('RISP_AB_GROUPS', '1 2 4 8').split()):
     scratch = torch.empty((max(groups, 1), n, cout, h, w), device='cuda')
-    d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=0, cin_img=0, epilogue=CN.EPI_NOBIAS, add_c=0,
+    d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=0, cin_img=0, epilogue=CN.EPI_NOBIAS | (CN.EPI_SHUFFLE2 if shuf else 0), add_c=0,
                    x=x.data_ptr(), wpack=pack.data_ptr(), bias=None, cvals=None, add=None, mask=None, y=y.data_ptr())
     res = {k_: [] for k_ in libs}
     for rnd in range(5):
