@@ -20,6 +20,9 @@
 // four vector subtractions/additions.
 #include "risp_common.h"
 
+#ifndef RISP_W43G_ABL
+#define RISP_W43G_ABL 0     // tools/ab_wino43.py: timing-only ablations of the LDS-DMA F(4,3) kernel (wrong outputs)
+#endif
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -898,8 +901,12 @@ __global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_c
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch % STAGES;
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): every DMA this wave has issued (chunks <= ch + STAGES - 2) has landed
+#if RISP_W43G_ABL != 1
         __builtin_amdgcn_s_barrier();                  // ... for every wave; buffer (ch-1) % STAGES is free
+#endif
+#if RISP_W43G_ABL != 3
         if (ch + STAGES - 1 < nchunks) issue(ch + STAGES - 1, (ch + STAGES - 1) % STAGES);
+#endif
         const float *sx = smem + buf * STAGE, *sw = sx + XPAD;
         const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (half * WIH + wave) * W43WP) + l31;
         const float *aw = sw + half * CP + l31;
@@ -929,10 +936,17 @@ __global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_c
                                  __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
 #pragma unroll
             for (int t = 0; t < 6; ++t)
+#if RISP_W43G_ABL == 5
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], opd[slot][t >> 1][t & 1], acc[t], 0, 0, 0);
+#else
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#if RISP_W43G_ABL == 2
+    if (acc[0][0] == 123.456f)
+#endif
     w43_epilogue<WGS == 3 ? 1 : 4>(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);   // 3 workgroups per CU: 168 registers
 }
 
