@@ -98,6 +98,11 @@ int risp_histc(const float *x, float *hist, int NC, int HW, int bins, void *stre
 /* SRCNNRes broadcast-plane values (srcnn_res_arch.py:36-43): cvals (N,9+P) =
  * [min_b,min_g,min_r | mean | max | pv (N,P)] from the stats of the (N,3,H,W) input. */
 int risp_srcnn_cvals(const float *stats, const float *pv, float *cvals, int N, int P, int HW, void *stream);
+/* the same values applied to a weight-only table: table (N,M) = cvals (N,9+P) @ rcase (9+P,M), terms in index order -
+ * the per-(image, cout, border case) constants that replace the 9+P broadcast planes of SRCNNRes' 9x9 first layer
+ * (srcnn_res_arch.py:41-46; M = 64 * 81, consumed by risp_conv2d with RISP_EPI_CASEBIAS). */
+int risp_srcnn_case_table(const float *stats, const float *pv, const float *rcase, float *table, int N, int P, int HW,
+                          int M, void *stream);
 
 /* whitebalance 'grayworld' - tools_origin.py:33-41 ("output is clipped to [0, 1]", :22).
  * OPSPEC: gains[n,c] = gray_n / max(mean[n,c],1e-6), gray = mean over c of the channel means;

@@ -392,9 +392,9 @@ class _SrcnnResFolded(torch.autograd.Function):
         P = c1.cin - 12
         pv = _dev(pv, 'params') if P else None
         stats, arg = channel_stats(x)
-        cvals = torch.empty((n, 9 + P), device=x.device, dtype=torch.float32)
-        L.call('risp_srcnn_cvals', _p(stats), _p(pv), _p(cvals), n, P, h * w, _stream())
-        table = torch.mm(cvals, fold.rcase)                              # (N, 64*81) border-case constants
+        table = torch.empty((n, fold.rcase.shape[1]), device=x.device, dtype=torch.float32)
+        L.call('risp_srcnn_case_table', _p(stats), _p(pv), _p(fold.rcase), _p(table), n, P, h * w, fold.rcase.shape[1],
+               _stream())                                                # (N, 64*81) border-case constants = cvals @ rcase
         t1 = conv(x, fold.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table)
         t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
         y = conv_small(t2, fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, infer=infer)

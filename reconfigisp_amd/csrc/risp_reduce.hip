@@ -164,6 +164,26 @@ __global__ void srcnn_cvals_kernel(const float *__restrict__ stats, const float 
     cvals[i] = v;
 }
 
+// ---- the same values applied to SRCNNRes' folded first layer: table[n][j] = sum_c cval[n][c] * rcase[c][j]
+// (convnets.py::SrcnnResFold; j = cout x border case).  One thread per entry, the 9+P values rebuilt per thread from
+// the statistics (wave-uniform loads), terms added in index order.
+__global__ __launch_bounds__(256) void srcnn_case_table_kernel(const float *__restrict__ stats, const float *__restrict__ pv,
+                                                               const float *__restrict__ rcase, float *__restrict__ table,
+                                                               int P, int M, float inv_hw) {
+    const int n = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    float acc = 0.f;
+    for (int c = 0; c < 9 + P; ++c) {
+        float v;
+        if (c < 3) v = stats[(n * 3 + c) * 4 + 0];
+        else if (c < 6) v = stats[(n * 3 + c - 3) * 4 + 1] * inv_hw;
+        else if (c < 9) v = stats[(n * 3 + c - 6) * 4 + 2];
+        else v = pv[n * P + (c - 9)];
+        acc = __builtin_fmaf(v, rcase[(size_t)c * M + j], acc);
+    }
+    table[(size_t)n * M + j] = acc;
+}
+
 // ---- per-plane histogram, torch.histc(x, bins, 0, 1) semantics (tools_origin.py:120-128):
 // values outside [0,1] (and NaN) are ignored, x == 1 lands in the last bin, raw counts.
 __global__ __launch_bounds__(256) void histc_kernel(const float *__restrict__ x, float *__restrict__ hist, int hw,
@@ -311,6 +331,16 @@ int risp_srcnn_cvals(const float *stats, const float *pv, float *cvals, int N, i
     hipLaunchKernelGGL(srcnn_cvals_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, pv, cvals,
                        N, P, 1.0f / (float)HW);
     RISP_LAUNCH_CHECK("risp_srcnn_cvals");
+    return 0;
+}
+
+int risp_srcnn_case_table(const float *stats, const float *pv, const float *rcase, float *table, int N, int P, int HW, int M,
+                          void *stream) {
+    RISP_CHECK_ARG(stats && rcase && table && N > 0 && N <= 65535 && P >= 0 && (P == 0 || pv) && HW > 0 && M > 0,
+                   "risp_srcnn_case_table: bad arguments");
+    hipLaunchKernelGGL(srcnn_case_table_kernel, dim3((M + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, stats, pv, rcase,
+                       table, P, M, 1.0f / (float)HW);
+    RISP_LAUNCH_CHECK("risp_srcnn_case_table");
     return 0;
 }
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     'risp_stats_bwd_rows': (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),
     'risp_histc': (_i, [_f, _f, _i, _i, _i, _s]),
     'risp_srcnn_cvals': (_i, [_f, _f, _f, _i, _i, _i, _s]),
+    'risp_srcnn_case_table': (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _s]),
     'risp_grayworld_gains_fwd': (_i, [_f, _f, _i, _i, _s]),
     'risp_grayworld_gains_bwd': (_i, [_f, _f, _f, _i, _i, _s]),
     'risp_chain_fwd': (_i, [_f, _i, C.POINTER(_i), _pp, _pp, _i, _i, _i, _s]),

@@ -192,6 +192,22 @@ def test_rect_sums_are_the_constant_channel_gradient(k, hw):
     assert_close(got, cv.grad, what='const-channel grad', rtol=2e-4, floor=1.0)
 
 
+@pytest.mark.parametrize('P', [0, 2, 5])
+def test_srcnn_case_table(P):
+    """risp_srcnn_case_table = (min | mean | max | params) @ rcase, against torch on the statistics torch computes."""
+    from reconfigisp_amd import lib as L
+    from reconfigisp_amd.functional import _p, _stream, channel_stats
+    n, h, w, m = 3, 12, 20, 64 * 81
+    x = torch.rand(n, 3, h, w, device='cuda')
+    pv = torch.rand(n, P, device='cuda') if P else None
+    rcase = rnd(9 + P, m, seed=35)
+    stats, _ = channel_stats(x)
+    table = torch.empty((n, m), device='cuda')
+    L.call('risp_srcnn_case_table', _p(stats), _p(pv), _p(rcase), _p(table), n, P, h * w, m, _stream())
+    cv = torch.cat([x.amin(dim=(2, 3)), x.mean(dim=(2, 3)), x.amax(dim=(2, 3))] + ([pv] if P else []), dim=1)
+    assert_close(table, cv.double() @ rcase.double(), what='case table', rtol=1e-5, floor=1.0)
+
+
 @pytest.mark.parametrize('P', [1, 3, 5])
 @pytest.mark.parametrize("hw", [(8, 8), (8, 12), (20, 36), (40, 72), (34, 30)])
 def test_srcnn_res_folded_equals_unfolded(P, hw):
