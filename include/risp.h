@@ -238,6 +238,9 @@ int risp_conv2d_wino5(const risp_conv_desc *d, void *stream);
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */
 int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksize, void *stream);
+/* ... and that product: gconst (N,C) = rs (N,M) @ wconst (M,C) (SRCNNRes: M = 64 * 81 rectangle sums per
+ * image, C = 9+P constant planes, srcnn_res_arch.py:41-46).  Deterministic. */
+int risp_srcnn_const_grad(const float *rs, const float *wconst, float *gconst, int N, int M, int C, void *stream);
 
 /* Backward-weight of the same layer: dw (cout,cin,k,k) = sum_{n,y,x} gy[n,co,y,x] * load(x)[n,ci,y+ky-p,x+kx-p]
  * (fully written).  Uses d->x, load_mode (PLAIN / CONSTCH), cin_img, cvals, N, H, W, cin, cout, ksize; gy is

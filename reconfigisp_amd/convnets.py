@@ -414,7 +414,8 @@ class _SrcnnResFolded(torch.autograd.Function):
         gx = conv_small(g1, fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3)     # image channels + residual path
         rs = torch.empty((n, c1.cout * fold.k * fold.k), device=gy.device, dtype=torch.float32)
         L.call('risp_rect_sums', _p(g1), _p(rs), n * c1.cout, h, w, fold.k, _stream())
-        gconst = torch.mm(rs, fold.wconst)                              # (N, 9+P): min, mean, max planes, then params
+        gconst = torch.empty((n, 9 + P), device=gy.device, dtype=torch.float32)     # min, mean, max planes, then params
+        L.call('risp_srcnn_const_grad', _p(rs), _p(fold.wconst), _p(gconst), n, rs.shape[1], 9 + P, _stream())
         row = gconst.shape[1]                                           # columns 0-2 / 3-5 / 6-8 of each row, read in place
         gb = gconst.data_ptr()
         L.call('risp_stats_bwd_rows', _p(gx), C.c_void_p(gb), C.c_void_p(gb + 12), C.c_void_p(gb + 24), _p(arg), n, 3, h * w,

@@ -296,6 +296,28 @@ __global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict_
     if (tid < K * K) out[(size_t)blockIdx.x * K * K + tid] = sums[tid / K][tid % K];
 }
 
+// gconst[n][c] = sum_j rs[n][j] * wconst[j][c]: the rectangle sums applied to the constant-plane weights (the backward
+// of the folded constants, C = 9 + P columns).  One workgroup per (image, column); every thread owns a fixed residue
+// class of j, the partial sums meet by wave shuffles and one LDS pass in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void const_grad_kernel(const float *__restrict__ rs, const float *__restrict__ wconst,
+                                                         float *__restrict__ gconst, int M, int C) {
+    const int c = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float a0 = 0.f, a1 = 0.f;
+    int j = tid;
+    for (; j + 256 < M; j += 512) {                      // two independent chains: the loads of both are in flight together
+        a0 = __builtin_fmaf(rs[(size_t)n * M + j], wconst[(size_t)j * C + c], a0);
+        a1 = __builtin_fmaf(rs[(size_t)n * M + j + 256], wconst[(size_t)(j + 256) * C + c], a1);
+    }
+    if (j < M) a0 = __builtin_fmaf(rs[(size_t)n * M + j], wconst[(size_t)j * C + c], a0);
+    float v = a0 + a1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __shared__ float part[4];
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    if (tid == 0) gconst[(size_t)n * C + c] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // y = epilogue(sum over channel groups of the partial sums), the groups added in index order
 __global__ __launch_bounds__(256) void small_reduce_kernel(const risp_conv_desc d, int groups, const float *__restrict__ partial) {
     const size_t plane = (size_t)d.H * d.W, total = (size_t)d.N * d.cout * plane;
@@ -418,6 +440,14 @@ int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksi
     const size_t lds = sizeof(float) * (size_t)phases * W;
     hipLaunchKernelGGL(rect_sums_kernel, dim3(planes), dim3(256), lds, (hipStream_t)stream, g, out, H, W, ksize);
     RISP_LAUNCH_CHECK("risp_rect_sums");
+    return 0;
+}
+
+int risp_srcnn_const_grad(const float *rs, const float *wconst, float *gconst, int N, int M, int C, void *stream) {
+    RISP_CHECK_ARG(rs && wconst && gconst && N > 0 && N <= 65535 && M > 0 && C >= 1, "risp_srcnn_const_grad: bad arguments (N=%d M=%d C=%d)",
+                   N, M, C);
+    hipLaunchKernelGGL(const_grad_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, rs, wconst, gconst, M, C);
+    RISP_LAUNCH_CHECK("risp_srcnn_const_grad");
     return 0;
 }
 

@@ -88,6 +88,7 @@ SIGNATURES = {
     'risp_conv_small_groups': (_i, [C.POINTER(ConvDesc)]),
     'risp_conv2d_small_split': (_i, [C.POINTER(ConvDesc), _f, _i, _s]),
     'risp_rect_sums': (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    'risp_srcnn_const_grad': (_i, [_f, _f, _f, _i, _i, _i, _s]),
     'risp_conv_wino3_chunk': (_i, []),
     'risp_conv_wino3_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino3': (_i, [C.POINTER(ConvDesc), _s]),

@@ -185,7 +185,10 @@ def test_rect_sums_are_the_constant_channel_gradient(k, hw):
     wt = rnd(cout, nconst, k, k, seed=32)
     rs = torch.empty((n, cout * k * k), device='cuda')
     L.call('risp_rect_sums', _p(g), _p(rs), n * cout, h, w, k, _stream())
-    got = rs @ wt.permute(0, 2, 3, 1).reshape(-1, nconst)
+    wconst = wt.permute(0, 2, 3, 1).reshape(-1, nconst).contiguous()
+    got = torch.empty((n, nconst), device='cuda')
+    L.call('risp_srcnn_const_grad', _p(rs), _p(wconst), _p(got), n, rs.shape[1], nconst, _stream())
+    assert_close(got, rs.double() @ wconst.double(), what='const grad product', rtol=1e-5, floor=1.0)
     cv = rnd(n, nconst, seed=33).requires_grad_(True)
     planes = cv[:, :, None, None].expand(n, nconst, h, w)
     (TF.conv2d(planes, wt, None, padding=k // 2) * g).sum().backward()
