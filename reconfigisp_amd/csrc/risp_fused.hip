@@ -43,7 +43,10 @@ __device__ __forceinline__ int refl(int i, int n) {
 }
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st4_nt(float *p, v4f v) {
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#ifndef RISP_STREAM_POLICY
+#define RISP_STREAM_POLICY "nt"            // tools/ab_fused.py: "sc1", "sc0 sc1", "sc1 nt" measured against it
+#endif
+    asm volatile("global_store_dwordx4 %0, %1, off " RISP_STREAM_POLICY ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ float q8f(float v) {
     return floorf(__builtin_amdgcn_fmed3f(v, 0.f, 255.f) + 0.5f);   // clamp in one instruction (v is never NaN here)
@@ -183,9 +186,9 @@ __global__ __launch_bounds__(256, RISP_FUSED_WAVES) void bilateral_chain_kernel(
             eg[i] = ctr[per + i];
             er[i] = ctr[2 * per + i];
         }
-        __builtin_nontemporal_store(*reinterpret_cast<v4f *>(&vb), reinterpret_cast<v4f *>(a.out_dem + o));
-        __builtin_nontemporal_store(*reinterpret_cast<v4f *>(&vg), reinterpret_cast<v4f *>(a.out_dem + o + plane));
-        __builtin_nontemporal_store(*reinterpret_cast<v4f *>(&vr), reinterpret_cast<v4f *>(a.out_dem + o + 2 * plane));
+        st4_nt(a.out_dem + o, *reinterpret_cast<v4f *>(&vb));
+        st4_nt(a.out_dem + o + plane, *reinterpret_cast<v4f *>(&vg));
+        st4_nt(a.out_dem + o + 2 * plane, *reinterpret_cast<v4f *>(&vr));
     }
 
     // ---- bilateral on 4 pixels
