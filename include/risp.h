@@ -366,7 +366,9 @@ int risp_origin_fastnlm(const float *x, float *y, const int32_t *block_size, con
 /* globaltonemapping 'reinhard' (mode 0: a=white_point, b=middle_grey), 'crysisengine' (1: a=lum_adapted),
  * 'filmic' (2: a=white_point, b=exposure_bias) - :526-543, :566-581, :604-623; whitebalance
  * 'whiteworld' (3: a=white_point_ratio, stats from risp_channel_stats) - :647-662.
- * a, b: (N) device arrays; scratch: 5*N floats. */
+ * a, b: (N) device arrays; scratch: risp_origin_tonemap_scratch_floats(N) floats (per-image constants and the
+ * partial sums of Reinhard's log-average luminance, added in a fixed order: deterministic). */
+size_t risp_origin_tonemap_scratch_floats(int N);
 int risp_origin_tonemap(const float *x, float *y, int mode, const float *a, const float *b, const float *stats,
                         float *scratch, int N, int HW, float in_scale, float out_div, void *stream);
 

@@ -67,19 +67,24 @@ __global__ __launch_bounds__(256) void bgr_bwd_kernel(const float *__restrict__ 
     }
 }
 
-// gp[row][j] = sum of the partial rows that map to `row` (Ctx::prow: the image itself, or row 0 for the whole batch),
-// images and workgroups in index order: bit-repeatable parameter gradients
+// gp[row][j] = sum of the partial rows that map to `row` (Ctx::prow: the image itself, or row 0 for the whole batch).
+// One wave per output element: lane l adds the partial rows l, l + 64, ... of the element in index order, a fixed
+// shuffle tree adds the lanes - bit-repeatable, and no thread walks the whole list alone (the one-thread-per-element
+// form took 63-75 us on 64 x 16 rows; this one a few).
 template <class Ctx>
-__global__ void param_finish_kernel(const float *__restrict__ part, float *__restrict__ gp, int N, int bx, int rows) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void param_finish_kernel(const float *__restrict__ part, float *__restrict__ gp, int N, int bx,
+                                                           int rows) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= rows * Ctx::NP) return;
     const int row = t / Ctx::NP, j = t - row * Ctx::NP;
+    const bool own = Ctx::prow(1) == 1;                 // per-image rows: only the image's own bx partial rows count
+    const int lo = own ? row * bx : 0, hi = own ? (row + 1) * bx : N * bx;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) {
-        if (Ctx::prow(n) != row) continue;
-        for (int b = 0; b < bx; ++b) s += part[((size_t)n * bx + b) * Ctx::NP + j];
-    }
-    gp[t] = s;
+    for (int i = lo + lane; i < hi; i += 64)
+        if (own || Ctx::prow(i / bx) == row) s += part[(size_t)i * Ctx::NP + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) gp[t] = s;
 }
 
 template <class Ctx>
@@ -103,7 +108,7 @@ int launch_bwd(const char *name, const float *x, const float *p, const float *gy
     if (bx > 32) bx = 32;
     hipLaunchKernelGGL(bgr_bwd_kernel<Ctx>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, p, gy, gx, scratch, hw4);
     const int rows = N;                                // gp is (N, NP): rows no image maps to (GtmManual: all but row 0) get 0
-    hipLaunchKernelGGL(param_finish_kernel<Ctx>, dim3((rows * Ctx::NP + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch,
+    hipLaunchKernelGGL(param_finish_kernel<Ctx>, dim3((rows * Ctx::NP + 3) / 4), dim3(256), 0, (hipStream_t)stream, scratch,
                        gp, N, bx, rows);
     RISP_LAUNCH_CHECK(name);
     return 0;

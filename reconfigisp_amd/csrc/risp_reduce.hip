@@ -186,24 +186,38 @@ __global__ __launch_bounds__(256) void srcnn_case_table_kernel(const float *__re
 
 // ---- per-plane histogram, torch.histc(x, bins, 0, 1) semantics (tools_origin.py:120-128):
 // values outside [0,1] (and NaN) are ignored, x == 1 lands in the last bin, raw counts.
+// `copies` private histograms per workgroup (lane l counts into copy l % copies, stored bin-major so that lanes hitting the
+// same bin land on different LDS banks): neighbouring pixels fall into the same bin, and on one shared histogram their
+// LDS atomics serialise.  Counts are integers: the float atomics that merge the workgroups are exact in any order.
 __global__ __launch_bounds__(256) void histc_kernel(const float *__restrict__ x, float *__restrict__ hist, int hw,
-                                                    int bins) {
+                                                    int bins, int copies) {
     extern __shared__ unsigned int sh[];
-    const int plane = blockIdx.y;
-    for (int b = threadIdx.x; b < bins; b += blockDim.x) sh[b] = 0u;
+    const int plane = blockIdx.y, cp = threadIdx.x % copies;
+    for (int b = threadIdx.x; b < bins * copies; b += blockDim.x) sh[b] = 0u;
     __syncthreads();
     const float *xb = x + (size_t)plane * hw;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
-        const float v = xb[i];
+    auto count = [&](float v) {
         if (v >= 0.f && v <= 1.f) {
             int pos = (int)(v * (float)bins);
             if (pos >= bins) pos = bins - 1;
-            atomicAdd(&sh[pos], 1u);
+            atomicAdd(&sh[pos * copies + cp], 1u);
         }
+    };
+    if ((hw & 3) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(xb);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw / 4; i += gridDim.x * blockDim.x) {
+            const float4 v = x4[i];
+            count(v.x); count(v.y); count(v.z); count(v.w);
+        }
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) count(xb[i]);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < bins; b += blockDim.x)
-        if (sh[b]) atomicAdd(&hist[(size_t)plane * bins + b], (float)sh[b]);
+    for (int b = threadIdx.x; b < bins; b += blockDim.x) {
+        unsigned int t = 0u;
+        for (int k = 0; k < copies; ++k) t += sh[b * copies + k];
+        if (t) atomicAdd(&hist[(size_t)plane * bins + b], (float)t);
+    }
 }
 
 // ---- mixed-op combiner
@@ -254,12 +268,15 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const MixArgs a, const flo
     }
 }
 
+// one wave per operand: lane l adds the partial rows l, l + 64, ... in index order, a fixed shuffle tree adds the lanes
 __global__ void mix_finish_kernel(const float *__restrict__ part, float *__restrict__ gw, int K, int blocks) {
-    const int k = threadIdx.x;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= K) return;
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * RISP_MAX_MIX + k];
-    gw[k] = s;
+    for (int b = lane; b < blocks; b += 64) s += part[(size_t)b * RISP_MAX_MIX + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) gw[k] = s;
 }
 
 // ---- sum over H,W of selected channel planes
@@ -352,8 +369,10 @@ int risp_histc(const float *x, float *hist, int NC, int HW, int bins, void *stre
     }
     int bx = (HW + 256 * 16 - 1) / (256 * 16);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(histc_kernel, dim3(bx, NC), dim3(256), bins * sizeof(unsigned int), (hipStream_t)stream, x, hist,
-                       HW, bins);
+    int copies = 16;                                   // private histograms per workgroup, within 16 KB of LDS
+    while (copies > 1 && bins * copies > 4096) copies >>= 1;
+    hipLaunchKernelGGL(histc_kernel, dim3(bx, NC), dim3(256), bins * copies * sizeof(unsigned int), (hipStream_t)stream, x, hist,
+                       HW, bins, copies);
     RISP_LAUNCH_CHECK("risp_histc");
     return 0;
 }
@@ -435,7 +454,7 @@ int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *g
     size_t b = (numel / 4 + 1023) / 1024;
     int grid = (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
     hipLaunchKernelGGL(mix_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, gy, scratch, numel / 4);
-    hipLaunchKernelGGL(mix_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, gw, K, grid);
+    hipLaunchKernelGGL(mix_finish_kernel, dim3(1), dim3(64 * RISP_MAX_MIX), 0, (hipStream_t)stream, scratch, gw, K, grid);
     RISP_LAUNCH_CHECK("risp_mix_bwd");
     return 0;
 }

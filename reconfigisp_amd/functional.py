@@ -612,7 +612,7 @@ def _hip_origin_tonemap(x, option, params, scales=(1.0, 1.0)):
     a = _vec(params[ka], n, x.device)
     b = _vec(params[kb], n, x.device) if kb else None
     y = torch.empty_like(x)
-    ws = torch.empty(5 * n, device=x.device, dtype=torch.float32)
+    ws = torch.empty(L.load().risp_origin_tonemap_scratch_floats(n), device=x.device, dtype=torch.float32)
     L.call('risp_origin_tonemap', _p(x), _p(y), mode, _p(a), _p(b), None, _p(ws), n, hw, scales[0], scales[1],
            _stream())
     return y
@@ -624,7 +624,7 @@ def _hip_origin_whiteworld(x, ratio, scales=(1.0, 1.0)):
     n, hw = x.shape[0], x.shape[2] * x.shape[3]
     stats, _ = channel_stats(x, want_arg=False)
     y = torch.empty_like(x)
-    ws = torch.empty(5 * n, device=x.device, dtype=torch.float32)
+    ws = torch.empty(L.load().risp_origin_tonemap_scratch_floats(n), device=x.device, dtype=torch.float32)
     r = _vec(ratio, n, x.device)          # keep every operand alive until the launch is enqueued
     L.call('risp_origin_tonemap', _p(x), _p(y), 3, _p(r), None, _p(stats), _p(ws), n, hw, scales[0], scales[1],
            _stream())

@@ -110,6 +110,7 @@ SIGNATURES = {
     'risp_origin_bilateral': (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _fl, _s]),
     'risp_origin_median': (_i, [_f, _f, _i, _i, _i, _i, _fl, _fl, _s]),
     'risp_origin_fastnlm': (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _s]),
+    'risp_origin_tonemap_scratch_floats': (C.c_size_t, [_i]),
     'risp_origin_tonemap': (_i, [_f, _f, _i, _f, _f, _f, _f, _i, _i, _fl, _fl, _s]),
     'risp_bilateral_chain_fwd': (_i, [_f, _i, _f, _f, _f, _f, _f, _i, _i, C.POINTER(_i), _pp, _pp, _i, _i, _i, _s]),
     'risp_raw_crop': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _fl, _s]),

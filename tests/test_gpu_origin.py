@@ -50,11 +50,13 @@ def test_origin_tonemaps_and_whiteworld(hw):
     codes_close(F.origin_whiteworld(x.cuda(), ratio), O.origin_whiteworld(x, ratio), 'whiteworld')
 
 
-@pytest.mark.parametrize('hw', [(16, 16), (40, 70)])
+@pytest.mark.parametrize('hw', [(16, 16), (40, 70), (24, 132), (70, 64)])
 def test_origin_denoisers(hw):
+    """W % 4 == 0 shapes take the 64 x 16 / 4-pixels-per-thread kernels (132: a last tile with 4 valid columns, whose
+    windows reflect inside the tile), the others the general one-pixel-per-thread kernels."""
     import reconfigisp_amd.functional as F
     x = rnd(2, 3, *hw, seed=3) * 255
-    for size in (3, 9):
+    for size in (3, 5, 7, 9, 11):
         codes_close(F.origin_denoise(x.cuda(), 'median', {'size': size}), O.origin_denoise(x, 'median', {'size': size}),
                     'median %d' % size, exact=True)
     bp = {'window_length': torch.tensor([3, 5]), 'sigma_color': torch.tensor([50.5, 12.0]),
