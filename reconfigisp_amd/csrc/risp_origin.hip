@@ -372,20 +372,23 @@ __global__ __launch_bounds__(256) void fastnlm_kernel(const float *__restrict__ 
     y[o + 2 * plane] = emit(nr * rden, so);
 }
 
-// K x K median (K = 5, 7, 9; 9 is the reference's default, tools_origin.py:746 with p = 0.5) of 8-bit codes, 4 pixels per
-// thread, on BYTES.  The tile is staged as packed codes (four pixels per LDS dword); a thread pulls the 12 bytes per
-// window row that its four windows share (three dwords), cuts each pixel's row out with v_alignbyte and keeps the
-// window in registers.  Rank counting uses the sum of absolute differences: with S(m) = sum |x_i - m| over a set of n
+// K x K median (K = 5 .. 17; 9 is the reference's default, tools_origin.py:746 with p = 0.5) of 8-bit codes, 4 pixels per
+// thread, on BYTES.  The tile is staged as packed codes (four pixels per LDS dword); a thread pulls the 12 (K <= 9) or
+// 20 bytes per window row that its four windows share, cuts a pixel's row out with v_alignbyte and keeps that pixel's
+// window in registers (K*K/4 dwords) through its bisection.  Rank counting uses the sum of absolute differences: with S(m) = sum |x_i - m| over a set of n
 // codes, S(m+1) - S(m) = #(x <= m) - #(x > m), so #(x <= m) = (S(m+1) - S(m) + n) / 2 - and v_sad_u8 adds four
-// |x - m| per instruction.  A bisection round costs 2 SADs per 4 codes (plus a compare per leftover code of a row)
+// |x - m| per instruction.  A bisection round costs 2 SADs per 4 codes (plus a compare for the last K*K % 4 codes)
 // instead of a compare and an add per code and an LDS read per code: the same exact median (smallest code whose rank
 // reaches the middle), about 4-5 x faster than the general kernel on 9 x 9.
 template <int K>
 __global__ __launch_bounds__(256) void median4_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W,
                                                       float si, float so) {
-    constexpr int R = K / 2, RP = 4, TWB = QX + 2 * RP, TWD = TWB / 4, TH = QY + 2 * R;   // tile row: 72 bytes = 18 dwords
+    constexpr int R = K / 2, RP = R <= 4 ? 4 : 8, TWB = QX + 2 * RP, TWD = TWB / 4, TH = QY + 2 * R;   // tile row: 72 / 80 bytes
+    constexpr int NDW = (2 * RP + 4) / 4;              // dwords of a tile row that cover the thread's four windows
     constexpr int ND = K / 4, NE = K % 4;              // full dwords and leftover codes per window row
-    static_assert(R <= RP && K <= 9, "window rows must fit the 12 bytes a thread loads");
+    constexpr int NL = K * NE, NLD = NL / 4, NLS = NL % 4;   // the leftovers of all rows, packed four to a dword again
+    constexpr int NW = K * ND + NLD;
+    static_assert(R <= RP && K <= 17, "window rows must fit the bytes a thread loads");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned *tile = reinterpret_cast<unsigned *>(lds);                  // [3][TH][TWD] packed codes
     const int n = blockIdx.z, x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
@@ -408,32 +411,38 @@ __global__ __launch_bounds__(256) void median4_kernel(const float *__restrict__ 
     const size_t plane = (size_t)H * W, o = (size_t)n * 3 * plane + (size_t)py * W + px;
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
-        unsigned wd[4][K][ND > 0 ? ND : 1];            // packed window rows of the 4 pixels
-        int we[4][K][NE > 0 ? NE : 1];                 // leftover codes
+        float res[4];
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            const unsigned *row = tile + (c * TH + ly + r) * TWD + lxd;     // bytes: image columns px-4 .. px+7
-            const unsigned d[3] = {row[0], row[1], row[2]};
+        for (int i = 0; i < 4; ++i) {
+            unsigned wd[NW > 0 ? NW : 1];                      // the window as packed dwords: row pieces, then leftovers
+            int ws[NLS > 0 ? NLS : 1], left[NL > 0 ? NL : 1];  // codes that fill no dword
+            const int off = RP - R + i;                        // first byte of pixel i's window row
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int off = RP - R + i;            // first byte of pixel i's window row
+            for (int r = 0; r < K; ++r) {
+                const unsigned *row = tile + (c * TH + ly + r) * TWD + lxd;     // bytes: image columns px-RP .. px+RP+3
+                unsigned d[NDW];
+#pragma unroll
+                for (int j = 0; j < NDW; ++j) d[j] = row[j];
 #pragma unroll
                 for (int j = 0; j < ND; ++j) {
                     const int b = off + 4 * j;
-                    wd[i][r][j] = (b & 3) ? __builtin_amdgcn_alignbyte(d[(b >> 2) + 1 < 3 ? (b >> 2) + 1 : 2], d[b >> 2], b & 3) : d[b >> 2];
+                    wd[r * ND + j] = (b & 3) ? __builtin_amdgcn_alignbyte(d[(b >> 2) + 1 < NDW ? (b >> 2) + 1 : NDW - 1], d[b >> 2], b & 3)
+                                             : d[b >> 2];
                 }
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
                     const int b = off + 4 * ND + e;
-                    we[i][r][e] = (int)((d[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                    left[r * NE + e] = (int)((d[b >> 2] >> (8 * (b & 3))) & 0xffu);
                 }
             }
-        }
-        float res[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int g = 0; g < NLD; ++g)
+                wd[K * ND + g] = (unsigned)left[4 * g] | ((unsigned)left[4 * g + 1] << 8) | ((unsigned)left[4 * g + 2] << 16) |
+                                 ((unsigned)left[4 * g + 3] << 24);
+#pragma unroll
+            for (int e = 0; e < NLS; ++e) ws[e] = left[4 * NLD + e];
             int lo = 0, hi = 255;                      // smallest code v with #(x <= v) >= need
-            constexpr int need = (K * K) / 2 + 1, n8 = 4 * ND * K;
+            constexpr int need = (K * K) / 2 + 1, n8 = 4 * NW;
 #pragma unroll 1
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;        // <= 254
@@ -441,15 +450,12 @@ __global__ __launch_bounds__(256) void median4_kernel(const float *__restrict__ 
                 unsigned sm = 0, sp = 0;
                 int cnt = 0;
 #pragma unroll
-                for (int r = 0; r < K; ++r) {
-#pragma unroll
-                    for (int j = 0; j < ND; ++j) {
-                        sm = __builtin_amdgcn_sad_u8(wd[i][r][j], m4, sm);
-                        sp = __builtin_amdgcn_sad_u8(wd[i][r][j], m4p, sp);
-                    }
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) cnt += we[i][r][e] <= mid ? 1 : 0;
+                for (int j = 0; j < NW; ++j) {
+                    sm = __builtin_amdgcn_sad_u8(wd[j], m4, sm);
+                    sp = __builtin_amdgcn_sad_u8(wd[j], m4p, sp);
                 }
+#pragma unroll
+                for (int e = 0; e < NLS; ++e) cnt += ws[e] <= mid ? 1 : 0;
                 cnt += ((int)sp - (int)sm + n8) >> 1;
                 if (cnt >= need) hi = mid; else lo = mid + 1;
             }
@@ -710,19 +716,22 @@ int risp_origin_median(const float *x, float *y, int size, int N, int H, int W, 
                        void *stream) {
     RISP_CHECK_ARG(x && y && N > 0 && N <= 65535 && size >= 1 && size <= 17 && (size & 1) && H > size / 2 && W > size / 2,
                    "risp_origin_median: bad arguments (size %d, H=%d W=%d)", size, H, W);
-    auto med_lds = [](int k) { return sizeof(unsigned) * 3 * (QY + 2 * (k / 2)) * ((QX + 8) / 4); };
+    auto med_lds = [](int k) { return sizeof(unsigned) * 3 * (QY + 2 * (k / 2)) * ((QX + (k <= 9 ? 8 : 16)) / 4); };
+    const bool t4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+#define RISP_MEDIAN4(KK)                                                                                                      \
+    hipLaunchKernelGGL(median4_kernel<KK>, tile4_grid(N, H, W), dim3(256), med_lds(KK), (hipStream_t)stream, x, y, H, W, in_scale, \
+                       out_div)
     if (size == 3 && tile4_ok(y, W, 1))
         hipLaunchKernelGGL(median3x4_kernel, tile4_grid(N, H, W), dim3(256), tile4_lds(3, 1), (hipStream_t)stream, x, y, H, W,
                            in_scale, out_div);
-    else if (size == 5 && tile4_ok(y, W, 2))
-        hipLaunchKernelGGL(median4_kernel<5>, tile4_grid(N, H, W), dim3(256), med_lds(5), (hipStream_t)stream, x, y, H, W, in_scale,
-                           out_div);
-    else if (size == 7 && tile4_ok(y, W, 3))
-        hipLaunchKernelGGL(median4_kernel<7>, tile4_grid(N, H, W), dim3(256), med_lds(7), (hipStream_t)stream, x, y, H, W, in_scale,
-                           out_div);
-    else if (size == 9 && tile4_ok(y, W, 4))
-        hipLaunchKernelGGL(median4_kernel<9>, tile4_grid(N, H, W), dim3(256), med_lds(9), (hipStream_t)stream, x, y, H, W, in_scale,
-                           out_div);
+    else if (size == 5 && t4) RISP_MEDIAN4(5);
+    else if (size == 7 && t4) RISP_MEDIAN4(7);
+    else if (size == 9 && t4) RISP_MEDIAN4(9);
+    else if (size == 11 && t4) RISP_MEDIAN4(11);
+    else if (size == 13 && t4) RISP_MEDIAN4(13);
+    else if (size == 15 && t4) RISP_MEDIAN4(15);
+    else if (size == 17 && t4) RISP_MEDIAN4(17);
+#undef RISP_MEDIAN4
     else
         hipLaunchKernelGGL(median_kernel, tile_grid(N, H, W), dim3(256), tile_lds(3, size / 2), (hipStream_t)stream, x, y, H, W,
                            size / 2, in_scale, out_div);

@@ -13,6 +13,10 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle runs beside every GPU test; on a many-core host torch's default of one thread per core makes its
+    # small tensor ops (unfold / sort / conv on 16 x 16 .. 70 x 64 images) crawl
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 def load_golden(name):
