@@ -239,12 +239,27 @@ __global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict_
         const int cg = tid % groups, ph = tid / groups;
         if (ph < phases) {
             for (int q = cg; q < wq; q += groups) {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int y = ph; y < H; y += phases) {
-                    const float4 v = *reinterpret_cast<const float4 *>(gp + (size_t)y * W + 4 * q);
-                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                // four independent accumulator chains: four 16-byte loads of the column are in flight together (one
+                // chain made this pass latency-bound: 233 us for 64 planes of 256 x 256 per image at batch 32)
+                float4 a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                int y = ph;
+                for (; y + 3 * phases < H; y += 4 * phases) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 v = *reinterpret_cast<const float4 *>(gp + (size_t)(y + u * phases) * W + 4 * q);
+                        a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+                    }
                 }
-                *reinterpret_cast<float4 *>(col + (size_t)ph * W + 4 * q) = a;
+                for (; y < H; y += phases) {
+                    const float4 v = *reinterpret_cast<const float4 *>(gp + (size_t)y * W + 4 * q);
+                    a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+                }
+                float4 t;
+                t.x = (a[0].x + a[1].x) + (a[2].x + a[3].x); t.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+                t.z = (a[0].z + a[1].z) + (a[2].z + a[3].z); t.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+                *reinterpret_cast<float4 *>(col + (size_t)ph * W + 4 * q) = t;
             }
         }
         __syncthreads();
