@@ -17,6 +17,7 @@ constexpr float kLn2 = 0.6931471805599453f;
 struct WbManualCtx {   // p = the per-image gain (N,3), i.e. what tools_origin.py:214 computes as params * 5
     static constexpr int NP = 3;
     float k[3];
+    __device__ WbManualCtx() {}                      // members filled by the caller (a context kept across a pixel loop)
     __device__ WbManualCtx(const float *p, int n) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) k[c] = p[n * 3 + c];
@@ -35,6 +36,7 @@ struct WbManualCtx {   // p = the per-image gain (N,3), i.e. what tools_origin.p
 struct GammaCtx {
     static constexpr int NP = 1;
     float g, toe;  // toe = T^(g-1): slope of the linear segment below T
+    __device__ GammaCtx() {}
     __device__ GammaCtx(const float *p, int n) {
         g = p[n];
         toe = __builtin_amdgcn_exp2f((g - 1.f) * kLog2Toe);
@@ -63,6 +65,7 @@ struct GammaCtx {
 struct GtmCtx {  // 4 segments; knots from row 0 of p only (tools_origin.py:423)
     static constexpr int NP = 3;
     float ys[4], sl[4];
+    __device__ GtmCtx() {}
     __device__ GtmCtx(const float *p, int) {
         float k[5] = {0.f, p[0], p[1], p[2], 1.f};
 #pragma unroll
@@ -114,6 +117,7 @@ struct GtmCtx {  // 4 segments; knots from row 0 of p only (tools_origin.py:423)
 struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR B G R 1
     static constexpr int NP = 30;
     float c[3][10];
+    __device__ WbqCtx() {}
     __device__ WbqCtx(const float *p, int n) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)

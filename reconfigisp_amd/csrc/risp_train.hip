@@ -33,13 +33,62 @@ __device__ __forceinline__ int op_np(int op) {
 
 template <bool WBQ>
 __global__ __launch_bounds__(256) void chain_train_kernel(const risp_train_desc a, const float inv_count) {
-    __shared__ float red[ROW * 4];
+    // accumulators of THIS instantiation: without a WbQuadratic stage the 30 quadratic slots are not carried (and not
+    // reduced); the loss sits last either way, and the scratch row keeps the common ROW layout
+    constexpr int NR = WBQ ? ROW : MT * 3 + 1;
+    __shared__ float red[NR * 4];
     const int n = blockIdx.y, H = a.H, W = a.W, wq = W / 2, nq = wq * (H / 2);
     const size_t plane = (size_t)H * W;
-    float acc[ROW];
+    float acc[NR];
 #pragma unroll
-    for (int j = 0; j < ROW; ++j) acc[j] = 0.f;
+    for (int j = 0; j < NR; ++j) acc[j] = 0.f;
     const float gscale = a.loss_kind == 0 ? 2.f * inv_count : inv_count;
+
+    // The per-image op contexts (gains, gamma and its toe slope, tone-curve knots and slopes, the 30 quadratic
+    // coefficients) are wave-uniform: the small ones are built ONCE before the pixel loop and pinned in scalar registers
+    // (v_readfirstlane).  Built inside the loop - as the one-shot inference kernels do - they cost two constructions
+    // per stage and iteration (30 loads + 30 fmas, four divisions, an exp2) and their share of the vector registers.
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    float sctx[MT][8];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sctx[k][j] = 0.f;
+        if (!WBQ && k < a.n_ops) {
+            const int op = a.ops[k];
+            if (op == RISP_OP_WB_MANUAL) {
+                const WbManualCtx c(a.blocks[k], n);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) sctx[k][j] = uni(c.k[j]);
+            } else if (op == RISP_OP_GAMMA) {
+                const GammaCtx c(a.blocks[k], n);
+                sctx[k][0] = uni(c.g); sctx[k][1] = uni(c.toe);
+            } else if (op == RISP_OP_GTM_MANUAL) {
+                const GtmCtx c(a.blocks[k], n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sctx[k][j] = uni(c.ys[j]); sctx[k][4 + j] = uni(c.sl[j]); }
+            }
+        }
+    }
+    // The instantiation with a WbQuadratic stage (30 coefficients, 30 more gradient accumulators) sits at its register
+    // budget: with pinned contexts it falls to one wave per SIMD (0.144 -> 0.20 ms per step), so it keeps the
+    // per-use constructions; pipelines without WbQuadratic gain a third (0.148 -> 0.098 ms).
+    auto wbm = [&](int k) {
+        if (WBQ) return WbManualCtx(a.blocks[k], n);
+        WbManualCtx c; c.k[0] = sctx[k][0]; c.k[1] = sctx[k][1]; c.k[2] = sctx[k][2]; return c;
+    };
+    auto gam = [&](int k) {
+        if (WBQ) return GammaCtx(a.blocks[k], n);
+        GammaCtx c; c.g = sctx[k][0]; c.toe = sctx[k][1]; return c;
+    };
+    auto gtm = [&](int k) {
+        if (WBQ) return GtmCtx(a.blocks[k], n);
+        GtmCtx c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c.ys[j] = sctx[k][j]; c.sl[j] = sctx[k][4 + j]; }
+        return c;
+    };
+    auto wbq = [&](int k) { return WbqCtx(a.blocks[k], n); };
 
     // a thread owns ONE ROW of a 2x2 quad (2 pixels): t -> (quad row qy, quad column qx, row r of the quad)
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < 2 * nq; t += gridDim.x * blockDim.x) {
@@ -65,7 +114,20 @@ __global__ __launch_bounds__(256) void chain_train_kernel(const risp_train_desc 
             if (k < a.n_ops) {
                 xs[k][0] = px[0];
                 xs[k][1] = px[1];
-                apply_op<2, WBQ>(a.ops[k], a.blocks[k], n, px);
+                const int op = a.ops[k];
+                if (op == RISP_OP_WB_MANUAL) {
+                    const WbManualCtx c = wbm(k);
+                    px[0] = c.fwd(px[0]); px[1] = c.fwd(px[1]);
+                } else if (op == RISP_OP_GAMMA) {
+                    const GammaCtx c = gam(k);
+                    px[0] = c.fwd(px[0]); px[1] = c.fwd(px[1]);
+                } else if (op == RISP_OP_GTM_MANUAL) {
+                    const GtmCtx c = gtm(k);
+                    px[0] = c.fwd(px[0]); px[1] = c.fwd(px[1]);
+                } else if (WBQ && op == RISP_OP_WB_QUADRATIC) {
+                    const WbqCtx c = wbq(k);
+                    px[0] = c.fwd(px[0]); px[1] = c.fwd(px[1]);
+                }
             }
         }
         float2 gt[3];
@@ -84,10 +146,10 @@ __global__ __launch_bounds__(256) void chain_train_kernel(const risp_train_desc 
             const float tb = i ? gt[0].y : gt[0].x, tg = i ? gt[1].y : gt[1].x, tr = i ? gt[2].y : gt[2].x;
             const float db = px[i].b - tb, dg = px[i].g - tg, dr = px[i].r - tr;
             if (a.loss_kind == 0) {
-                acc[ROW - 1] += (db * db + dg * dg) + dr * dr;
+                acc[NR - 1] += (db * db + dg * dg) + dr * dr;
                 g[i] = {db * gscale, dg * gscale, dr * gscale};
             } else {                                          // nn.L1Loss: sign(d) / count, sign(0) = 0
-                acc[ROW - 1] += (fabsf(db) + fabsf(dg)) + fabsf(dr);
+                acc[NR - 1] += (fabsf(db) + fabsf(dg)) + fabsf(dr);
                 auto sg = [gscale](float d) { return d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f); };
                 g[i] = {sg(db), sg(dg), sg(dr)};
             }
@@ -97,32 +159,32 @@ __global__ __launch_bounds__(256) void chain_train_kernel(const risp_train_desc 
         for (int k = MT - 1; k >= 0; --k) {
             if (k < a.n_ops) {
                 const int op = a.ops[k];
-                const float *p = a.blocks[k];
                 if (op == RISP_OP_WB_MANUAL) {
-                    const WbManualCtx c(p, n);
+                    const WbManualCtx c = wbm(k);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) g[i] = c.bwd(xs[k][i], g[i], acc + 3 * k);
                 } else if (op == RISP_OP_GAMMA) {
-                    const GammaCtx c(p, n);
+                    const GammaCtx c = gam(k);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) g[i] = c.bwd(xs[k][i], g[i], acc + 3 * k);
                 } else if (op == RISP_OP_GTM_MANUAL) {
-                    const GtmCtx c(p, n);
+                    const GtmCtx c = gtm(k);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) g[i] = c.bwd(xs[k][i], g[i], acc + 3 * k);
                 } else if (WBQ && op == RISP_OP_WB_QUADRATIC) {
-                    const WbqCtx c(p, n);
+                    const WbqCtx c = wbq(k);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) g[i] = c.bwd(xs[k][i], g[i], acc + 3 * MT);
                 }
             }
         }
     }
-    block_sum<ROW>(acc, red);
+    block_sum<NR>(acc, red);
     if (threadIdx.x == 0) {
         float *row = a.scratch + ((size_t)n * gridDim.x + blockIdx.x) * ROW;
 #pragma unroll
-        for (int j = 0; j < ROW; ++j) row[j] = acc[j];
+        for (int j = 0; j < NR - 1; ++j) row[j] = acc[j];
+        row[ROW - 1] = acc[NR - 1];
     }
 }
 
@@ -199,7 +261,9 @@ int risp_chain_train_step(const risp_train_desc *dp, void *stream) {
     RISP_CHECK_ARG(n_wbq <= 1, "risp_chain_train_step: at most one WbQuadratic stage");
     const float inv_count = 1.0f / ((float)a.N * 3.f * (float)a.H * (float)a.W);
     const int nq = (a.W / 2) * (a.H / 2);
-    int bx = (2 * nq + 256 * 16 - 1) / (256 * 16);      // >= 16 pixel pairs per thread so the 49-value reduction amortises
+    // 16 pixel pairs per thread - the measured optimum of both instantiations (64 x 256 x 256: 8 pairs +12 %, 12 +16 %,
+    // 32 +27 % step time)
+    int bx = (2 * nq + 256 * 16 - 1) / (256 * 16);
     if (bx < 1) bx = 1;
     if (bx > BX_MAX) bx = BX_MAX;
     hipStream_t s = (hipStream_t)stream;
