@@ -106,11 +106,14 @@ def srcnn_fold_tables(w1):
     """(rcase (9+P, cout*k*k), wconst (cout*k*k, 9+P)) of SRCNNRes' first layer w1 (cout, 12+P, k, k): see SrcnnResFold."""
     k, p = w1.shape[2], w1.shape[2] // 2
     wc = w1[:, 3:]
-    cases = []
-    for i in range(k):                                               # taps lo..hi of border case i survive
-        cases.append((p - i, k - 1) if i < p else (0, k - 1 - (i - p)))
-    rc = torch.stack([torch.stack([wc[:, :, a:b + 1, c:d + 1].sum(dim=(2, 3)) for (c, d) in cases], dim=-1)
-                      for (a, b) in cases], dim=-2)                  # (cout, 9+P, k, k)
+    # border case i keeps the taps lo..hi of a filter row / column; all k x k case sums at once as two contractions with
+    # the 0/1 case-membership matrix (float64, rounded once: 81 slice sums per layer were 81 launches each, and the packs
+    # of every slot are rebuilt after each proxy fine-tuning round)
+    member = torch.zeros((k, k), dtype=torch.float64, device=w1.device)
+    for i in range(k):
+        lo, hi = (p - i, k - 1) if i < p else (0, k - 1 - (i - p))
+        member[i, lo:hi + 1] = 1.0
+    rc = torch.einsum('ocyx,iy,jx->ocij', wc.double(), member, member).to(w1.dtype)     # (cout, 9+P, k, k)
     rcase = rc.permute(1, 0, 2, 3).reshape(wc.shape[1], -1).contiguous()
     wconst = wc.permute(0, 2, 3, 1).reshape(-1, wc.shape[1]).contiguous()
     return rcase, wconst
