@@ -97,6 +97,7 @@ def timed(fn, steps, warmup, device, world):
         fn()
         marks.append(time.perf_counter())
     ev1.record()
+    t_issued = time.perf_counter()
     # host time to ISSUE a step (diagnostic): mean, median and worst single step
     gaps = sorted(b - a for a, b in zip([t0] + marks[:-1], marks))
     timed.host_us = (marks[-1] - t0) / steps * 1e6
@@ -108,6 +109,9 @@ def timed(fn, steps, warmup, device, world):
     wall = time.perf_counter() - t0
     gc.enable()
     dev_ms = ev0.elapsed_time(ev1)
+    if os.environ.get('RISP_BENCH_TIMELINE') == '1':      # diagnostic: where a short window's fixed cost goes
+        sys.stderr.write('window: first step issued after %.1f us, all %d after %.1f us, wall %.1f us, device ev0->ev1 %.1f us\n'
+                         % ((marks[0] - t0) * 1e6, steps, (t_issued - t0) * 1e6, wall * 1e6, dev_ms * 1e3))
     if world > 1:
         t = torch.tensor([wall], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
