@@ -241,3 +241,48 @@ def test_bilateral_on_odd_height_takes_the_standalone_kernel():
                                   [None, None], origin=True)
         d = (y.cpu() - ref).abs()
         assert d.max().item() <= 1.01 * 5 * 0.2 / 255 + 1e-6 and (d > 1e-5).float().mean().item() < 5e-3
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (40, 132), (22, 64)])
+@pytest.mark.parametrize('form', ['codes', 'raw'])
+def test_tile_forms_give_identical_bits(hw, form):
+    """Every classical stencil has a general kernel (32 x 8 tiles, one pixel per thread) and, for W % 4 == 0 and a
+    16-byte aligned output, a 64 x 16 form with 4 pixels per thread (packed bytes + v_sad_u8 for the median).  Same
+    input, the output pointer moved by one float to force the general kernel: the results must be the same bits -
+    quantised codes and the float in front of the quantisation alike."""
+    import ctypes as C
+    from reconfigisp_amd import lib as L
+    h, w = hw
+    n = 2
+    dev = torch.device('cuda')
+    x = (rnd(n, 3, h, w, seed=91) * 255).to(dev)
+    bay = (rnd(n, 1, h, w, seed=92) * 255).to(dev)
+    so = 1.0 if form == 'codes' else -1.0
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def both(call, shape):
+        outs = []
+        for shift in (0, 1):
+            buf = torch.zeros(int(np.prod(shape)) + 4, device=dev)
+            y = buf[shift:shift + int(np.prod(shape))].view(shape)
+            assert (y.data_ptr() % 16 == 0) == (shift == 0)
+            call(y)
+            outs.append(y.clone())
+        assert torch.equal(outs[0], outs[1]), 'max difference %g' % (outs[0] - outs[1]).abs().max().item()
+
+    win = torch.tensor([3, 5], dtype=torch.int32, device=dev)
+    sc, ss = torch.tensor([50.5, 12.0], device=dev), torch.tensor([50.5, 1.5], device=dev)
+    both(lambda y: L.call('risp_origin_bilateral', p(x), p(y), p(win), p(sc), p(ss), 5, n, h, w, 1.0, so, None), x.shape)
+    win3 = torch.tensor([3, 3], dtype=torch.int32, device=dev)
+    both(lambda y: L.call('risp_origin_bilateral', p(x), p(y), p(win3), p(sc), p(ss), 3, n, h, w, 1.0, so, None), x.shape)
+    blk, srch = torch.tensor([3, 3], dtype=torch.int32, device=dev), torch.tensor([3, 3], dtype=torch.int32, device=dev)
+    dec = torch.tensor([50.5, 8.0], device=dev)
+    both(lambda y: L.call('risp_origin_fastnlm', p(x), p(y), p(blk), p(srch), p(dec), 3, 3, n, h, w, 1.0, so, None), x.shape)
+    srch5 = torch.tensor([3, 5], dtype=torch.int32, device=dev)
+    both(lambda y: L.call('risp_origin_fastnlm', p(x), p(y), p(blk), p(srch5), p(dec), 3, 5, n, h, w, 1.0, so, None), x.shape)
+    for lap in (0, 1):
+        both(lambda y: L.call('risp_origin_demosaic', p(bay), p(y), lap, n, h, w, 1.0, so, None), (n, 3, h, w))
+    if form == 'codes':
+        for size in (3, 5, 7, 9, 13, 17):
+            if size // 2 < min(h, w):
+                both(lambda y: L.call('risp_origin_median', p(x), p(y), size, n, h, w, 1.0, 1.0, None), x.shape)
