@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""GPU box: per-op forward / input-gradient difference between the F(2,3) and F(4,3) 3x3 kernels at 16x16."""
+"""Diagnostic script (not collected by pytest; it lives under tests/ because it uses the test helpers and,
+through them, the oracle).  GPU box: per-op forward / input-gradient difference between the F(2,3) and F(4,3) 3x3 kernels at 16x16."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import conftest  # noqa: F401  (puts oracle/ on the path)
 import torch

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""GPU box: alpha / parameter gradient errors of the super-net golden under the three 3x3 kernels (ReLU-kink check)."""
+"""Diagnostic script (not collected by pytest; it lives under tests/ because it uses the test helpers and,
+through them, the oracle).  GPU box: alpha / parameter gradient errors of the super-net golden under the three 3x3 kernels (ReLU-kink check)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from conftest import load_golden
