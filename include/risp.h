@@ -186,7 +186,16 @@ typedef struct {
     int epilogue, add_c;
     const float *x, *wpack, *bias, *cvals, *add, *mask;
     float *y;
+    /* Grouped launch (group_n = 0: off).  The same-geometry operators of a super-net slot - the 8 SRCNNRes proxies of an
+     * sRGB slot, the 2 proxy demosaics (super_prune_fifteen_demos_four_bayer_two.py:35-52, looped at :183-212) - run each
+     * layer as ONE launch: the N images are N / group_n consecutive groups of group_n images, group g convolves with
+     * wpack + g * wpack_gs and bias + g * bias_gs (floats); y, mask, cvals (and x, add unless shared) are the groups'
+     * tensors stacked along N.  RISP_GROUP_SHARED_X / _ADD: x / add hold ONE group's group_n images, read by every
+     * group (the slot input).  Per image the arithmetic is that of the ungrouped launch: results are bit-identical. */
+    int group_n, group_flags;
+    long long wpack_gs, bias_gs;
 } risp_conv_desc;
+enum { RISP_GROUP_SHARED_X = 1, RISP_GROUP_SHARED_ADD = 2 };
 size_t risp_conv_wpack_floats(int cin, int cout, int ksize);
 /* w: device (cout,cin,k,k) torch layout.  transpose=1: w is the FORWARD layer's (cin,cout,k,k)
  * tensor and the pack holds the backward-data convolution (roles swapped, taps rotated 180). */
@@ -241,6 +250,31 @@ int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksi
 /* ... and that product: gconst (N,C) = rs (N,M) @ wconst (M,C) (SRCNNRes: M = 64 * 81 rectangle sums per
  * image, C = 9+P constant planes, srcnn_res_arch.py:41-46).  Deterministic. */
 int risp_srcnn_const_grad(const float *rs, const float *wconst, float *gconst, int N, int M, int C, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * The same-geometry proxies of a super-net slot as ONE launch per layer (the 8 SRCNNRes of an sRGB slot,
+ * super_prune_fifteen_demos_four_bayer_two.py:35-52 / :183-212; srcnn_res_arch.py:15-53).  The convolutions use
+ * risp_conv_desc.group_n; these are the non-convolution links of the chain for all members at once.  Member g has P[g]
+ * parameter channels; tensors of the group are the members' tensors stacked along N (member-major: row g * N + n).
+ * Per member every value is computed exactly as by the single-operator entry point named beside it.
+ * ------------------------------------------------------------------------- */
+#define RISP_MAX_GROUP 16
+typedef struct risp_srcnn_group_desc {
+    int G, N, HW, M;                              /* members, images per member, H*W, table width (cout * k * k) */
+    int P[RISP_MAX_GROUP];
+    const float *pv[RISP_MAX_GROUP];              /* (N, P[g]) parameter blocks (forward) */
+    const float *rcase[RISP_MAX_GROUP];           /* (9 + P[g], M) folded first-layer tables (forward) */
+    const float *wconst[RISP_MAX_GROUP];          /* (M, 9 + P[g]) constant-plane weights (backward) */
+} risp_srcnn_group_desc;
+/* table (G*N, M): risp_srcnn_case_table per member; stats (N,3,4) of the shared input */
+int risp_srcnn_case_table_group(const float *stats, const risp_srcnn_group_desc *d, float *table, void *stream);
+/* gconst (G*N, row), row >= max(9 + P): risp_srcnn_const_grad per member into columns [0, 9 + P[g]), zeros beyond */
+int risp_srcnn_const_grad_group(const float *rs, const risp_srcnn_group_desc *d, float *gconst, int row, void *stream);
+/* out (N,C,H,W) = sum over the members, in member order, of stack (G,N,C,H,W).  gstats != NULL: member g's term first
+ * receives risp_stats_bwd_rows with g_min / g_mean / g_max = columns [0,C) / [C,2C) / [2C,3C) of gstats (G*N, row) and
+ * the argmin / argmax indices `arg` (N,C,2) of the shared input. */
+int risp_group_sum(const float *stack, float *out, int G, int N, int C, int HW, const float *gstats, int row,
+                   const int32_t *arg, void *stream);
 
 /* Backward-weight of the same layer: dw (cout,cin,k,k) = sum_{n,y,x} gy[n,co,y,x] * load(x)[n,ci,y+ky-p,x+kx-p]
  * (fully written).  Uses d->x, load_mode (PLAIN / CONSTCH), cin_img, cvals, N, H, W, cin, cout, ksize; gy is

@@ -17,6 +17,7 @@ from .... import functional as F
 from ....isp_kernels import demosaic as _dm
 from . import registry as R
 from . import tools_origin as T
+from . import tools_proxy as TP
 
 
 # HIP streams the ops of a slot are spread over when the batch is small (1 = off), and what "small" means
@@ -97,19 +98,47 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             cache[key] = torch.tensor(mask, dtype=torch.uint8, device=device)
         return cache[key]
 
-    def _run_ops(self, ops, args, x):
-        """outs[i] = ops[i](x, args[i]).  The surviving ops of a slot are independent given the slot input, so they are
-        issued round-robin on two HIP streams: launches of different ops overlap and fill each other's gaps - a
-        convolution launch runs its workgroups in lockstep rounds and leaves the matrix pipes idle through each
-        prologue / store drain, worst on a small batch (the per-GPU batch of the 8-GPU search is 4 images: one or two
-        rounds per launch).  The backward pass inherits the streams (autograd runs a node on the stream of its
-        forward).  Same kernels, same arguments, same summation order in the mixture: results are bit-identical to
-        the single-stream order.  Measured (tools/bench_darts.py, n_step 2): batch 4 0.113 -> 0.097 s per iteration,
-        batch 32 0.62 -> 0.60 s; 3 and 4 streams are no faster."""
+    def _jobs(self, slot, mods, index, args, x):
+        """The surviving ops of a slot as launch jobs [(positions in `index`, callable -> list of outputs)].  Same-geometry
+        proxies - the SRCNNRes family of an sRGB slot (:35-52), the two proxy demosaics - form ONE job that runs every layer
+        as a single grouped launch (convnets.srcnn_res_group); everything else is a job of its own.  Heavy jobs come first
+        so that the round-robin over the streams puts the group and Path-Restore on different ones."""
+        families = ((TP.ProxyNet, 'res'), (TP.ProxyDemosaicNet, 'demosaic'))
+        jobs, taken = [], set()
+        cache = self.__dict__.setdefault('_group_cache', {}).setdefault(slot, {})
+        for cls, kind in families:
+            pos = [i for i, k in enumerate(index) if isinstance(mods[k], cls)]
+            members = [mods[index[i]] for i in pos]
+            if len(pos) >= 2 and F.can_group(members, x):
+                if kind == 'res':
+                    fn = (lambda members=members, pos=pos: F.srcnn_res_group(x, [args[i] for i in pos], members, cache))
+                else:
+                    fn = (lambda members=members: F.srcnn_demosaic_group(x, members, cache))
+                jobs.append((pos, fn))
+                taken.update(pos)
+        heavy = [i for i in range(len(index)) if i not in taken and isinstance(mods[index[i]], (TP.PathRestore14lBgr,
+                                                                                                  TP.PathRestore14lBayer))]
+        rest = [i for i in range(len(index)) if i not in taken and i not in heavy]
+        single = [([i], (lambda i=i: [mods[index[i]](x, args[i])])) for i in heavy + rest]
+        # group, Path-Restore, then the light ops: with two streams the two heavy jobs land on different streams
+        return jobs[:1] + single[:len(heavy)] + jobs[1:] + single[len(heavy):]
+
+    def _run_jobs(self, jobs, n_out, x, args):
+        """outs[i] for every surviving op.  The jobs of a slot are independent given the slot input, so they are issued
+        round-robin on two HIP streams: launches of different jobs overlap and fill each other's gaps - a convolution
+        launch runs its workgroups in lockstep rounds and leaves the matrix pipes idle through each prologue / store
+        drain.  The backward pass inherits the streams (autograd runs a node on the stream of its forward).  Same
+        kernels, same arguments, same summation order in the mixture: results are bit-identical to the single-stream
+        order.  Measured in round 2 (tools/bench_darts.py, n_step 2, op-by-op jobs): batch 4 0.113 -> 0.097 s per
+        iteration, batch 32 0.62 -> 0.60 s; 3 and 4 streams are no faster."""
         pixels = x.shape[0] * x.shape[2] * x.shape[3]
-        n_streams = SLOT_STREAMS if (x.is_cuda and len(ops) > 2 and pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
+        n_streams = SLOT_STREAMS if (x.is_cuda and len(jobs) > 2 and pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
+        outs = [None] * n_out
         if n_streams <= 1:
-            return [op(x, a) for op, a in zip(ops, args)]
+            for pos, fn in jobs:
+                for i, o in zip(pos, fn()):
+                    outs[i] = o
+            return outs
         main = torch.cuda.current_stream()
         pool = self.__dict__.setdefault('_side_streams', {})
         key = (x.device.index, n_streams)
@@ -119,16 +148,18 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         for s in streams[1:]:
             s.wait_stream(main)                           # the slot input (and the parameter blocks) are ready
             x.record_stream(s)
-        outs = []
-        for i, (op, a) in enumerate(zip(ops, args)):
-            s = streams[i % n_streams]
-            if a is not None and s is not main:
-                a.record_stream(s)
+        for j, (pos, fn) in enumerate(jobs):
+            s = streams[j % n_streams]
+            if s is not main:
+                for i in pos:
+                    if args[i] is not None:
+                        args[i].record_stream(s)
             with torch.cuda.stream(s):
-                o = op(x, a)
-            if s is not main and o is not x:
-                o.record_stream(main)                     # consumed by the mixture kernel on the main stream
-            outs.append(o)
+                res = fn()
+            for i, o in zip(pos, res):
+                if s is not main and o is not x:
+                    o.record_stream(main)                 # consumed by the mixture kernel on the main stream
+                outs[i] = o
         for s in streams[1:]:
             main.wait_stream(s)
         return outs
@@ -160,9 +191,10 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                     live_pars.append(par)
             blocks = iter(F.param_blocks(live_pars, n))  # sigmoid(par).repeat(n, 1) of every surviving op: one launch
             args = [next(blocks) if pars[k].nelement() > 0 else None for k in index]
-            outs = self._run_ops([mods[k] for k in index], args, x)
+            jobs = self._jobs(slot, mods, index, args, x)
+            outs = self._run_jobs(jobs, len(index), x, args)
             sel = post if len(index) == len(weights) else post[index]
-            y = F.mix(sel, outs, w_host=[weights[k] for k in index])
+            y = F.mix(sel, outs, w_host=[weights[k] for k in index], stacks=[pos for pos, _ in jobs if len(pos) > 1])
             if pruned_pars:
                 y = F.attach_zero_grad(y, pruned_pars)
             self.middle_results.append(y)

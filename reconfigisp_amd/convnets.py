@@ -153,18 +153,37 @@ class SmallConv:
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 
-def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False):
+def _group_fields(d, n, group, wpack, bias):
+    """Fill the grouped-launch fields of a ConvDesc: ``group`` = (G, flags) with the members' packs stacked along
+    dimension 0 of ``wpack`` / ``bias``; the launch then covers G * n images (include/risp.h: group_n)."""
+    if group is None:
+        return n
+    g, flags = group
+    if wpack.shape[0] != g or (bias is not None and bias.shape[0] != g):
+        raise ValueError('grouped launch: %d members but the stacked packs hold %d' % (g, wpack.shape[0]))
+    d.group_n, d.group_flags = n, flags
+    d.wpack_gs = wpack.stride(0)
+    d.bias_gs = bias.stride(0) if bias is not None else 0
+    d.N = g * n
+    return g * n
+
+
+def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False, out=None, group=None, split=None):
     """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 12).  ``infer``: never split the input
     channels over workgroups - the split depends on the grid, and an inference result must not depend on the batch a
-    tile travels in (test_split.py batches tiles)."""
+    tile travels in (test_split.py batches tiles).  ``group``: see ``_group_fields``; ``split``: force the channel split
+    (the per-member form of a grouped launch uses the split the grouped grid would take)."""
     if sc.bias is None:
         epi |= EPI_NOBIAS
-    shape = (n, sc.cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, sc.cout, h, w)
-    out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    nn_ = n * (group[0] if group else 1)
+    if out is None:
+        shape = (nn_, sc.cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (nn_, sc.cout, h, w)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
-    groups = 1 if infer else L.load().risp_conv_small_groups(C.byref(d))
+    _group_fields(d, n, group, sc.wpack, sc.bias)
+    groups = 1 if infer else (split if split is not None else L.load().risp_conv_small_groups(C.byref(d)))
     if groups > 1:                                  # small grid: split the input channels over several workgroups per tile
         scratch = torch.empty((groups,) + tuple(out.shape), device=x.device, dtype=torch.float32)
         L.call('risp_conv2d_small_split', C.byref(d), _p(scratch), groups, _stream())
@@ -187,14 +206,18 @@ def _issued_flops(entry, cin, cout, k, pixels):
 
 
 def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None, epi=0, add=None, add_c=0,
-         mask=None, out=None, infer=False):
+         mask=None, out=None, infer=False, group=None):
     """One fused convolution launch at resolution (h,w); returns the output tensor.  ``infer``: no backward pass
-    will read this layer's activations (selects the F(4,3) form of a 3x3 layer)."""
+    will read this layer's activations (selects the F(4,3) form of a 3x3 layer).  ``group`` = (G, flags): ``pc`` holds the
+    packs of G same-geometry layers stacked along dimension 0 and the launch covers G * n images (``_group_fields``)."""
     cin, cout = (pc.cout, pc.cin) if transpose else (pc.cin, pc.cout)
     if transpose:
         epi |= EPI_NOBIAS
+    if group is not None and pc.k == 3:
+        raise ValueError('grouped launches are not available for 3x3 layers (the Winograd F(4,3) / F(2,3) kernels)')
+    nn_ = n * (group[0] if group else 1)
     if out is None:
-        shape = (n, cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (n, cout, h, w)
+        shape = (nn_, cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (nn_, cout, h, w)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
     wino, entry = (pc.wino_bwd if transpose else pc.wino_fwd), pc.wino_entry
     # F(4,3) has about twice the rounding error of F(2,3) (still ~2e-7 of max|y|).  Round 1 kept training FORWARD passes on
@@ -218,12 +241,14 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
                 (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
                  (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
+    wpack = wino if use_wino else (pc.bwd if transpose else pc.fwd)
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
-                   epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wino if use_wino else (pc.bwd if transpose else pc.fwd)),
+                   epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wpack),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
+    _group_fields(d, n, group, wpack, None if transpose else pc.bias)
     L.call(entry if use_wino else 'risp_conv2d', C.byref(d), _stream())
     if MFMA_ISSUED is not None:
-        MFMA_ISSUED[0] += _issued_flops(entry if use_wino else 'risp_conv2d', cin, cout, pc.k, n * h * w)
+        MFMA_ISSUED[0] += _issued_flops(entry if use_wino else 'risp_conv2d', cin, cout, pc.k, nn_ * h * w)
     return out
 
 
@@ -531,3 +556,252 @@ def build_srcnn_packs(seq, residual=False):
     if not residual and seq[4].weight.shape[0] <= 12 and seq[4].weight.shape[2] in (3, 5):
         packs[2].small = SmallConv(seq[4].weight, seq[4].bias)
     return packs
+
+
+# --------------------------------------------------------------------------- grouped launches: one launch per LAYER
+# The same-geometry proxies of a super-net slot - the 8 SRCNNRes of an sRGB slot, the 2 SRCNNDemosaic of the demosaic slot
+# (super_prune_fifteen_demos_four_bayer_two.py:35-52, looped at :183-212) - run every layer as ONE launch: the members'
+# images are stacked along N, the member index sits in the grid and selects the weights (include/risp.h: group_n).  At the
+# 4-image per-GPU batch of the 8-GPU search a single member's launch is one or two rounds of workgroups; eight of them
+# fill the chip.  GROUP_LAUNCH=0 keeps the data flow (stacked buffers, one summed input gradient) but issues the members'
+# launches one by one - same kernels, same per-image arithmetic, bit-identical results (tests/test_gpu_group.py).
+GROUP_LAUNCH = os.environ.get('RISP_GROUP_LAUNCH', '1') != '0'
+LAUNCHES = None           # tests / tools set this to [0] to count C-ABI launches of the grouped paths
+
+
+class _Stacked:
+    """Packs of G same-shape layers stacked along dimension 0 (what ``conv`` / ``conv_small`` take with ``group=``)."""
+
+    def __init__(self, members, tensors, scalars):
+        for a in scalars:
+            vals = {getattr(m, a) for m in members}
+            if len(vals) != 1:
+                raise ValueError('grouped layer: members disagree on %s: %s' % (a, sorted(vals)))
+            setattr(self, a, vals.pop())
+        for a in tensors:
+            ts = [getattr(m, a, None) for m in members]
+            setattr(self, a, torch.stack(ts) if all(t is not None for t in ts) else None)
+        self.wino43_fwd = self.wino43_bwd = None
+        self.members = list(members)
+
+
+def stack_packed(pcs):
+    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd'), ('cin', 'cout', 'k', 'wino_entry'))
+
+
+def stack_small(scs):
+    return _Stacked(scs, ('wpack', 'bias'), ('cin', 'cout', 'k'))
+
+
+def _stack_grads(gys, like):
+    """The members' upstream gradients as ONE (G*N, ...) tensor: in place when they already are consecutive slices of
+    one buffer (functional._Mix.backward allocates them that way), else copied; None entries count as zeros."""
+    g0 = gys[0]
+    if all(g is not None and g.is_contiguous() and g.dtype == torch.float32 for g in gys):
+        step = g0.numel() * 4
+        if all(g.data_ptr() == g0.data_ptr() + k * step for k, g in enumerate(gys)):
+            try:
+                return g0.as_strided((len(gys) * g0.shape[0],) + tuple(g0.shape[1:]), g0.stride())
+            except RuntimeError:
+                pass                                    # adjacent by coincidence, not one storage
+    return torch.cat([_dev(g, 'grad') if g is not None else torch.zeros_like(like) for g in gys])
+
+
+class SrcnnResGroup:
+    """Stacked packs of G SRCNNRes members with folded first layers (see SrcnnResFold)."""
+
+    def __init__(self, packs_list):
+        self.packs_list = list(packs_list)
+        self.G = len(packs_list)
+        folds = [p[0].fold for p in packs_list]
+        if any(f is None for f in folds):
+            raise ValueError('grouped SRCNNRes: every member needs the folded first layer')
+        self.P = [p[0].cin - 12 for p in packs_list]
+        self.k = folds[0].k
+        self.img = stack_packed([f.img for f in folds])            # 9x9 3 -> 64
+        self.c2 = stack_packed([p[1] for p in packs_list])         # 5x5 64 -> 32
+        self.c3 = stack_packed([p[2] for p in packs_list])         # 5x5 32 -> 3 (its backward-data runs on the matrix cores)
+        self.tail = stack_small([f.tail for f in folds])           # 5x5 32 -> 3 forward, direct kernel
+        self.bwd_img = stack_small([f.bwd_img for f in folds])     # 9x9 64 -> 3 backward-data, direct kernel
+        self.rcase = [f.rcase for f in folds]
+        self.wconst = [f.wconst for f in folds]
+        self.M = self.rcase[0].shape[1]
+
+    def desc(self, n, hw, pvs=None):
+        d = L.SrcnnGroupDesc()
+        d.G, d.N, d.HW, d.M = self.G, n, hw, self.M
+        for g in range(self.G):
+            d.P[g] = self.P[g]
+            d.rcase[g], d.wconst[g] = self.rcase[g].data_ptr(), self.wconst[g].data_ptr()
+            d.pv[g] = pvs[g].data_ptr() if pvs is not None and self.P[g] else None
+        return d
+
+
+def _count(k=1):
+    if LAUNCHES is not None:
+        LAUNCHES[0] += k
+
+
+class _SrcnnResGroupFn(torch.autograd.Function):
+    """G SRCNNRes members on one shared input: outputs (y_0, ..., y_{G-1}), each (N,3,H,W) - slices of one buffer."""
+
+    @staticmethod
+    def forward(ctx, x, gp, grouped, *pvs):
+        x = _dev(x, 'img')
+        n, _, h, w = x.shape
+        G = gp.G
+        pvs = [_dev(p, 'params') if gp.P[g] else None for g, p in enumerate(pvs)]
+        for g, p in enumerate(pvs):
+            if gp.P[g] and (p.dim() != 2 or p.shape[0] != n or p.shape[1] != gp.P[g]):
+                raise ValueError('SRCNNRes group member %d: param_vec must be (N=%d,%d), got %s' % (g, n, gp.P[g], tuple(p.shape)))
+        stats, arg = channel_stats(x)                   # of the shared input: once for the whole group
+        table = torch.empty((G * n, gp.M), device=x.device, dtype=torch.float32)
+        L.call('risp_srcnn_case_table_group', _p(stats), C.byref(gp.desc(n, h * w, pvs)), _p(table), _stream())
+        if grouped:
+            t1 = conv(x, gp.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table, group=(G, L.GROUP_SHARED_X))
+            t2 = conv(t1, gp.c2, n, h, w, epi=EPI_RELU, group=(G, 0))
+            y = conv_small(t2, gp.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, group=(G, L.GROUP_SHARED_ADD))
+            _count(5 + 1)
+        else:
+            dev = dict(device=x.device, dtype=torch.float32)
+            t1, t2 = torch.empty((G * n, 64, h, w), **dev), torch.empty((G * n, 32, h, w), **dev)
+            y = torch.empty((G * n, 3, h, w), **dev)
+            split = _small_split(t2, gp.tail, G * n, h, w, EPI_ADD, 3)
+            for g, (c1, c2, c3) in enumerate(gp.packs_list):
+                s = slice(g * n, (g + 1) * n)
+                conv(x, c1.fold.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table[s], out=t1[s])
+                conv(t1[s], c2, n, h, w, epi=EPI_RELU, out=t2[s])
+                conv_small(t2[s], c1.fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, out=y[s], split=split)
+            _count(3 + 3 * G)
+        ctx.save_for_backward(t1, t2, arg, x)
+        ctx.gp, ctx.dims, ctx.grouped = gp, (n, h, w), grouped
+        return tuple(y.view(G, n, 3, h, w).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gys):
+        t1, t2, arg, x = ctx.saved_tensors
+        gp, (n, h, w), G = ctx.gp, ctx.dims, ctx.gp.G
+        gy = _stack_grads(gys, x)                       # (G*N,3,H,W)
+        dev = dict(device=gy.device, dtype=torch.float32)
+        if ctx.grouped:
+            g2 = conv(gy, gp.c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2, group=(G, 0))
+            g1 = conv(g2, gp.c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1, group=(G, 0))
+            gxs = conv_small(g1, gp.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3, group=(G, 0))
+            _count(3)
+        else:
+            g2, g1 = torch.empty((G * n, 32, h, w), **dev), torch.empty((G * n, 64, h, w), **dev)
+            gxs = torch.empty((G * n, 3, h, w), **dev)
+            split = _small_split(g1, gp.bwd_img, G * n, h, w, EPI_ADD, 3)
+            for g, (c1, c2, c3) in enumerate(gp.packs_list):
+                s = slice(g * n, (g + 1) * n)
+                conv(gy[s], c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2[s], out=g2[s])
+                conv(g2[s], c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1[s], out=g1[s])
+                conv_small(g1[s], c1.fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy[s], add_c=3, out=gxs[s], split=split)
+            _count(3 * G)
+        rs = torch.empty((G * n, gp.M), **dev)
+        L.call('risp_rect_sums', _p(g1), _p(rs), G * n * 64, h, w, gp.k, _stream())
+        row = 9 + max(gp.P)
+        gconst = torch.empty((G * n, row), **dev)       # min, mean, max planes, then the members' parameters
+        L.call('risp_srcnn_const_grad_group', _p(rs), C.byref(gp.desc(n, h * w)), _p(gconst), row, _stream())
+        gx = torch.empty((n, 3, h, w), **dev)
+        L.call('risp_group_sum', _p(gxs), _p(gx), G, n, 3, h * w, _p(gconst), row, _p(arg), _stream())
+        _count(3)
+        gpvs = tuple(gconst[g * n:(g + 1) * n, 9:9 + gp.P[g]] if gp.P[g] else None for g in range(G))
+        return (gx, None, None) + gpvs
+
+
+def _small_split(x, sc, n_total, h, w, epi, add_c):
+    """the channel split ``conv_small`` would take for the grouped launch (so that the per-member form uses the same)"""
+    d = L.ConvDesc(N=n_total, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
+                   add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=None, cvals=None, add=None, mask=None, y=None)
+    return L.load().risp_conv_small_groups(C.byref(d))
+
+
+def srcnn_res_group(x, pvs, packs_list, cache):
+    """[SRCNNRes_g(x, pvs[g]) for g] with one launch per layer.  ``cache``: a dict owned by the caller (the slot) that keeps
+    the stacked packs while the members' packs are unchanged."""
+    key = tuple(id(p) for p in packs_list)
+    gp = cache.get('srcnn_res')
+    if gp is None or gp[0] != key:
+        gp = cache['srcnn_res'] = (key, SrcnnResGroup(packs_list))
+    return list(_SrcnnResGroupFn.apply(x, gp[1], GROUP_LAUNCH, *pvs))
+
+
+class SrcnnDemosaicGroup:
+    """Stacked packs of G SRCNNDemosaic members (srcnn_demosaic_arch.py:14-55)."""
+
+    def __init__(self, packs_list):
+        self.packs_list = list(packs_list)
+        self.G = len(packs_list)
+        if any(getattr(p[0], 'small_bwd', None) is None or getattr(p[2], 'small', None) is None for p in packs_list):
+            raise ValueError('grouped SRCNNDemosaic: members need the direct-kernel forms of their first and last layer')
+        self.c1 = stack_packed([p[0] for p in packs_list])         # 9x9 4 -> 64 (space-to-depth load)
+        self.c2 = stack_packed([p[1] for p in packs_list])         # 1x1 64 -> 32
+        self.c3 = stack_packed([p[2] for p in packs_list])         # 5x5 32 -> 12: backward-data on the matrix cores
+        self.tail = stack_small([p[2].small for p in packs_list])  # 5x5 32 -> 12 + PixelShuffle, direct kernel
+        self.bwd_first = stack_small([p[0].small_bwd for p in packs_list])   # 9x9 64 -> 4 through PixelShuffle
+
+
+class _SrcnnDemosaicGroupFn(torch.autograd.Function):
+    """G SRCNNDemosaic members on one shared mosaic: outputs (y_0, ..., y_{G-1}), each (N,3,2h,2w)."""
+
+    @staticmethod
+    def forward(ctx, x, gp, grouped, infer):
+        x = _dev(x, 'img')
+        n, h, w = x.shape[0], x.shape[2] // 2, x.shape[3] // 2
+        G = gp.G
+        if grouped:
+            t1 = conv(x, gp.c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU, group=(G, L.GROUP_SHARED_X))
+            t2 = conv(t1, gp.c2, n, h, w, epi=EPI_RELU, group=(G, 0))
+            y = conv_small(t2, gp.tail, n, h, w, epi=EPI_SHUFFLE2, infer=infer, group=(G, 0))
+            _count(3)
+        else:
+            dev = dict(device=x.device, dtype=torch.float32)
+            t1, t2 = torch.empty((G * n, 64, h, w), **dev), torch.empty((G * n, 32, h, w), **dev)
+            y = torch.empty((G * n, 3, 2 * h, 2 * w), **dev)
+            split = _small_split(t2, gp.tail, G * n, h, w, EPI_SHUFFLE2, 0)
+            for g, (c1, c2, c3) in enumerate(gp.packs_list):
+                s = slice(g * n, (g + 1) * n)
+                conv(x, c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU, out=t1[s])
+                conv(t1[s], c2, n, h, w, epi=EPI_RELU, out=t2[s])
+                conv_small(t2[s], c3.small, n, h, w, epi=EPI_SHUFFLE2, infer=infer, out=y[s], split=split)
+            _count(3 * G)
+        ctx.save_for_backward(t1, t2, x)
+        ctx.gp, ctx.dims, ctx.grouped = gp, (n, h, w), grouped
+        return tuple(y.view(G, n, 3, 2 * h, 2 * w).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gys):
+        t1, t2, x = ctx.saved_tensors
+        gp, (n, h, w), G = ctx.gp, ctx.dims, ctx.gp.G
+        like = torch.empty(0)
+        gy = _stack_grads(gys, gys[0] if gys[0] is not None else like)
+        dev = dict(device=gy.device, dtype=torch.float32)
+        if ctx.grouped:
+            g2 = conv(gy, gp.c3, n, h, w, transpose=True, load=LOAD_UNSHUFFLE2, epi=EPI_MASK, mask=t2, group=(G, 0))
+            g1 = conv(g2, gp.c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1, group=(G, 0))
+            gxs = conv_small(g1, gp.bwd_first, n, h, w, epi=EPI_SHUFFLE2, group=(G, 0))
+            _count(3)
+        else:
+            g2, g1 = torch.empty((G * n, 32, h, w), **dev), torch.empty((G * n, 64, h, w), **dev)
+            gxs = torch.empty((G * n, 1, 2 * h, 2 * w), **dev)
+            split = _small_split(g1, gp.bwd_first, G * n, h, w, EPI_SHUFFLE2, 0)
+            for g, (c1, c2, c3) in enumerate(gp.packs_list):
+                s = slice(g * n, (g + 1) * n)
+                conv(gy[s], c3, n, h, w, transpose=True, load=LOAD_UNSHUFFLE2, epi=EPI_MASK, mask=t2[s], out=g2[s])
+                conv(g2[s], c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1[s], out=g1[s])
+                conv_small(g1[s], c1.small_bwd, n, h, w, epi=EPI_SHUFFLE2, out=gxs[s], split=split)
+            _count(3 * G)
+        gx = torch.empty_like(x)
+        L.call('risp_group_sum', _p(gxs), _p(gx), G, n, 1, 4 * h * w, None, 0, None, _stream())
+        _count(1)
+        return gx, None, None, None
+
+
+def srcnn_demosaic_group(x, packs_list, cache):
+    """[SRCNNDemosaic_g(x) for g] with one launch per layer (see srcnn_res_group)."""
+    key = tuple(id(p) for p in packs_list)
+    gp = cache.get('srcnn_demosaic')
+    if gp is None or gp[0] != key:
+        gp = cache['srcnn_demosaic'] = (key, SrcnnDemosaicGroup(packs_list))
+    return list(_SrcnnDemosaicGroupFn.apply(x, gp[1], GROUP_LAUNCH, not torch.is_grad_enabled()))

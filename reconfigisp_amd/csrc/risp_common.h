@@ -59,6 +59,27 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float *lds) {
     __syncthreads();
 }
 
+// Grouped convolution launch (risp_conv_desc.group_n > 0): the descriptor as image n's group sees it - weights and
+// bias of group g = n / group_n; shared tensors rebased so that the kernels' usual indexing by n lands on image
+// n - g * group_n.  Wave-uniform (n comes from blockIdx): scalar arithmetic, once per workgroup.
+__device__ __forceinline__ risp_conv_desc risp_conv_group_view(risp_conv_desc d, int n) {
+    if (d.group_n > 0) {
+        const int g = n / d.group_n;
+        const size_t hw = (size_t)d.H * d.W, back = (size_t)g * d.group_n;
+        d.wpack += (size_t)g * d.wpack_gs;
+        if (d.bias) d.bias += (size_t)g * d.bias_gs;
+        if (d.group_flags & RISP_GROUP_SHARED_X) d.x -= back * (d.load_mode == RISP_LOAD_CONSTCH ? d.cin_img : d.cin) * hw;
+        if ((d.group_flags & RISP_GROUP_SHARED_ADD) && d.add) d.add -= back * d.add_c * hw;
+    }
+    return d;
+}
+
+#define RISP_CHECK_GROUP(d, name)                                                                                        \
+    RISP_CHECK_ARG((d).group_n == 0 || ((d).group_n > 0 && (d).N % (d).group_n == 0 && (d).wpack_gs >= 0 && (d).bias_gs >= 0 && \
+                                        (d).wpack_gs % 4 == 0),                                                           \
+                   name ": grouped launch needs N %% group_n == 0 and non-negative strides, wpack_gs %% 4 == 0 (N=%d group_n=%d)", \
+                   (d).N, (d).group_n)
+
 struct f3 {
     float b, g, r;
 };

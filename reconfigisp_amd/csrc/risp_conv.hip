@@ -94,7 +94,7 @@ __device__ __forceinline__ float4 load_px4(const risp_conv_desc &d, int n, int c
 // written to LDS after it.  PP = ping-pong LDS buffers (one barrier per chunk); otherwise one buffer
 // and two barriers.
 template <int KS, int CK, int CB, bool FAST, bool PP>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc d) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc d_in) {
     constexpr int PAD = KS / 2, IH = TH + KS - 1, IW = TW + KS - 1, CP = 32 * CB, TAPS = KS * KS;
     constexpr int IWP = FAST ? (KS == 1 ? 32 : 40) : IW;      // LDS row stride (FAST: 16-byte aligned rows)
     constexpr int XOFF = FAST ? (KS == 1 ? 0 : 4 - PAD) : 0;  // first needed column inside a staged row
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const risp_conv_desc 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, n = blockIdx.z;
+    const risp_conv_desc d = risp_conv_group_view(d_in, n);
     const int wrow = wave * RW;
     const int nchunks = (d.cin + CK - 1) / CK;
 #ifdef RISP_CONV_STAMPS
@@ -520,6 +521,7 @@ int risp_conv2d(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d: null tensor");
+    RISP_CHECK_GROUP(d, "risp_conv2d");
     RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64,
                    "risp_conv2d: bad shape N=%d H=%d W=%d cin=%d cout=%d", d.N, d.H, d.W, d.cin, d.cout);
     RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d: bias missing");

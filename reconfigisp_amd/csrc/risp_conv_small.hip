@@ -33,13 +33,14 @@ template <int KS> struct SmallCfg { static constexpr int CCH = KS == 9 ? 3 : 4; 
 // SPY = output rows per thread: 2 (64 x 32 tiles) when the grid fills the chip, 1 (64 x 16 tiles, twice the
 // workgroups) for small batches - the per-GPU batch of the 8-GPU search is 4 images.
 template <int KS, int NP, int SPY>
-__global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d, int groups, float *__restrict__ partial) {
+__global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d_in, int groups, float *__restrict__ partial) {
     constexpr int SY = 16 * SPY;
     constexpr int P = KS / 2, TH_ = SY + 2 * P, CCH = SmallCfg<KS>::CCH, ROWV = STW / 4;
     extern __shared__ float4 lds4[];                       // [CCH][TH_][STW]
     // groups > 1 (small grids): the input channels are split over `groups` workgroups per tile, each writes its raw
     // partial sums to `partial` [group][N][cout][H][W] and small_reduce_kernel finishes (fixed order: deterministic)
     const int tid = threadIdx.x, n = blockIdx.z / groups, grp = blockIdx.z - n * groups;
+    const risp_conv_desc d = risp_conv_group_view(d_in, n);
     const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
     const int cpg = (d.cin + groups - 1) / groups, cbeg = grp * cpg, cend = (cbeg + cpg < d.cin) ? cbeg + cpg : d.cin;
     const int lx = (tid & 15) * SPX, ly = (tid >> 4) * SPY;
@@ -334,12 +335,13 @@ __global__ __launch_bounds__(256) void const_grad_kernel(const float *__restrict
 }
 
 // y = epilogue(sum over channel groups of the partial sums), the groups added in index order
-__global__ __launch_bounds__(256) void small_reduce_kernel(const risp_conv_desc d, int groups, const float *__restrict__ partial) {
-    const size_t plane = (size_t)d.H * d.W, total = (size_t)d.N * d.cout * plane;
+__global__ __launch_bounds__(256) void small_reduce_kernel(const risp_conv_desc d_in, int groups, const float *__restrict__ partial) {
+    const size_t plane = (size_t)d_in.H * d_in.W, total = (size_t)d_in.N * d_in.cout * plane;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int co = (int)((i / plane) % d.cout);
-    const size_t n = i / (plane * d.cout), pix = i % plane;
+    const int co = (int)((i / plane) % d_in.cout);
+    const size_t n = i / (plane * d_in.cout), pix = i % plane;
+    const risp_conv_desc d = risp_conv_group_view(d_in, (int)n);
     float v = partial[i];
     for (int g = 1; g < groups; ++g) v += partial[(size_t)g * total + i];
     const int epi = d.epilogue;
@@ -422,6 +424,7 @@ static int conv2d_small_impl(const risp_conv_desc *dp, float *scratch, int group
                    "risp_conv2d_small_split: %d groups need a scratch buffer and N * groups <= 65535", groups);
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_small: null tensor");
+    RISP_CHECK_GROUP(d, "risp_conv2d_small");
     RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cout > 0 && d.cout <= 12,
                    "risp_conv2d_small: bad shape N=%d H=%d W=%d cin=%d cout=%d (cout <= 12)", d.N, d.H, d.W, d.cin, d.cout);
     RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_small: only plain loads");

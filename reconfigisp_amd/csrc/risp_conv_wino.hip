@@ -302,7 +302,7 @@ constexpr int W5IH = WTH + 4, W5TAPS = 30;
 #define RISP_W5_WAVES 2
 #endif
 template <int CK>
-__global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const risp_conv_desc d, int ncb) {
+__global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const risp_conv_desc d_in, int ncb) {
     constexpr int CP = 32;
     constexpr int XN = CK * W5IH * WIWP, WN = W5TAPS * CK * CP;
     constexpr int NXV = (XN / 4 + 255) / 256, NWV = (WN / 4 + 255) / 256;
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const risp_conv_desc d = risp_conv_group_view(d_in, n);
     const int nchunks = (d.cin + CK - 1) / CK;
     const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
 
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const ri
 // conv_wino43_glds_kernel (see there).  The raw tile (4 x 8 x 72 floats = 9 wave-instructions of 64 x 16 bytes) and
 // the weight slab (30 x 4 x 32 floats = 15) make exactly 24 = 6 per wave; 2 LDS stages of 24 KB, 3 workgroups per CU.
 template <int WGS>
-__global__ __launch_bounds__(256, WGS) void conv_wino5_glds_kernel(const risp_conv_desc d, int ncb) {
+__global__ __launch_bounds__(256, WGS) void conv_wino5_glds_kernel(const risp_conv_desc d_in, int ncb) {
     constexpr int CK = 4, CP = 32;
     constexpr int XN = CK * W5IH * WIWP, WN = W5TAPS * CK * CP;          // floats: 2304, 3840
     constexpr int XI = XN / 256, WI = WN / 256, PER_WAVE = (XI + WI) / 4;
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(256, WGS) void conv_wino5_glds_kernel(const risp_co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const risp_conv_desc d = risp_conv_group_view(d_in, n);
     const int nchunks = d.cin / CK;
     const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
     const size_t hw = (size_t)d.H * d.W;
@@ -991,6 +993,7 @@ int risp_conv2d_wino3(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_wino3: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino3: null tensor");
+    RISP_CHECK_ARG(d.group_n == 0, "risp_conv2d_wino3: grouped launches are not supported by the 3x3 Winograd kernels");
     RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 &&
                        d.ksize == 3,
                    "risp_conv2d_wino3: needs a 3x3 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,
@@ -1020,6 +1023,7 @@ int risp_conv2d_wino43(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_wino43: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino43: null tensor");
+    RISP_CHECK_ARG(d.group_n == 0, "risp_conv2d_wino43: grouped launches are not supported by the 3x3 Winograd kernels");
     RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 && d.ksize == 3 &&
                        (size_t)d.N * ((d.cout + 31) / 32) <= 65535,
                    "risp_conv2d_wino43: needs a 3x3 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,
@@ -1074,6 +1078,7 @@ int risp_conv2d_wino5(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_wino5: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino5: null tensor");
+    RISP_CHECK_GROUP(d, "risp_conv2d_wino5");
     RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 && d.ksize == 5 &&
                        (size_t)d.N * ((d.cout + 31) / 32) <= 65535,
                    "risp_conv2d_wino5: needs a 5x5 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,

@@ -202,9 +202,10 @@ class _Mix(torch.autograd.Function):
     """y = sum_k w[k] * o_k ; w is a 1-D tensor (gradient flows to it), o_k the op outputs."""
 
     @staticmethod
-    def forward(ctx, w, w_host, *outs):
+    def forward(ctx, w, w_host, stacks, *outs):
         outs = [_dev(o) for o in outs]
         k = len(outs)
+        ctx.stacks = stacks
         if w_host is None:                  # the caller usually has the values on the host already (no second D2H)
             w_host = w.detach().cpu().tolist()
         w_host = [float(v) for v in w_host]
@@ -223,13 +224,19 @@ class _Mix(torch.autograd.Function):
         outs = ctx.saved_tensors
         gy = _dev(gy, 'grad')
         k = len(outs)
-        need = ctx.needs_input_grad[2:]
-        gos = [torch.empty_like(o) if nd else None for o, nd in zip(outs, need)]
+        need = ctx.needs_input_grad[3:]
+        gos = [None] * k
+        for members in (ctx.stacks or ()):          # operands that feed ONE grouped launch: consecutive slices of one buffer
+            if all(need[i] for i in members):
+                buf = torch.empty((len(members),) + tuple(outs[members[0]].shape), device=gy.device, dtype=torch.float32)
+                for j, i in enumerate(members):
+                    gos[i] = buf[j]
+        gos = [g if g is not None else (torch.empty_like(o) if nd else None) for g, o, nd in zip(gos, outs, need)]
         gw = torch.empty(k, device=gy.device, dtype=torch.float32)
         scratch = torch.empty(L.load().risp_mix_scratch_floats(), device=gy.device, dtype=torch.float32)
         L.call('risp_mix_bwd', L.ptr_array([o.data_ptr() for o in outs]), (C.c_float * k)(*ctx.w_host), k, _p(gy),
                L.ptr_array([g.data_ptr() if g is not None else None for g in gos]), _p(gw), _p(scratch), gy.numel(), _stream())
-        return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]), None) + tuple(gos)
+        return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]), None, None) + tuple(gos)
 
 
 class _PruneSoftmax(torch.autograd.Function):
@@ -422,8 +429,8 @@ class _HipImpl:
         return _DemosaicNearest.apply(x)
 
     @staticmethod
-    def mix(w, outs, w_host=None):
-        return _Mix.apply(w, w_host, *outs)
+    def mix(w, outs, w_host=None, stacks=None):
+        return _Mix.apply(w, w_host, stacks, *outs)
 
     @staticmethod
     def prune_softmax(alpha, threshold, unavailable=None):
@@ -477,6 +484,31 @@ class _HipImpl:
         return CN.srcnn_demosaic(x, packs)
 
     @staticmethod
+    def srcnn_res_group(x, pvs, modules, cache):
+        from . import convnets as CN
+        packs = [_packs(m, (lambda m=m: CN.build_srcnn_packs(m.srcnn, residual=True))) for m in modules]
+        return CN.srcnn_res_group(x, pvs, packs, cache)
+
+    @staticmethod
+    def srcnn_demosaic_group(x, modules, cache):
+        from . import convnets as CN
+        packs = [_packs(m, (lambda m=m: CN.build_srcnn_packs(m.srcnn))) for m in modules]
+        return CN.srcnn_demosaic_group(x, packs, cache)
+
+    @staticmethod
+    def can_group(modules, x):
+        """True when these same-class proxies can run as one grouped launch per layer on input x"""
+        from . import convnets as CN
+        from .codes.models.modules.srcnn_res_arch import SRCNNRes
+        if len(modules) < 2 or not x.is_cuda or x.shape[3] % 4 or x.data_ptr() % 16:
+            return False
+        if any(getattr(m, 'train_weights', False) for m in modules) and torch.is_grad_enabled():
+            return False                             # a proxy under fine-tuning needs its weight gradients: own launches
+        if isinstance(modules[0], SRCNNRes):
+            return CN._srcnn_fold_ok(x.shape[2], x.shape[3]) and all(m.srcnn[4].weight.shape[0] <= 4 for m in modules)
+        return x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0
+
+    @staticmethod
     def path14l_bayer(x, module):
         from . import convnets as CN
         packs = _packs(module, lambda: CN.build_path14l_packs(module.path_restore_14l, False))
@@ -528,9 +560,11 @@ def demosaic_nearest(x, p=None):
     return _IMPL.demosaic_nearest(x, p)
 
 
-def mix(w, outs, w_host=None):
-    """sum_k w[k] * outs[k]; ``w_host``: the same weights as Python floats when the caller already holds them."""
-    return _IMPL.mix(w, outs, w_host)
+def mix(w, outs, w_host=None, stacks=None):
+    """sum_k w[k] * outs[k]; ``w_host``: the same weights as Python floats when the caller already holds them;
+    ``stacks``: lists of operand positions whose gradients should come back as consecutive slices of one buffer (the
+    members of a grouped launch read them in place)."""
+    return _IMPL.mix(w, outs, w_host, stacks)
 
 
 def prune_softmax(alpha, threshold, unavailable=None):
@@ -560,6 +594,19 @@ def srcnn_res(x, pv, module):
 
 def srcnn_demosaic(x, module):
     return _IMPL.srcnn_demosaic(x, module)
+
+
+def srcnn_res_group(x, pvs, modules, cache):
+    """[srcnn_res(x, pvs[g], modules[g]) for g] as ONE launch per layer (convnets.srcnn_res_group)."""
+    return _IMPL.srcnn_res_group(x, pvs, modules, cache)
+
+
+def srcnn_demosaic_group(x, modules, cache):
+    return _IMPL.srcnn_demosaic_group(x, modules, cache)
+
+
+def can_group(modules, x):
+    return _IMPL.can_group(modules, x)
 
 
 def path14l_bayer(x, module):

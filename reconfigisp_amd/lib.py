@@ -24,7 +24,18 @@ class ConvDesc(C.Structure):
     _fields_ = [('N', _i), ('H', _i), ('W', _i), ('cin', _i), ('cout', _i), ('ksize', _i),
                 ('load_mode', _i), ('cin_img', _i), ('epilogue', _i), ('add_c', _i),
                 ('x', _f), ('wpack', _f), ('bias', _f), ('cvals', _f), ('add', _f), ('mask', _f),
-                ('y', _f)]
+                ('y', _f),
+                ('group_n', _i), ('group_flags', _i), ('wpack_gs', C.c_longlong), ('bias_gs', C.c_longlong)]
+
+
+GROUP_SHARED_X, GROUP_SHARED_ADD = 1, 2
+GROUP_MAX = 16
+
+
+class SrcnnGroupDesc(C.Structure):
+    """mirror of risp_srcnn_group_desc"""
+    _fields_ = [('G', _i), ('N', _i), ('HW', _i), ('M', _i), ('P', _i * GROUP_MAX), ('pv', _f * GROUP_MAX),
+                ('rcase', _f * GROUP_MAX), ('wconst', _f * GROUP_MAX)]
 
 
 TRAIN_MAX = 6
@@ -89,6 +100,9 @@ SIGNATURES = {
     'risp_conv2d_small_split': (_i, [C.POINTER(ConvDesc), _f, _i, _s]),
     'risp_rect_sums': (_i, [_f, _f, _i, _i, _i, _i, _s]),
     'risp_srcnn_const_grad': (_i, [_f, _f, _f, _i, _i, _i, _s]),
+    'risp_srcnn_case_table_group': (_i, [_f, C.POINTER(SrcnnGroupDesc), _f, _s]),
+    'risp_srcnn_const_grad_group': (_i, [_f, C.POINTER(SrcnnGroupDesc), _f, _i, _s]),
+    'risp_group_sum': (_i, [_f, _f, _i, _i, _i, _i, _f, _i, _f, _s]),
     'risp_conv_wino3_chunk': (_i, []),
     'risp_conv_wino3_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino3': (_i, [C.POINTER(ConvDesc), _s]),

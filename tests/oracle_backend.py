@@ -21,8 +21,13 @@ class OracleImpl:
     conditional_fc = staticmethod(lambda img, flat, widths: O.conditional_fc(img, flat, tuple(widths[:-1]), widths[-1]))
     demosaic_nearest = staticmethod(lambda x, p=None: O.demosaic_nearest(x))
 
+    # grouped launches are a launch-count matter of the HIP path; on the seam they are the members one by one
+    can_group = staticmethod(lambda modules, x: len(modules) >= 2)
+    srcnn_res_group = staticmethod(lambda x, pvs, ms, cache: [OracleImpl.srcnn_res(x, pv, m) for pv, m in zip(pvs, ms)])
+    srcnn_demosaic_group = staticmethod(lambda x, ms, cache: [OracleImpl.srcnn_demosaic(x, m) for m in ms])
+
     @staticmethod
-    def mix(w, outs, w_host=None):
+    def mix(w, outs, w_host=None, stacks=None):
         y = 0
         for wk, o in zip(w, outs):
             y = y + o * wk

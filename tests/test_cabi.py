@@ -37,7 +37,7 @@ def test_conv_desc_matches_header():
         decl = decl.replace('typedef struct {', '').strip()
         if not decl:
             continue
-        names = decl.split(None, 1)[1] if not decl.startswith('const') else decl.split('float', 1)[1]
+        names = re.sub(r'^(const\s+)?(float|int|long long)\s*', '', decl)
         fields += [n.strip().lstrip('*') for n in names.split(',')]
     assert [f for f, _ in lib.ConvDesc._fields_] == fields
 
@@ -71,7 +71,7 @@ def _struct_fields(name):
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r'^(const\s+)?(float|int|unsigned char)\s*', '', decl)
+        decl = re.sub(r'^(const\s+)?(float|int|long long|unsigned char)\s*', '', decl)
         for part in decl.split(','):
             fields.append(re.sub(r'\[.*?\]', '', part).replace('*', '').strip())
     return fields
@@ -81,6 +81,9 @@ def test_training_and_mixture_descriptors_match_header():
     from reconfigisp_amd import lib
     assert [f.rstrip('_') for f, _ in lib.TrainDesc._fields_] == _struct_fields('risp_train_desc')
     assert [f for f, _ in lib.ParamBlocksDesc._fields_] == _struct_fields('risp_param_blocks_desc')
+    assert [f for f, _ in lib.SrcnnGroupDesc._fields_] == _struct_fields('risp_srcnn_group_desc')
     assert lib.TRAIN_MAX == 6 and lib.PARAM_OPS_MAX == 16           # RISP_MAX_TRAIN_CHAIN / RISP_MAX_PARAM_OPS
+    assert lib.GROUP_MAX == 16 and '#define RISP_MAX_GROUP 16' in open(os.path.join(ROOT, 'include', 'risp.h')).read()
+    assert (lib.GROUP_SHARED_X, lib.GROUP_SHARED_ADD) == (1, 2)
     text = open(os.path.join(ROOT, 'include', 'risp.h')).read()
     assert '#define RISP_MAX_TRAIN_CHAIN 6' in text and '#define RISP_MAX_PARAM_OPS 16' in text
