@@ -73,6 +73,7 @@ class DartsModel(BaseModel):
             self.momentum_G = t['momentum_G']
             self.lr_meta = t['lr_meta']
             self.sync_arch_grads = bool(t.get('sync_arch_grads', True)) if hasattr(t, 'get') else True
+            self.step_reuse = bool(t.get('step_reuse', True)) if hasattr(t, 'get') else True
             self.optimizer_G = torch.optim.SGD(self.netG_attr.trainable_parameters, t['lr_G'],
                                                momentum=self.momentum_G)
             self.optimizer_alpha = torch.optim.Adam(self.netG_attr.alphas, lr=t['lr_G'],
@@ -217,6 +218,18 @@ class DartsModel(BaseModel):
                 torch._foreach_copy_(dst, src)
 
     def optimize_alphas(self):
+        # forwards #1 (virtual step), #3 and #4 (Hessian) evaluate netG on the same train batch with the same alphas: the
+        # parameter-free CNN ops upstream of the first shifted parameter are computed once (SuperPrune...begin_reuse)
+        reuse = self.step_reuse and hasattr(self.netG_attr, 'begin_reuse')
+        if reuse:
+            self.netG_attr.begin_reuse()
+        try:
+            self._optimize_alphas()
+        finally:
+            if reuse:
+                self.netG_attr.end_reuse()
+
+    def _optimize_alphas(self):
         self.optimizer_alpha.zero_grad()
         self.virtual_step()
         loss = self._loss(self.netV, self.val_img, self.val_gt, self.val_glb_flag, self.cri_pix_v)[0]

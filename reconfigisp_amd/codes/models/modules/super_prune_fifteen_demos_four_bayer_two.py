@@ -35,6 +35,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         self.trainable_params = []
         self.slot_names = []
         self._weight_cache = {}
+        self._reuse = None          # step-level reuse scope (begin_reuse / end_reuse)
 
         def empty():
             return nn.Parameter(torch.zeros(0))
@@ -98,7 +99,34 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             cache[key] = torch.tensor(mask, dtype=torch.uint8, device=device)
         return cache[key]
 
-    def _jobs(self, slot, mods, index, args, x):
+    # ------------------------------------------------------------------ step-level reuse
+    def begin_reuse(self):
+        """Until end_reuse(): forwards whose input batch, alphas and (for the ops concerned) parameters are unchanged take
+        the outputs and saved activations of the parameter-free CNN ops from the first such forward instead of
+        recomputing them.  DartsModel opens the scope around the architecture step: forwards #1, #3 and #4 of an
+        iteration (darts_model.py:182-222, 270-324) see the same train batch and the same alphas, slots 0-1 have no
+        trainable parameters, and the Path-Restore op of the first sRGB slot sees an identical input.  Identity is
+        tracked by value tokens: (data_ptr, _version) of the network input, then per slot (input token, alpha version,
+        versions of the slot's parameters) - the finite-difference shifts of the parameters bump their versions, so
+        everything downstream of a shifted parameter misses the cache by construction.  Results are bit-identical."""
+        self._reuse = {}
+
+    def end_reuse(self):
+        self._reuse = None
+        for mods in self.all_modules:
+            for m in mods:
+                m.__dict__.pop('_risp_reuse', None)
+
+    def _record(self, slot, k, token, mod):
+        """the reuse record of op k of `slot` for this input token (None outside a scope / for ops with parameters)"""
+        if self._reuse is None or token is None:
+            mod.__dict__.pop('_risp_reuse', None)
+            return None
+        rec = self._reuse.setdefault((slot, k, token), {})
+        mod.__dict__['_risp_reuse'] = rec
+        return rec
+
+    def _jobs(self, slot, mods, index, args, x, token=None):
         """The surviving ops of a slot as launch jobs [(positions in `index`, callable -> list of outputs)].  Same-geometry
         proxies - the SRCNNRes family of an sRGB slot (:35-52), the two proxy demosaics - form ONE job that runs every layer
         as a single grouped launch (convnets.srcnn_res_group); everything else is a job of its own.  Heavy jobs come first
@@ -113,12 +141,15 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                 if kind == 'res':
                     fn = (lambda members=members, pos=pos: F.srcnn_res_group(x, [args[i] for i in pos], members, cache))
                 else:
-                    fn = (lambda members=members: F.srcnn_demosaic_group(x, members, cache))
+                    rec = self._record(slot, index[pos[0]], token, members[0])
+                    fn = (lambda members=members, rec=rec: F.srcnn_demosaic_group(x, members, cache, rec))
                 jobs.append((pos, fn))
                 taken.update(pos)
         heavy = [i for i in range(len(index)) if i not in taken and isinstance(mods[index[i]], (TP.PathRestore14lBgr,
                                                                                                   TP.PathRestore14lBayer))]
         rest = [i for i in range(len(index)) if i not in taken and i not in heavy]
+        for i in heavy:
+            self._record(slot, index[i], token, mods[index[i]])      # read by F.path14l_* through the module
         single = [([i], (lambda i=i: [mods[index[i]](x, args[i])])) for i in heavy + rest]
         # group, Path-Restore, then the light ops: with two streams the two heavy jobs land on different streams
         return jobs[:1] + single[:len(heavy)] + jobs[1:] + single[len(heavy):]
@@ -167,6 +198,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
     def forward(self, x):
         n = x.size(0)
         self.middle_results = []
+        token = (x.data_ptr(), x._version, tuple(x.shape)) if self._reuse is not None else None
         for slot, (mods, pars, alpha) in enumerate(zip(self.all_modules, self.all_params, self.all_alphas)):
             # softmax -> strict-< prune against threshold * max (detached) -> renormalise by the detached sum: one launch
             unavailable = self._unavailable(mods, alpha.device)
@@ -191,7 +223,9 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                     live_pars.append(par)
             blocks = iter(F.param_blocks(live_pars, n))  # sigmoid(par).repeat(n, 1) of every surviving op: one launch
             args = [next(blocks) if pars[k].nelement() > 0 else None for k in index]
-            jobs = self._jobs(slot, mods, index, args, x)
+            jobs = self._jobs(slot, mods, index, args, x, token)
+            if token is not None:       # value token of this slot's output
+                token = (token, slot, alpha.data_ptr(), alpha._version, tuple((p.data_ptr(), p._version) for p in live_pars))
             outs = self._run_jobs(jobs, len(index), x, args)
             sel = post if len(index) == len(weights) else post[index]
             y = F.mix(sel, outs, w_host=[weights[k] for k in index], stacks=[pos for pos, _ in jobs if len(pos) > 1])

@@ -280,11 +280,20 @@ class PackCache:
 
 # --------------------------------------------------------------------------- Path-Restore (14 layers)
 class _Path14l(torch.autograd.Function):
+    """``record`` (a dict, or None): step-level reuse.  The first call stores the output and the saved activations in it;
+    a later call with the same record returns them without launching anything - the caller guarantees that input and
+    weights are unchanged (DartsModel: forwards #1, #3, #4 of an iteration see the same batch, darts_model.py:182-222,
+    270-324).  Each call is its own autograd node, so every backward pass runs with its own upstream gradient."""
+
     @staticmethod
-    def forward(ctx, x, packs, bayer, infer):
+    def forward(ctx, x, packs, bayer, infer, record=None):
         x = _dev(x, 'img')
         n = x.shape[0]
         h, w = (x.shape[2] // 2, x.shape[3] // 2) if bayer else (x.shape[2], x.shape[3])
+        ctx.packs, ctx.bayer, ctx.dims = packs, bayer, (n, h, w)
+        if record is not None and 'y' in record:
+            ctx.save_for_backward(*record['saved'])
+            return record['y'].detach()
         first, blocks, last = packs
         r = conv(x, first, n, h, w, load=LOAD_UNSHUFFLE2 if bayer else LOAD_PLAIN, epi=EPI_RELU, infer=infer)
         saved = [r]
@@ -295,7 +304,8 @@ class _Path14l(torch.autograd.Function):
         # the 64 -> 4 / 3 tail runs on the direct small-cout kernel (the matrix-core kernel pads cout to 32)
         y = conv_small(r, last.small, n, h, w, epi=EPI_SHUFFLE2 if bayer else 0, infer=infer)
         ctx.save_for_backward(*saved)
-        ctx.packs, ctx.bayer, ctx.dims = packs, bayer, (n, h, w)
+        if record is not None:
+            record['y'], record['saved'] = y.detach(), saved
         return y
 
     @staticmethod
@@ -312,8 +322,8 @@ class _Path14l(torch.autograd.Function):
             u, r_in = saved[1 + 2 * k], saved[2 * k]
             gu = conv(g, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=u)
             g = conv(gu, c1, n, h, w, transpose=True, epi=EPI_ADD | EPI_MASK, add=g, add_c=64, mask=r_in)
-        gx = conv_small(g, first.small_bwd, n, h, w, epi=EPI_SHUFFLE2 if ctx.bayer else 0)
-        return gx, None, None, None
+        gx = conv_small(g, first.small_bwd, n, h, w, epi=EPI_SHUFFLE2 if ctx.bayer else 0) if ctx.needs_input_grad[0] else None
+        return gx, None, None, None, None
 
 
 def build_path14l_packs(seq, flip_bgr):
@@ -331,12 +341,12 @@ def build_path14l_packs(seq, flip_bgr):
     return first, blocks, last
 
 
-def path14l(x, packs, bayer):
+def path14l(x, packs, bayer, record=None):
     # autograd globally off (test.py / test_split.py / serving): nothing in the process will differentiate through
     # these activations, so the 3x3 layers may take the F(4,3) form.  With autograd on - even for an op whose own
     # input needs no gradient - the F(2,3) form keeps the rounding, and with it the ReLU masks of every downstream
     # op, as close to the reference's arithmetic as the direct kernel does.
-    return _Path14l.apply(x, packs, bayer, not torch.is_grad_enabled())
+    return _Path14l.apply(x, packs, bayer, not torch.is_grad_enabled(), record)
 
 
 # --------------------------------------------------------------------------- SRCNN (residual proxy)
@@ -746,10 +756,14 @@ class _SrcnnDemosaicGroupFn(torch.autograd.Function):
     """G SRCNNDemosaic members on one shared mosaic: outputs (y_0, ..., y_{G-1}), each (N,3,2h,2w)."""
 
     @staticmethod
-    def forward(ctx, x, gp, grouped, infer):
+    def forward(ctx, x, gp, grouped, infer, record=None):
         x = _dev(x, 'img')
         n, h, w = x.shape[0], x.shape[2] // 2, x.shape[3] // 2
         G = gp.G
+        ctx.gp, ctx.dims, ctx.grouped = gp, (n, h, w), grouped
+        if record is not None and 'y' in record:           # step-level reuse, see _Path14l
+            ctx.save_for_backward(*record['saved'])
+            return tuple(record['y'].detach().view(G, n, 3, 2 * h, 2 * w).unbind(0))
         if grouped:
             t1 = conv(x, gp.c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU, group=(G, L.GROUP_SHARED_X))
             t2 = conv(t1, gp.c2, n, h, w, epi=EPI_RELU, group=(G, 0))
@@ -767,7 +781,8 @@ class _SrcnnDemosaicGroupFn(torch.autograd.Function):
                 conv_small(t2[s], c3.small, n, h, w, epi=EPI_SHUFFLE2, infer=infer, out=y[s], split=split)
             _count(3 * G)
         ctx.save_for_backward(t1, t2, x)
-        ctx.gp, ctx.dims, ctx.grouped = gp, (n, h, w), grouped
+        if record is not None:
+            record['y'], record['saved'] = y.detach(), (t1, t2, x)
         return tuple(y.view(G, n, 3, 2 * h, 2 * w).unbind(0))
 
     @staticmethod
@@ -795,13 +810,13 @@ class _SrcnnDemosaicGroupFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         L.call('risp_group_sum', _p(gxs), _p(gx), G, n, 1, 4 * h * w, None, 0, None, _stream())
         _count(1)
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
-def srcnn_demosaic_group(x, packs_list, cache):
-    """[SRCNNDemosaic_g(x) for g] with one launch per layer (see srcnn_res_group)."""
+def srcnn_demosaic_group(x, packs_list, cache, record=None):
+    """[SRCNNDemosaic_g(x) for g] with one launch per layer (see srcnn_res_group); ``record``: see _Path14l."""
     key = tuple(id(p) for p in packs_list)
     gp = cache.get('srcnn_demosaic')
     if gp is None or gp[0] != key:
         gp = cache['srcnn_demosaic'] = (key, SrcnnDemosaicGroup(packs_list))
-    return list(_SrcnnDemosaicGroupFn.apply(x, gp[1], GROUP_LAUNCH, not torch.is_grad_enabled()))
+    return list(_SrcnnDemosaicGroupFn.apply(x, gp[1], GROUP_LAUNCH, not torch.is_grad_enabled(), record))

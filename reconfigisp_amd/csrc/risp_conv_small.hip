@@ -32,8 +32,13 @@ template <int KS> struct SmallCfg { static constexpr int CCH = KS == 9 ? 3 : 4; 
 // srcnn_demosaic_arch.py:21, which the matrix-core kernel pads to 32).  The weight pack is [cin][k][k][2 NP].
 // SPY = output rows per thread: 2 (64 x 32 tiles) when the grid fills the chip, 1 (64 x 16 tiles, twice the
 // workgroups) for small batches - the per-GPU batch of the 8-GPU search is 4 images.
+// Occupancy: the 3x3 and 9x9 forms with 4 couts are held to 128 registers = FOUR workgroups per CU (a few spilled
+// values outside the tap loops): the weights arrive by scalar loads whose latency three waves per SIMD do not cover, and
+// the 1024-tile grid of a grouped launch at the per-GPU batch of the 8-GPU search is then ONE round of workgroups
+// instead of 768 + 256 (9x9 64 -> 3 on 32 x 256 x 256: 1050 -> 873 us).  The 5x5 form loses (44 bytes of scratch in
+// the loop: 215 -> 277 us) and keeps its 165 registers.
 template <int KS, int NP, int SPY>
-__global__ __launch_bounds__(256) void conv_small_kernel(const risp_conv_desc d_in, int groups, float *__restrict__ partial) {
+__global__ __launch_bounds__(256, (NP == 2 && KS != 5 ? 4 : (NP == 2 ? 3 : 2))) void conv_small_kernel(const risp_conv_desc d_in, int groups, float *__restrict__ partial) {
     constexpr int SY = 16 * SPY;
     constexpr int P = KS / 2, TH_ = SY + 2 * P, CCH = SmallCfg<KS>::CCH, ROWV = STW / 4;
     extern __shared__ float4 lds4[];                       // [CCH][TH_][STW]

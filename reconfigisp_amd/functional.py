@@ -490,10 +490,10 @@ class _HipImpl:
         return CN.srcnn_res_group(x, pvs, packs, cache)
 
     @staticmethod
-    def srcnn_demosaic_group(x, modules, cache):
+    def srcnn_demosaic_group(x, modules, cache, record=None):
         from . import convnets as CN
         packs = [_packs(m, (lambda m=m: CN.build_srcnn_packs(m.srcnn))) for m in modules]
-        return CN.srcnn_demosaic_group(x, packs, cache)
+        return CN.srcnn_demosaic_group(x, packs, cache, record)
 
     @staticmethod
     def can_group(modules, x):
@@ -512,13 +512,13 @@ class _HipImpl:
     def path14l_bayer(x, module):
         from . import convnets as CN
         packs = _packs(module, lambda: CN.build_path14l_packs(module.path_restore_14l, False))
-        return CN.path14l(x, packs, True)
+        return CN.path14l(x, packs, True, module.__dict__.get('_risp_reuse'))
 
     @staticmethod
     def path14l_bgr(x, module):
         from . import convnets as CN
         packs = _packs(module, lambda: CN.build_path14l_packs(module.path_restore_14l, True))
-        return CN.path14l(x, packs, False)
+        return CN.path14l(x, packs, False, module.__dict__.get('_risp_reuse'))
 
 
 def _packs(module, build):
@@ -601,8 +601,8 @@ def srcnn_res_group(x, pvs, modules, cache):
     return _IMPL.srcnn_res_group(x, pvs, modules, cache)
 
 
-def srcnn_demosaic_group(x, modules, cache):
-    return _IMPL.srcnn_demosaic_group(x, modules, cache)
+def srcnn_demosaic_group(x, modules, cache, record=None):
+    return _IMPL.srcnn_demosaic_group(x, modules, cache, record)
 
 
 def can_group(modules, x):

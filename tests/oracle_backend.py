@@ -24,7 +24,7 @@ class OracleImpl:
     # grouped launches are a launch-count matter of the HIP path; on the seam they are the members one by one
     can_group = staticmethod(lambda modules, x: len(modules) >= 2)
     srcnn_res_group = staticmethod(lambda x, pvs, ms, cache: [OracleImpl.srcnn_res(x, pv, m) for pv, m in zip(pvs, ms)])
-    srcnn_demosaic_group = staticmethod(lambda x, ms, cache: [OracleImpl.srcnn_demosaic(x, m) for m in ms])
+    srcnn_demosaic_group = staticmethod(lambda x, ms, cache, record=None: [OracleImpl.srcnn_demosaic(x, m) for m in ms])
 
     @staticmethod
     def mix(w, outs, w_host=None, stacks=None):

@@ -1,0 +1,87 @@
+"""GPU: step-level reuse inside a DARTS iteration (SuperPrune...begin_reuse, DartsModel.optimize_alphas): forwards #1, #3
+and #4 (darts_model.py:182-222, 270-324) see the same train batch and alphas, so the parameter-free CNN ops upstream of
+the first shifted parameter are computed once.  Architecture gradients, validation loss and the state after the step are
+the SAME BITS with the cache on and off; the cache removes launches."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_host_logic import darts_opt, seed_darts
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def _run(reuse, iters=2):
+    from reconfigisp_amd import convnets as CN
+    from reconfigisp_amd.codes.models import create_model
+    g = load_golden('darts_step')
+    opt = darts_opt(torch.device('cuda'))
+    opt['train']['step_reuse'] = reuse
+    torch.manual_seed(0)
+    model = create_model(opt)
+    seed_darts(model)
+    data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
+    out = []
+    calls = [0]
+    real = CN.L.call
+
+    def counting(name, *a):
+        calls[0] += 1
+        return real(name, *a)
+
+    CN.L.call = counting
+    try:
+        for it in range(iters):
+            model.feed_data(data)
+            model.update_learning_rate(it, warmup_iter=-1)
+            model.optimize_alphas()
+            out.append(model.val_loss.detach().clone())
+            out += [a.grad.clone() for a in model.netG.alphas]
+            model.optimize_parameters()
+            out += [v.detach().clone() for v in model.netG.state_dict().values()]
+    finally:
+        CN.L.call = real
+    return out, calls[0], model
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+def test_search_iteration_identical_with_and_without_step_reuse():
+    on, calls_on, model = _run(True)
+    off, calls_off, _ = _run(False)
+    assert len(on) == len(off)
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)
+    # 2 of the 3 train-batch forwards skip Path-Restore-Bayer (14 launches), the proxy demosaics (3) and the Path-Restore op
+    # of the first sRGB slot (14) in every iteration
+    assert calls_off - calls_on >= 2 * 2 * (14 + 3 + 14)
+    assert model.netG._reuse is None                                  # the scope is closed after the architecture step
+    assert all('_risp_reuse' not in m.__dict__ for mods in model.netG.all_modules for m in mods)
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+def test_reuse_scope_misses_when_the_input_or_a_parameter_changes():
+    """outside DartsModel: same input twice hits, an in-place change of the input or of a slot parameter misses"""
+    from test_host_logic import build_supernet
+    import isp_oracle as O
+    net = build_supernet(2, torch.device('cuda'))
+    bay, _ = O.synthetic_raw(2, 32, 32, seed=4)
+    bay = bay.cuda()
+    ref = net(bay).detach()
+    net.begin_reuse()
+    try:
+        a = net(bay).detach()
+        n_rec = len(net._reuse)
+        b = net(bay).detach()
+        assert len(net._reuse) == n_rec and torch.equal(a, ref) and torch.equal(b, ref)
+        with torch.no_grad():
+            net.param_step1_gamma.add_(0.25)                          # first sRGB slot: downstream Path-Restore must recompute
+        c = net(bay).detach()
+        assert len(net._reuse) > n_rec
+        bay.mul_(0.5)                                                 # new input value, same storage
+        d = net(bay).detach()
+    finally:
+        net.end_reuse()
+    assert torch.equal(c, net(bay.mul(2.0)).detach()) and not torch.equal(c, ref)
+    assert torch.equal(d, net(bay).detach())
