@@ -243,6 +243,14 @@ int risp_conv_wino5_chunk(void);
 size_t risp_conv_wino5_wpack_floats(int cin, int cout);
 int risp_conv2d_wino5(const risp_conv_desc *d, void *stream);
 
+/* The same operator for a 9x9 layer over exactly 3 input channels and 33..64 output channels - SRCNNRes' first layer with its
+ * broadcast planes folded out (srcnn_res_arch.py:18, 41-46): the reduction index k = ci * 81 + ky * 9 + kx is linear, so the
+ * matrix instruction's two k-slots hold consecutive k and 3 channels cost 122 instructions per tile instead of the 162 that
+ * channel PAIRS cost in risp_conv2d.  wpack: [244][64] floats, row k = w[co][ci][ky][kx] over co (rows >= 243 and columns >=
+ * cout zero), 16-byte aligned.  load_mode PLAIN, W % 4 == 0, 16-byte aligned tensors; epilogue RELU | NOBIAS | CASEBIAS. */
+size_t risp_conv_k3_wpack_floats(int cin, int cout, int ksize);
+int risp_conv2d_k3(const risp_conv_desc *d, void *stream);
+
 /* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */

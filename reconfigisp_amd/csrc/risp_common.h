@@ -80,6 +80,21 @@ __device__ __forceinline__ risp_conv_desc risp_conv_group_view(risp_conv_desc d,
                    name ": grouped launch needs N %% group_n == 0 and non-negative strides, wpack_gs %% 4 == 0 (N=%d group_n=%d)", \
                    (d).N, (d).group_n)
 
+typedef __attribute__((address_space(3))) void lptr_t;
+// One LDS-DMA wave-instruction: lanes whose bit is set in `mask` copy 16 bytes from their `src` to LDS byte address
+// lds_dst + 16 * lane; the others are switched off by EXEC inside the statement (no compiler branch around it, so
+// every wave issues the same number of DMAs) and leave their slot untouched.  M0 and EXEC are saved and restored in
+// the same statement.  Inline asm rather than __builtin_amdgcn_global_load_lds: beside the builtin hipcc turns the
+// counted lgkmcnt(N) waits of the following operand reads into lgkmcnt(0).
+__device__ __forceinline__ void lds_dma16(const float *src, float *dst_wave_base, unsigned long long mask) {
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)dst_wave_base);
+    unsigned long long keep_exec;
+    unsigned keep_m0;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(src), "s"(lds_dst), "s"(mask) : "memory");
+}
+
 struct f3 {
     float b, g, r;
 };

@@ -357,3 +357,63 @@ def test_random_layer_shapes(seed, monkeypatch):
     assert_close(got, (gref + addb) * (maskb > 0), what=tag + ' bwd-data add+mask')
     if cout <= 12 and k in (3, 5) or cout <= 4 and k == 9:
         assert_close(CN.conv_small(x, CN.SmallConv(wt, b), n, h, w, epi=CN.EPI_RELU), torch.relu(lin), what=tag + ' small')
+
+
+@pytest.mark.parametrize('hw', [(8, 8), (16, 32), (20, 36), (40, 72), (256, 256)])
+@pytest.mark.parametrize('cout', [64, 48])
+def test_linear_k_9x9_over_three_channels(cout, hw):
+    """risp_conv2d_k3 (SRCNNRes' folded first layer, srcnn_res_arch.py:18): against PyTorch, with the border-case table
+    and ReLU epilogue, ungrouped and as a grouped launch of three members on one shared input; and against the general
+    kernel (another summation order: float tolerance)."""
+    from reconfigisp_amd import convnets as CN
+    import ctypes as C
+    from reconfigisp_amd import lib as L
+    from reconfigisp_amd.functional import _p, _stream
+    h, w = hw
+    n = 2
+    packs, ws, bs = [], [], []
+    for g in range(3):
+        wt, b = rnd(cout, 3, 9, 9, seed=30 + g) * 0.1, rnd(cout, seed=40 + g) * 0.1
+        pc = CN.PackedConv(wt, b)
+        pc.k3 = CN.k3_weights(wt)
+        packs.append(pc); ws.append(wt); bs.append(b)
+    x = rnd(n, 3, h, w, seed=50)
+    table = rnd(3 * n, cout, 9, 9, seed=51) * 0.1
+
+    def launch(pc, xx, tab, epi, group=None):
+        assert CN.K3
+        calls = []
+        real = L.call
+        L.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            y = CN.conv(xx, pc, n, h, w, epi=epi, cvals=tab, group=group)
+        finally:
+            L.call = real
+        assert calls == ['risp_conv2d_k3']
+        return y
+
+    ref = [TF.conv2d(x, ws[g], bs[g], padding=4) for g in range(3)]
+    assert_close(launch(packs[0], x, None, 0), ref[0], what='k3 plain')
+    # border-case table + ReLU
+    def case_of(v, L_):
+        return torch.tensor([i if i < 4 else (8 - (L_ - 1 - i) if i >= L_ - 4 else 4) for i in range(L_)])
+    cy, cx = case_of(0, h).cuda(), case_of(0, w).cuda()
+    def with_table(g):
+        t = table[g * n:(g + 1) * n]
+        return torch.relu(ref[g] + t[:, :, cy][:, :, :, cx])
+    y = launch(packs[1], x, table[n:2 * n].contiguous(), CN.EPI_RELU | CN.EPI_CASEBIAS)
+    assert_close(y, with_table(1), what='k3 casebias + relu')
+    # grouped: three members, one shared input
+    stacked = CN.stack_packed(packs)
+    yg = launch(stacked, x, table, CN.EPI_RELU | CN.EPI_CASEBIAS, group=(3, L.GROUP_SHARED_X))
+    for g in range(3):
+        single = launch(packs[g], x, table[g * n:(g + 1) * n].contiguous(), CN.EPI_RELU | CN.EPI_CASEBIAS)
+        assert torch.equal(yg[g * n:(g + 1) * n], single)
+        assert_close(single, with_table(g), what='k3 member %d' % g)
+    # the general kernel on the same layer
+    CN.K3 = False
+    try:
+        general = CN.conv(x, packs[0], n, h, w)
+    finally:
+        CN.K3 = True
+    assert_close(launch(packs[0], x, None, 0), general, rtol=1e-5, floor=1.0, what='k3 vs general kernel')
