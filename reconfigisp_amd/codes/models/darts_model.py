@@ -147,8 +147,8 @@ class DartsModel(BaseModel):
 
     def _allreduce_mean(self, tensors):
         """Average a list of small gradient tensors over the ranks with ONE flat all-reduce (RCCL)."""
-        if not self.distributed or self.world == 1:
-            return tensors
+        if not self.distributed:
+            return tensors                          # (a world of one still goes through the collective: same code path)
         live = [t for t in tensors if t is not None and t.numel()]
         if not live:
             return tensors

@@ -32,19 +32,22 @@ TILE_STREAMS = int(os.environ.get('RISP_TILE_STREAMS', '2'))      # 1 = everythi
 _SIDE = {}
 
 
-def run_frame(model, frame, size, stride, tile_batch=16, rank=0, world=1, gather=gather_tiles, blend=blend_tiles):
+def run_frame(model, frame, size, stride, tile_batch=16, rank=0, world=1, gather=gather_tiles, blend=blend_tiles,
+              collective=False):
     """frame: (1,C,H,W) tensor.  Returns the blended (1,3,H,W) output of the last pipeline stage.
 
     ``world > 1`` (one process per GPU, torch.distributed initialised): the tiles are independent, so rank r runs
     tiles r, r + world, ... ; the last-stage tiles are exchanged with ONE all_gather (RCCL over xGMI: 63 x 3 MB for a
     3000 x 4000 frame) and every rank blends the frame - no other communication.  The result is bit-identical to
-    the single-process run: a tile's arithmetic does not depend on which tiles share its batch."""
+    the single-process run: a tile's arithmetic does not depend on which tiles share its batch.  A rank may own no tile
+    at all (fewer tiles than ranks): it contributes padding.  ``collective``: take the all_gather path even when
+    world == 1 (the RCCL self-test on a one-GPU box, tests/test_gpu_rccl.py)."""
     dev = model.device
     img = frame[0].to(dev)
     _, H, W = img.shape
     positions = tile_grid(H, W, size, stride)
     mine = np.arange(rank, len(positions), world)
-    tiles = gather(img, positions[mine], size)
+    tiles = gather(img, positions[mine], size) if len(mine) else img.new_zeros((0, img.shape[0]) + tuple(int(v) for v in size))
     if rank <= 0:
         print('Split into {} patches'.format(len(positions)))
     outs = []
@@ -55,11 +58,15 @@ def run_frame(model, frame, size, stride, tile_batch=16, rank=0, world=1, gather
     side = None
     if main is not None and TILE_STREAMS > 1 and len(mine) > tile_batch:
         side = _SIDE.setdefault(img.device.index, torch.cuda.Stream(device=img.device))
-        side.wait_stream(main)
         tiles.record_stream(side)
     for k, at in enumerate(range(0, len(mine), tile_batch)):
         chunk = tiles[at: at + tile_batch]
         stream = side if (side is not None and k % 2) else main
+        if k == 1 and side is not None:
+            # first use of the side stream: AFTER batch 0 has been issued on the main stream - the model fills its lazily
+            # built caches (packed weights, per-image parameter blocks) with launches on the stream of their first use
+            # and later batches find them by host-side keys, so those launches must be ordered before the side stream
+            side.wait_stream(main)
         if stream is None:
             model.feed_data((chunk, chunk))        # dummy ground truth, as in the reference (:93)
             _, mids = model.test()
@@ -72,8 +79,11 @@ def run_frame(model, frame, size, stride, tile_batch=16, rank=0, world=1, gather
         outs.append(mids[-1])
     if side is not None:
         main.wait_stream(side)
-    local = torch.cat(outs, dim=0)
-    if world > 1:
+    if outs:
+        local = torch.cat(outs, dim=0)
+    else:                                          # this rank owns no tile (fewer tiles than ranks)
+        local = img.new_zeros((0, 3) + tuple(int(v) for v in size))
+    if world > 1 or collective:
         import torch.distributed as dist
         per = (len(positions) + world - 1) // world
         if local.shape[0] < per:                   # ranks at the tail own one tile less: pad to a common shape

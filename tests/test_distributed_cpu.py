@@ -110,7 +110,7 @@ def _cpu_blend(patches, positions, full, stride):
     return acc / cnt
 
 
-def _frame_job(rank, world):
+def _frame_job(rank, world, shape=(44, 62)):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import reconfigisp_amd.functional as F
@@ -125,17 +125,17 @@ def _frame_job(rank, world):
                       path=dict(pretrain_model_G=None, strict_load=True))
     model = create_model(opt)
     g = np.random.Generator(np.random.PCG64(5))
-    frame = torch.from_numpy(g.random((1, 1, 44, 62)).astype(np.float32))
+    frame = torch.from_numpy(g.random((1, 1) + tuple(shape)).astype(np.float32))
     return run_frame(model, frame, (16, 16), (12, 12), tile_batch=2, rank=rank, world=world, gather=_cpu_gather,
                      blend=_cpu_blend)
 
 
-def _frame_worker(rank, world, port, out):
+def _frame_worker(rank, world, port, out, shape=(44, 62)):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        y = _frame_job(rank, world)
+        y = _frame_job(rank, world, shape)
         torch.save(y, out + '.%d' % rank)
     finally:
         dist.destroy_process_group()
@@ -150,4 +150,13 @@ def test_frame_tiles_sharded_over_ranks_equal_one_process(tmp_path, world):
     out = str(tmp_path / 'frame.pt')
     mp.spawn(_frame_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     for r in range(world):
+        assert torch.equal(torch.load(out + '.%d' % r), ref), 'rank %d' % r
+
+
+def test_frame_with_fewer_tiles_than_ranks(tmp_path):
+    """a 20 x 20 frame is 4 tiles; with 5 ranks the last one owns none and contributes padding to the all_gather"""
+    ref = _frame_job(0, 1, (20, 20))
+    out = str(tmp_path / 'small.pt')
+    mp.spawn(_frame_worker, args=(5, _free_port(), out, (20, 20)), nprocs=5, join=True)
+    for r in range(5):
         assert torch.equal(torch.load(out + '.%d' % r), ref), 'rank %d' % r

@@ -49,3 +49,16 @@ def test_bench_gpus2_self_launch_dry_run():
     assert s['allreduce_s_per_step'] > 0 and s['one_gpu']['s_per_step'] > 0
     # two ranks with half of the batch each compute the same averaged gradients as one rank with the whole batch
     assert abs(s['loss_rank0'] - s['one_gpu']['loss']) < 0.2 * abs(s['one_gpu']['loss']) + 1e-6
+
+
+def test_bench_gpus8_self_launch_dry_run():
+    """what the driver's SCALE run starts on an 8-GPU node, with all eight ranks on device 0 over gloo: launcher,
+    rendezvous, batch / tile sharding, the four all-reduces per search iteration, one line"""
+    line = _bench('--gpus', '8', '--steps', '50', '--warmup', '5', '--batch', '8', '--search-batch', '8', '--no-cnn',
+                  RISP_BENCH_ONE_DEVICE='1')
+    assert line['n_gpus'] == 8 and line['dry_run_all_ranks_on_one_device'] is True
+    assert line['config']['global_batch'] == 64 and 'cpu_baseline' not in line
+    s = line['extra']['search_step']
+    assert 'error' not in s, s
+    assert s['n_gpus'] == 8 and s['per_rank_batch'] == 1 and s['allreduce_calls_per_step'] == 4
+    assert s['one_gpu']['s_per_step'] > 0 and s['speedup_vs_one_gpu'] > 0
