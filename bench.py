@@ -166,40 +166,69 @@ def measured_traffic(algorithmic_bytes):
     return None
 
 
-def cpu_baseline(bay, arch, budget_s=10.0):
-    """The CPU oracle (restatement of the reference's torch-CPU path) on a bounded sample of the same
-    batch.  The thread count is the best of a short sweep (torch's default of one thread per core
-    oversubscribes these small element-wise ops on a 256-core host)."""
+def host_cpu():
+    """(model string, physical cores, logical cores) from /proc/cpuinfo"""
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                k, _, v = ln.partition(':')
+                k, v = k.strip(), v.strip()
+                if k == 'model name':
+                    model = v
+                elif k == 'physical id':
+                    phys = v
+                elif k == 'core id':
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(bay, arch, point_s=3.0, min_iters=10):
+    """The CPU oracle (restatement of the reference's torch-CPU path, oracle/isp_oracle.py) on the WHOLE batch the GPU
+    leg times, on the host cores of this box.  Thread sweep 8, 16, ... up to every logical core,
+    `point_s` seconds per point; then at least `min_iters` timed repetitions at the best count.  About 25-35 s in total."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import isp_oracle as O
-    cores = os.cpu_count() or 1
+    model, physical, logical = host_cpu()
     names = O.parse_architecture(arch)
     raw = [torch.tensor(O.PARAM_INIT[k]) for k in names]
-    n = min(4, bay.shape[0])
-    sample = bay[:n].cpu()
+    sample = bay.cpu()
+    n = sample.shape[0]
     run = lambda: O.fixed_pipeline(sample, names, raw, [None] * len(names), origin=True)
 
-    def rate(threads, seconds, max_reps):
+    def rate(threads, seconds, min_reps):
         torch.set_num_threads(threads)
         run()
         reps, t0 = 0, time.perf_counter()
-        while reps < 1 or (time.perf_counter() - t0 < seconds and reps < max_reps):
+        while reps < min_reps or time.perf_counter() - t0 < seconds:
             run()
             reps += 1
         return reps, time.perf_counter() - t0
 
+    points = sorted({t for t in (8, 16, 32, 64, 128, 256, 512) if t < logical} | {logical})
+    sweep = {}
     with torch.no_grad():
-        best, best_rate = 1, 0.0
-        for th in sorted({8, 16, 32, 64} & set(range(1, cores + 1))) or [cores]:
-            reps, dt = rate(th, 0.5, 20)
-            if reps / dt > best_rate:
-                best, best_rate = th, reps / dt
-        reps, dt = rate(best, budget_s, 2000)
-    mpix = n * bay.shape[2] * bay.shape[3] * reps / dt / 1e6
-    return {'value': round(mpix, 2), 'unit': 'MPix/s', 'cores': best, 'kind': 'port',
-            'sample': '%d of the %d 256x256 patches x %d repetitions of %s through oracle/isp_oracle.py '
-                      '(torch CPU fp32, best of a thread sweep = %d threads on a %d-core host)'
-                      % (n, bay.shape[0], reps, arch, best, cores)}
+        for th in points:
+            reps, dt = rate(th, point_s, 1)
+            sweep[th] = reps / dt
+        best = max(sweep, key=sweep.get)
+        reps, dt = rate(best, point_s, min_iters)
+    pix = n * bay.shape[2] * bay.shape[3]
+    return {'value': round(pix * reps / dt / 1e6, 2), 'unit': 'MPix/s', 'cores': best, 'kind': 'port',
+            'cpu_model': model, 'physical_cores': physical, 'logical_cores': logical,
+            'thread_sweep_MPix_s': {str(t): round(pix * r / 1e6, 2) for t, r in sorted(sweep.items())},
+            'sample': 'the whole batch of %d 256x256 patches x %d repetitions of %s through oracle/isp_oracle.py (torch CPU '
+                      'fp32) at the best thread count of the sweep (%d threads; %s, %d physical / %d logical cores)'
+                      % (n, reps, arch, best, model, physical, logical)}
 
 
 def free_port():

@@ -53,21 +53,25 @@ def assert_close(a, b, rtol=1e-4, atol=1e-6, what='', floor=0.05):
 
 class ErrorBudget:
     """Measured fp32 error budget.  A float64 evaluation of the same graph is the truth; the reference's (or the
-    oracle's) own float32 result shows what fp32 arithmetic costs; the HIP result may cost at most ``factor`` times that:
+    oracle's) own float32 result shows what fp32 arithmetic costs; the HIP result may cost at most ``factor`` times that,
+    and never more than the north-star bar:
 
-        max|hip - fp64| / scale  <=  factor * E_ref(family) + atol,      scale = max(1, max|fp64|)
+        e_hip = max|hip - fp64| / max|fp64|   <=   min(factor * E_ref(family), bar) + atol        (bar = 1e-4)
 
-    E_ref(family) is the LARGEST relative fp32 error of the reference over the quantities of one family (slot outputs,
-    architecture gradients, parameter gradients, ...) in the test.  Per family, not per tensor, because everything
-    downstream of a ReLU mask is discontinuous in the pre-activations: a pre-activation within an ulp of zero is
-    clipped by one fp32 implementation and not by another, and which tensor that lands in is arbitrary (measured: the
-    reference is 1.2e-4 off on the second DARTS iteration's architecture gradients and 8e-7 on the first's; the HIP
-    path the other way round).  ``atol`` = 4e-6 (64 ulp of the tensor's magnitude) covers the hardware exp2 / log2
-    approximations and the fixed summation order of the reductions.  The north-star bar is 1e-4.
-    Checks are collected; ``finish()`` fails with the full list (RISP_BUDGET_REPORT=1 prints every measured pair)."""
+    Errors are relative to the tensor's OWN largest magnitude (no floor: a sub-unit tensor is not judged absolutely).
+    E_ref(family) is the largest relative fp32 error of the reference over the quantities of one family (slot outputs,
+    architecture gradients, parameter gradients, ...): everything downstream of a ReLU mask is discontinuous in the
+    pre-activations - one within an ulp of zero is clipped by one fp32 implementation and not by another, and which
+    tensor that lands in is arbitrary (measured: the reference is 1.2e-4 off on the second DARTS iteration's architecture
+    gradients and 8e-7 on the first's; the HIP path the other way round).  That licence is limited twice: the bound is
+    capped at the bar, and at most ONE member of a family may cost more than ``factor`` times what the reference's own
+    fp32 result costs on that very tensor (a flipped mask shows up in one place; a systematically coarser kernel shows
+    up everywhere).  ``atol`` = 4e-6 (64 ulp of the tensor's magnitude) covers the hardware exp2 / log2 approximations
+    and the fixed summation order of the reductions.  Checks are collected; ``finish()`` fails with the full list
+    (RISP_BUDGET_REPORT=1 prints every measured pair with its ratio)."""
 
-    def __init__(self, factor=2.0, atol=4e-6):
-        self.factor, self.atol, self.rows = factor, atol, []
+    def __init__(self, factor=2.0, atol=4e-6, bar=1e-4, outliers=1):
+        self.factor, self.atol, self.bar, self.outliers, self.rows = factor, atol, bar, outliers, []
 
     def __call__(self, got, ref32, ref64, what='', family=None):
         import torch
@@ -76,20 +80,30 @@ class ErrorBudget:
         assert got.shape == ref64.shape == ref32.shape, '%s shapes %s %s %s' % (what, got.shape, ref32.shape, ref64.shape)
         if not got.size:
             return
-        scale = max(1.0, np.abs(ref64).max())
+        scale = np.abs(ref64).max() or 1.0
         self.rows.append((what, np.abs(got - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale, family or what))
 
     def finish(self):
-        fam = {}
+        fam, over = {}, {}
         for _, _, e_ref, family in self.rows:
             fam[family] = max(fam.get(family, 0.0), e_ref)
         bad = []
         for what, e_got, e_ref, family in self.rows:
-            ok = e_got <= self.factor * fam[family] + self.atol
+            bound = min(self.factor * fam[family], self.bar) + self.atol
+            ok = e_got <= bound
+            own = e_got <= self.factor * e_ref + self.atol
+            if not own:
+                over.setdefault(family, []).append(what)
             if os.environ.get('RISP_BUDGET_REPORT') == '1':
-                print('BUDGET %-40s hip %.2e  ref32 %.2e  family %-12s %.2e %s' % (what, e_got, e_ref, family, fam[family],
-                                                                                  '' if ok else '  <-- OVER'))
+                print('BUDGET %-40s hip %.2e  ref32 %.2e  ratio %6.2f  family %-12s %.2e %s%s' % (
+                    what, e_got, e_ref, e_got / max(e_ref, 1e-30), family, fam[family], '' if ok else '  <-- OVER',
+                    '' if own else '  (over its own reference)'))
             if not ok:
-                bad.append('%s: |hip - fp64| = %.3e of scale; reference fp32: %.3e (family %s: %.3e)' % (
+                bad.append('%s: |hip - fp64| = %.3e of the tensor\'s magnitude; reference fp32: %.3e (family %s: %.3e)' % (
                     what, e_got, e_ref, family, fam[family]))
-        assert not bad, 'over the fp32 error budget (%.1f x reference + %.1e):\n  ' % (self.factor, self.atol) + '\n  '.join(bad)
+        for family, members in over.items():
+            if len(members) > self.outliers:
+                bad.append('family %s: %d members cost more than %.1f x their own reference error (at most %d may): %s' % (
+                    family, len(members), self.factor, self.outliers, ', '.join(members)))
+        assert not bad, 'over the fp32 error budget (min(%.1f x reference, %.0e) + %.1e):\n  ' % (
+            self.factor, self.bar, self.atol) + '\n  '.join(bad)

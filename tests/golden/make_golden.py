@@ -583,7 +583,67 @@ def gold_f64():
     npz('isp_model_f64', **out)
 
 
+# ---------------------------------------------------------------- 11. local/global and latency losses (utils/util_loss.py:8-64)
+def gold_losses():
+    """The reference's local_global_loss / latency_loss on mixed, all-local and all-global flags (value + gradient of the
+    image), and one DartsModel iteration with pixel_criterion 'local_global_l2' fed the 6-tuple batch
+    (models/darts_model.py:131-133, 149-167)."""
+    import utils.util_loss as UL
+    import models.darts_model as DM
+    from collections import OrderedDict
+    mse = nn.MSELoss()
+    out = {}
+    a0, b = rnd(4, 3, 16, 16, seed=70) * 0.8 + 0.1, rnd(4, 3, 16, 16, seed=71)
+    out['lg_in'], out['lg_gt'] = a0, b
+    for tag, flags in (('mixed', [0, 1, 0, 2]), ('local', [0, 0, 0, 0]), ('global', [1, 1, 1, 1])):
+        a = a0.clone().requires_grad_(True)
+        f = torch.tensor(flags, dtype=torch.int64)
+        loss = UL.local_global_loss(a, b, f, mse)
+        g, = torch.autograd.grad(loss, a)
+        out['lg_%s_flags' % tag], out['lg_%s_loss' % tag], out['lg_%s_grad' % tag] = f, loss.detach(), g
+    # an image darker than half the target: the gain clamps at 2 (and a negative-mean image: clamp(mean, 0) + 1e-6)
+    a = torch.cat([a0[:1] * 0.1, -a0[1:2]]).requires_grad_(True)
+    f = torch.zeros(2, dtype=torch.int64)
+    loss = UL.local_global_loss(a, b[:2], f, mse)
+    out['lg_clamp_in'], out['lg_clamp_loss'] = a.detach().clone(), loss.detach()
+    out['lg_clamp_grad'], = torch.autograd.grad(loss, a)
+    a = a0.clone().requires_grad_(True)
+    lat = torch.tensor(3.7, requires_grad=True)
+    loss, term = UL.latency_loss(a, b, lat, target_latency=2.5, w=0.07, fidelity_loss=mse)
+    ga, gl = torch.autograd.grad(loss, (a, lat))
+    out.update(lat_latency=lat.detach(), lat_loss=loss.detach(), lat_term=term.detach(), lat_grad=ga, lat_grad_latency=gl)
+
+    opt = OrderedDict(model='darts', gpu_ids=None, dist=False, is_train=True,
+                      network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=2,
+                                     n_modules=15, prune_threshold=0.2),
+                      path=dict(pretrain_model_G=None, strict_load=True),
+                      train=dict(lr_G=1e-2, momentum_G=0.9, lr_meta=1e-2, beta1=0.9, beta2=0.99,
+                                 pixel_criterion='local_global_l2', lr_scheme='MultiStepLR', lr_steps=[1000],
+                                 restarts=None, restart_weights=None, lr_gamma=0.5, clear_state=False))
+    model = DM.DartsModel(opt)
+    for net in (model.netG, model.netV):
+        seed_supernet(net, 1000)
+        with torch.no_grad():
+            net.alpha_demosaic[3] = -20.0
+    img, gt = rnd(2, 1, 16, 16, seed=40), rnd(2, 3, 16, 16, seed=41)
+    vimg, vgt = rnd(2, 1, 16, 16, seed=42), rnd(2, 3, 16, 16, seed=43)
+    flag, vflag = torch.tensor([0, 1], dtype=torch.int64), torch.tensor([1, 0], dtype=torch.int64)
+    out.update(d_img=img, d_gt=gt, d_flag=flag, d_val_img=vimg, d_val_gt=vgt, d_val_flag=vflag)
+    model.feed_data((img, gt, flag, vimg, vgt, vflag))
+    model.update_learning_rate(0, warmup_iter=-1)
+    model.optimize_alphas()
+    out['d_val_loss'] = model.val_loss.detach().clone()
+    for k, a in enumerate(model.netG.alphas):
+        out['d_alpha_grad%d' % k] = a.grad.clone()
+    model.optimize_parameters()
+    out['d_loss'] = np.array(model.log_dict['loss'], np.float32)
+    for k, v in model.netG.state_dict().items():
+        out['d_' + k] = v.detach().clone()
+    npz('losses', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls', 'f64']
+    which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls',
+                             'f64', 'losses']
     for w in which:
         globals()['gold_' + w]()
