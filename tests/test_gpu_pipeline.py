@@ -126,12 +126,16 @@ def test_reference_yaml_pipeline_matches_oracle():
     ref, rmids = O.fixed_pipeline(bay, names, [torch.tensor(O.PARAM_INIT[k]) for k in names], wts)
     with torch.no_grad():
         y = net(bay.cuda())
-    for a, b, k in zip(net.intermediate_results, rmids, names):
-        # CASCADED comparison: each stage inherits the previous stages' fp32 differences, and random-weight CNN outputs
-        # fall on gamma's steep toe (slope 32 below 1/1024), which amplifies them - 5e-4 of the stage's magnitude here.
-        # The precise statement about this pipeline is the per-stage fp64 error budget,
-        # tests/test_gpu_error_budget.py::test_reference_yaml_cnn_pipeline_within_budget (every stage from the same input)
-        assert_close(a, b, floor=1.0, rtol=5e-4, what='stage ' + k)
+    # Stage by stage at the 1e-4 bar: every stage of the oracle starts from the GPU's previous stage output, so a stage is
+    # judged on its own arithmetic (a cascaded comparison inherits upstream fp32 noise, which gamma's toe - slope 32
+    # below 1/1024 - amplifies: that end-to-end statement is the PSNR check below and the fp64 error budget,
+    # tests/test_gpu_error_budget.py::test_reference_yaml_cnn_pipeline_within_budget)
+    x = bay
+    for k, (name, got) in enumerate(zip(names, net.intermediate_results)):
+        par = None if not O.PARAM_INIT[name] else torch.sigmoid(torch.tensor(O.PARAM_INIT[name])).repeat(2, 1)
+        assert_close(got, O.apply_op(name, x, par, wts[k]), floor=1.0, rtol=1e-4, what='stage ' + name)
+        x = got.detach().cpu()
+    assert len(rmids) == len(net.intermediate_results)
     from reconfigisp_amd.codes.utils import util
     d = util.psnr_tensors(y, ref.cuda())
     assert d > 80, 'PSNR(build vs oracle) = %.1f dB' % d

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import isp_oracle as O
-from conftest import assert_close as _assert_close, load_golden
+from conftest import assert_close as _assert_close, load_golden, ref_rtol
 
 
 def assert_close(a, b, **kw):
@@ -56,7 +56,7 @@ def build_supernet(n_step, dev):
 
 
 def test_supernet_matches_reference(dev):
-    g = load_golden('supernet_n2')
+    g, g64 = load_golden('supernet_n2'), load_golden('supernet_n2_f64')
     net = build_supernet(2, dev)
     assert list(net.state_dict().keys()) == list(g['state_keys'])
     assert len(net.trainable_parameters) == int(g['n_trainable'])
@@ -72,7 +72,7 @@ def test_supernet_matches_reference(dev):
     grads = torch.autograd.grad(y, [named[k] for k in keys], T(g['gy']).to(dev), allow_unused=True)
     for k, gr in zip(keys, grads):
         gr = torch.zeros_like(named[k]) if gr is None else gr
-        assert_close(gr, g['g_' + k], rtol=2e-4, what='grad ' + k)
+        assert_close(gr, g['g_' + k], rtol=ref_rtol(g, g64, 'g_' + k), what='grad ' + k)
 
 
 def test_origin_universal_matches_reference(dev):
@@ -159,7 +159,7 @@ def seed_darts(model):
 @pytest.mark.filterwarnings('ignore:Detected call of')
 def test_darts_search_step_matches_reference(dev):
     from reconfigisp_amd.codes.models import create_model
-    g = load_golden('darts_step')
+    g, g64 = load_golden('darts_step'), load_golden('darts_step_f64')
     model = create_model(darts_opt(dev))
     seed_darts(model)
     data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
@@ -167,15 +167,27 @@ def test_darts_search_step_matches_reference(dev):
         model.feed_data(data)
         model.update_learning_rate(it, warmup_iter=-1)
         model.optimize_alphas()
-        assert_close(model.val_loss, g['it%d_val_loss' % it], rtol=2e-4, what='val loss')
+        assert_close(model.val_loss, g['it%d_val_loss' % it], rtol=1e-4, what='val loss')
         for k, a in enumerate(model.netG.alphas):
-            # fp32 vs fp32: both sides carry up to ~1.2e-4 of fp32 error on these (tests/test_gpu_error_budget.py measures
-            # each against float64); 5e-4 of the gradient's magnitude bounds their sum
-            assert_close(a.grad, g['it%d_alpha_grad%d' % (it, k)], rtol=5e-4, atol=1e-7, what='alpha grad %d' % k)
+            # fp32 vs the reference's fp32: the 1e-4 bar plus the golden's OWN distance from the float64 evaluation of the
+            # reference (up to 7.1e-5 of the gradient's magnitude, tests/golden/darts_step_f64.npz) - conftest.ref_rtol
+            key = 'it%d_alpha_grad%d' % (it, k)
+            assert_close(a.grad, g[key], rtol=ref_rtol(g, g64, key), atol=1e-7, what='alpha grad %d' % k)
         model.optimize_parameters()
-        assert abs(model.log_dict['loss'] - float(g['it%d_loss' % it])) <= 2e-4 * abs(float(g['it%d_loss' % it]))
+        assert abs(model.log_dict['loss'] - float(g['it%d_loss' % it])) <= 1e-4 * abs(float(g['it%d_loss' % it]))
         for k, v in model.netG.state_dict().items():
-            assert_close(v, g['it%d_%s' % (it, k)], rtol=1e-3, atol=1e-6, what='it%d %s' % (it, k))
+            # (the reference's fp32 state is up to 3.7e-4 off its own float64 evaluation on the near-zero parameters)
+            key = 'it%d_%s' % (it, k)
+            if k == 'alpha_demosaic':
+                # DemosaicNet has no implementation in this build (the plugin's weights are not distributed): its
+                # probability is exactly 0 and its logit receives NO gradient, where the reference's e^-20 softmax tail
+                # hands Adam a 1e-8 gradient that it turns into a 5e-3 move.  A documented difference, not a tolerance:
+                # the masked logit stays where it was, the three live ones are compared like everything else.
+                assert v[3].item() == -20.0
+                live = {key: g[key][:3]}, {key: g64[key][:3]}
+                assert_close(v[:3], g[key][:3], rtol=ref_rtol(live[0], live[1], key), atol=1e-6, what=key)
+                continue
+            assert_close(v, g[key], rtol=ref_rtol(g, g64, key), atol=1e-6, what=key)
 
 
 @pytest.mark.filterwarnings('ignore:Detected call of')
@@ -348,10 +360,16 @@ def test_darts_iteration_with_local_global_loss_and_six_tuple_batch(dev):
     model.optimize_alphas()
     assert_close(model.val_loss, g['d_val_loss'], rtol=2e-4, what='val loss')
     for k, a in enumerate(model.netG.alphas):
-        assert_close(a.grad, g['d_alpha_grad%d' % k], rtol=5e-4, atol=1e-7, what='alpha grad %d' % k)
+        assert_close(a.grad, g['d_alpha_grad%d' % k], rtol=2e-4, atol=1e-7, what='alpha grad %d' % k)
     model.optimize_parameters()
     assert abs(model.log_dict['loss'] - float(g['d_loss'])) <= 2e-4 * abs(float(g['d_loss']))
     for k, v in model.netG.state_dict().items():
-        assert_close(v, g['d_' + k], rtol=1e-3, atol=1e-6, what=k)
+        if k == 'alpha_demosaic':                 # the masked DemosaicNet logit: see test_darts_search_step_matches_reference
+            assert v[3].item() == -20.0
+            v, ref = v[:3], g['d_' + k][:3]
+        else:
+            ref = g['d_' + k]
+        # (no float64 evaluation of this case: the bar plus the 3.7e-4 the reference's own fp32 state is off in darts_step)
+        assert_close(v, ref, rtol=5e-4, atol=1e-6, what=k)
     with pytest.raises(ValueError, match='Invalid data format'):
         model.feed_data((1, 2, 3))
