@@ -99,9 +99,13 @@ class DartsModel(BaseModel):
             tensors = list(self.netG.parameters())
             for m in ops(self.netG):
                 tensors += list(m.parameters()) + list(m.buffers())
-            for t in tensors:
-                if t.numel():
-                    dist.broadcast(t.data, src=0)
+            with torch.no_grad():
+                for t in tensors:
+                    if t.numel():
+                        dist.broadcast(t, src=0)          # on the tensor itself: the in-place write bumps its version
+            for net in (self.netG, self.netV):
+                if hasattr(net, 'invalidate_weight_cache'):
+                    net.invalidate_weight_cache()
         with torch.no_grad():
             for g, v in zip(ops(self.netG), ops(self.netV)):
                 v.load_state_dict(g.state_dict())

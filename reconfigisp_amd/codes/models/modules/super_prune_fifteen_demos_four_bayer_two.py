@@ -70,6 +70,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         # ops and zero-size placeholders are kept in plain lists (only alphas / param_step* are
         # registered, as in the reference); make them follow .to()/.cuda() all the same
         super()._apply(fn, *args, **kwargs)
+        self._weight_cache.clear()
         for mods in self.all_modules:
             for m in mods:
                 m._apply(fn, *args, **kwargs)
@@ -78,6 +79,14 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                 if p.numel() == 0:
                     p.data = fn(p.data)
         return self
+
+    def load_state_dict(self, *args, **kwargs):
+        self._weight_cache.clear()             # keyed on alpha._version, which copy_ bumps - and writes through .data do not
+        return super().load_state_dict(*args, **kwargs)
+
+    def invalidate_weight_cache(self):
+        """call after writing an alpha through ``.data`` (no version bump): the host copy of the mixture weights is stale"""
+        self._weight_cache.clear()
 
     def _unavailable(self, mods, device):
         """uint8 mask of ops that cannot run in this build (DemosaicNet without a registered implementation): they are

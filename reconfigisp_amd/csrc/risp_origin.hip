@@ -661,7 +661,11 @@ size_t tile_lds(int C, int R) { return sizeof(float) * C * (TX + 2 * R) * (TY + 
 dim3 tile4_grid(int N, int H, int W) { return dim3((W + QX - 1) / QX, (H + QY - 1) / QY, N); }
 size_t tile4_lds(int C, int R) { return sizeof(float) * C * tile4_tw(R) * (QY + 2 * R); }
 // the 4-pixels-per-thread form: 16-byte stores (rows and the output base 16-byte aligned) and an LDS tile within the 64 KB default
-bool tile4_ok(const float *y, int W, int R) { return W % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && tile4_lds(3, R) <= 64 * 1024; }
+// the 4-pixel kernels read the input and write the output in 16-byte vectors: BOTH pointers must be aligned (a contiguous
+// view with a storage offset that is not a multiple of 4 floats takes the general kernels)
+bool tile4_ok(const float *x, const float *y, int W, int R) {
+    return W % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && tile4_lds(3, R) <= 64 * 1024;
+}
 
 }  // namespace
 
@@ -671,7 +675,7 @@ int risp_origin_demosaic(const float *bayer, float *bgr, int laplacian, int N, i
                          float out_div, void *stream) {
     RISP_CHECK_ARG(bayer && bgr && N > 0 && N <= 65535 && H >= 4 && W >= 4 && H % 2 == 0 && W % 2 == 0,
                    "risp_origin_demosaic: bad arguments (N=%d H=%d W=%d)", N, H, W);
-    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 15) == 0) {
+    if (W % 4 == 0 && ((reinterpret_cast<uintptr_t>(bgr) | reinterpret_cast<uintptr_t>(bayer)) & 15) == 0) {
         if (laplacian)
             hipLaunchKernelGGL(demosaic4_kernel<true>, tile4_grid(N, H, W), dim3(256), tile4_lds(1, 2), (hipStream_t)stream, bayer, bgr, H,
                                W, in_scale, out_div);
@@ -695,7 +699,7 @@ int risp_origin_bilateral(const float *x, float *y, const int32_t *window, const
                        max_window <= 17 && (max_window & 1) && H > max_window / 2 && W > max_window / 2,
                    "risp_origin_bilateral: bad arguments (window %d, H=%d W=%d)", max_window, H, W);
     const int R = max_window / 2;
-    if (tile4_ok(y, W, R)) {
+    if (tile4_ok(x, y, W, R)) {
         if (R == 1)
             hipLaunchKernelGGL(bilateral4_kernel<1>, tile4_grid(N, H, W), dim3(256), tile4_lds(3, R), (hipStream_t)stream, x, y,
                                window, sigma_color, sigma_space, H, W, R, in_scale, out_div);
@@ -717,11 +721,11 @@ int risp_origin_median(const float *x, float *y, int size, int N, int H, int W, 
     RISP_CHECK_ARG(x && y && N > 0 && N <= 65535 && size >= 1 && size <= 17 && (size & 1) && H > size / 2 && W > size / 2,
                    "risp_origin_median: bad arguments (size %d, H=%d W=%d)", size, H, W);
     auto med_lds = [](int k) { return sizeof(unsigned) * 3 * (QY + 2 * (k / 2)) * ((QX + (k <= 9 ? 8 : 16)) / 4); };
-    const bool t4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const bool t4 = W % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
 #define RISP_MEDIAN4(KK)                                                                                                      \
     hipLaunchKernelGGL(median4_kernel<KK>, tile4_grid(N, H, W), dim3(256), med_lds(KK), (hipStream_t)stream, x, y, H, W, in_scale, \
                        out_div)
-    if (size == 3 && tile4_ok(y, W, 1))
+    if (size == 3 && tile4_ok(x, y, W, 1))
         hipLaunchKernelGGL(median3x4_kernel, tile4_grid(N, H, W), dim3(256), tile4_lds(3, 1), (hipStream_t)stream, x, y, H, W,
                            in_scale, out_div);
     else if (size == 5 && t4) RISP_MEDIAN4(5);
@@ -747,7 +751,7 @@ int risp_origin_fastnlm(const float *x, float *y, const int32_t *block_size, con
                        max_block <= 17 && max_search >= 1 && max_search <= 17 && H > R && W > R,
                    "risp_origin_fastnlm: bad arguments (block %d search %d, H=%d W=%d)", max_block, max_search, H, W);
     RISP_CHECK_ARG(tile_lds(3, R) <= 64 * 1024, "risp_origin_fastnlm: window too large for the LDS tile");
-    if (tile4_ok(y, W, R)) {
+    if (tile4_ok(x, y, W, R)) {
         if (R == 2)
             hipLaunchKernelGGL(fastnlm4_kernel<true>, tile4_grid(N, H, W), dim3(256), tile4_lds(3, R), (hipStream_t)stream, x, y,
                                block_size, search_block, decay, H, W, R, in_scale, out_div);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void histc_kernel(const float *__restrict__ x,
             atomicAdd(&sh[pos * copies + cp], 1u);
         }
     };
-    if ((hw & 3) == 0) {
+    if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {          // 16-byte loads need an aligned plane base
         const float4 *x4 = reinterpret_cast<const float4 *>(xb);
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw / 4; i += gridDim.x * blockDim.x) {
             const float4 v = x4[i];

@@ -286,3 +286,40 @@ def test_tile_forms_give_identical_bits(hw, form):
         for size in (3, 5, 7, 9, 13, 17):
             if size // 2 < min(h, w):
                 both(lambda y: L.call('risp_origin_median', p(x), p(y), size, n, h, w, 1.0, 1.0, None), x.shape)
+
+
+def test_unaligned_input_views_take_the_general_kernels():
+    """The 4-pixel forms read the INPUT in 16-byte vectors too: a contiguous view whose storage offset is not a multiple
+    of 4 floats (aligned output) must give the bits of the aligned call - every classical stencil and the histogram."""
+    import ctypes as C
+    from reconfigisp_amd import lib as L
+    n, h, w = 2, 40, 72
+    dev = torch.device('cuda')
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def shifted(t):
+        buf = torch.zeros(t.numel() + 4, device=dev)
+        v = buf[1:1 + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4 and v.is_contiguous()
+        return v
+
+    x = (rnd(n, 3, h, w, seed=93) * 255).to(dev)
+    bay = (rnd(n, 1, h, w, seed=94) * 255).to(dev)
+    win = torch.tensor([3, 3], dtype=torch.int32, device=dev)
+    sc, ss = torch.tensor([50.5, 12.0], device=dev), torch.tensor([50.5, 1.5], device=dev)
+    dec = torch.tensor([50.5, 8.0], device=dev)
+    calls = [
+        (x, lambda s, y: L.call('risp_origin_bilateral', p(s), p(y), p(win), p(sc), p(ss), 3, n, h, w, 1.0, 1.0, None), x.shape),
+        (x, lambda s, y: L.call('risp_origin_fastnlm', p(s), p(y), p(win), p(win), p(dec), 3, 3, n, h, w, 1.0, 1.0, None), x.shape),
+        (x, lambda s, y: L.call('risp_origin_median', p(s), p(y), 3, n, h, w, 1.0, 1.0, None), x.shape),
+        (x, lambda s, y: L.call('risp_origin_median', p(s), p(y), 9, n, h, w, 1.0, 1.0, None), x.shape),
+        (bay, lambda s, y: L.call('risp_origin_demosaic', p(s), p(y), 1, n, h, w, 1.0, 1.0, None), (n, 3, h, w)),
+        (x / 255, lambda s, y: L.call('risp_histc', p(s), p(y), n * 3, h * w, 32, None), (n * 3, 32)),
+    ]
+    for src, call, shape in calls:
+        src = src.contiguous()
+        a, b = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+        call(src, a)
+        call(shifted(src), b)
+        assert torch.equal(a, b)
