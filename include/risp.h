@@ -149,6 +149,31 @@ size_t risp_mix_scratch_floats(void);
 int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *gy,
                  float *const *go, float *gw, float *scratch, size_t numel, void *stream);
 
+/* The mixture of a slot with its ELEMENT-WISE operators computed on the fly: operand k of y = sum_k w[k] o_k is either a
+ * materialised (N,3,H,W) tensor (kind RISP_SLOT_TENSOR, ptr = the tensor: the CNN proxies) or o_k = op(x, params) for
+ * kind RISP_OP_SKIP / WB_MANUAL / GAMMA / GTM_MANUAL / WB_QUADRATIC / GAIN3 (ptr = the (N,P) parameter block; at most one
+ * operand of each kind) evaluated in registers from the slot input x: x is read once and the operators' outputs never
+ * touch HBM.  pmul[k] multiplies a WB_MANUAL block on the way in (the wrapper's params * 5, tools_origin.py:214) and its
+ * gradient on the way out.  y is bit-identical to running the operators one by one and risp_mix_fwd.
+ * Backward: gw (K) = <gy, o_k>; go[k] (tensor operands, may be NULL) = w[k] gy; gx = sum over the element-wise operands
+ * (operand order) of their input gradients at upstream w[k] gy (NULL allowed only when there is none); gp[k] = (N,P)
+ * parameter-gradient block of operand k (GTM_MANUAL: whole batch in row 0), fully written, may be NULL.  Deterministic. */
+#define RISP_SLOT_TENSOR (-1)
+#define RISP_SLOT_ROW (RISP_MAX_MIX + 40)
+typedef struct risp_slot_mix_desc {
+    int K, N, HW;
+    int kind[RISP_MAX_MIX];
+    float w[RISP_MAX_MIX], pmul[RISP_MAX_MIX];
+    const float *ptr[RISP_MAX_MIX];
+    float *go[RISP_MAX_MIX];                      /* backward */
+    float *gp[RISP_MAX_MIX];                      /* backward */
+    const float *x;
+    float *y;                                     /* forward */
+} risp_slot_mix_desc;
+int risp_slot_mix_fwd(const risp_slot_mix_desc *d, void *stream);
+size_t risp_slot_mix_scratch_floats(int N, int HW);
+int risp_slot_mix_bwd(const risp_slot_mix_desc *d, const float *gy, float *gx, float *gw, float *scratch, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Convolution layers of the learned proxies on fp32 MFMA
  * (srcnn_res_arch.py:15-24, srcnn_demosaic_arch.py:14-25, path_14l_*_arch.py:6-57).

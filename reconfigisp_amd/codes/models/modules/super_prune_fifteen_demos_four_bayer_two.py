@@ -21,6 +21,10 @@ from . import tools_proxy as TP
 
 
 # HIP streams the ops of a slot are spread over when the batch is small (1 = off), and what "small" means
+FUSE_SLOT = os.environ.get('RISP_FUSE_SLOT', '1') != '0'     # element-wise operators evaluated inside the mixture kernel
+# module class -> name of the element-wise operator in functional.SLOT_KINDS
+_POINTWISE = {T.Skip: 'skip', T.WbManual: 'wb_manual', T.Gamma: 'gamma', T.GtmManual: 'gtm_manual', T.WbQuadratic: 'wb_quadratic',
+              T.Grayworld: 'grayworld'}
 SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '2'))
 SLOT_STREAMS_MAX_PIXELS = int(os.environ.get('RISP_SLOT_STREAMS_MAX_PIXELS', str(1 << 40)))
 
@@ -135,13 +139,13 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         mod.__dict__['_risp_reuse'] = rec
         return rec
 
-    def _jobs(self, slot, mods, index, args, x, token=None):
+    def _jobs(self, slot, mods, index, args, x, token=None, skip=()):
         """The surviving ops of a slot as launch jobs [(positions in `index`, callable -> list of outputs)].  Same-geometry
         proxies - the SRCNNRes family of an sRGB slot (:35-52), the two proxy demosaics - form ONE job that runs every layer
         as a single grouped launch (convnets.srcnn_res_group); everything else is a job of its own.  Heavy jobs come first
         so that the round-robin over the streams puts the group and Path-Restore on different ones."""
         families = ((TP.ProxyNet, 'res'), (TP.ProxyDemosaicNet, 'demosaic'))
-        jobs, taken = [], set()
+        jobs, taken = [], set(skip)               # `skip`: positions the fused mixture evaluates itself
         cache = self.__dict__.setdefault('_group_cache', {}).setdefault(slot, {})
         for cls, kind in families:
             pos = [i for i, k in enumerate(index) if isinstance(mods[k], cls)]
@@ -232,12 +236,24 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                     live_pars.append(par)
             blocks = iter(F.param_blocks(live_pars, n))  # sigmoid(par).repeat(n, 1) of every surviving op: one launch
             args = [next(blocks) if pars[k].nelement() > 0 else None for k in index]
-            jobs = self._jobs(slot, mods, index, args, x, token)
+            # element-wise operators (gamma, white balances, tone curve, gray world, skip: :195-210) are not run at all -
+            # the mixture kernel evaluates them from the slot input in registers (F.slot_mix)
+            fused = {}
+            if FUSE_SLOT and x.dim() == 4 and x.shape[1] == 3:
+                names = {i: _POINTWISE[type(mods[k])] for i, k in enumerate(index) if type(mods[k]) in _POINTWISE}
+                if len(names) >= 1 and F.can_fuse_slot(x, list(names.values())):
+                    fused = names
+            jobs = self._jobs(slot, mods, index, args, x, token, skip=set(fused))
             if token is not None:       # value token of this slot's output
                 token = (token, slot, alpha.data_ptr(), alpha._version, tuple((p.data_ptr(), p._version) for p in live_pars))
             outs = self._run_jobs(jobs, len(index), x, args)
             sel = post if len(index) == len(weights) else post[index]
-            y = F.mix(sel, outs, w_host=[weights[k] for k in index], stacks=[pos for pos, _ in jobs if len(pos) > 1])
+            stacks = [pos for pos, _ in jobs if len(pos) > 1]
+            if fused:
+                entries = [('op', fused[i], args[i]) if i in fused else ('tensor', outs[i]) for i in range(len(index))]
+                y = F.slot_mix(sel, x, entries, w_host=[weights[k] for k in index], stacks=stacks)
+            else:
+                y = F.mix(sel, outs, w_host=[weights[k] for k in index], stacks=stacks)
             if pruned_pars:
                 y = F.attach_zero_grad(y, pruned_pars)
             self.middle_results.append(y)

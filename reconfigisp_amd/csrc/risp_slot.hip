@@ -16,6 +16,7 @@
 // Every per-member value is computed by the expression sequence of the per-operator kernels (risp_reduce.hip,
 // risp_conv_small.hip), so a grouped launch and G single launches give the same bits.
 #include "risp_common.h"
+#include "risp_ops.h"
 
 namespace {
 
@@ -112,6 +113,283 @@ int check_group(const risp_srcnn_group_desc *d, const char *who, bool fwd) {
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The mixture of a slot with its ELEMENT-WISE operators computed on the fly (super_prune_fifteen_demos_four_bayer_two.py:
+// 195-210; tools_origin.py:53-73 gamma, 205-225 manual white balance, 27-45 gray world, 256-262 skip, 317-359
+// WbQuadratic, 414-440 GtmManual).  Operand k of  y = sum_k w_k o_k  is either a materialised tensor (the CNN
+// proxies) or one of those operators applied to the slot input x in registers: x is read once, y written once, and
+// the five or six 12 B/pixel tensors the operators would write - and the mixture re-read - never exist.
+// Per operand the value is ctx.fwd(x) of risp_ops.h, i.e. the bits the stand-alone kernel stores, and the sum runs in
+// operand order with separate multiply and add like mix_fwd_kernel: y is bit-identical to the unfused slot.
+using namespace risp_ops;
+
+template <bool WBQ>
+__device__ __forceinline__ void slot_contexts(const risp_slot_mix_desc &d, int n, WbManualCtx &wm, GammaCtx &ga, GtmCtx &gt,
+                                              WbqCtx &wq, float (&g3)[3]) {
+    for (int k = 0; k < d.K; ++k) {
+        const float *p = d.ptr[k];
+        switch (d.kind[k]) {
+            case RISP_OP_WB_MANUAL:
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wm.k[c] = p[n * 3 + c] * d.pmul[k];      // gain = params * 5, tools_origin.py:214
+                break;
+            case RISP_OP_GAMMA: ga = GammaCtx(p, n); break;
+            case RISP_OP_GTM_MANUAL: gt = GtmCtx(p, n); break;
+            case RISP_OP_WB_QUADRATIC:
+                if constexpr (WBQ) wq = WbqCtx(p, n);
+                break;
+            case RISP_OP_GAIN3:
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g3[c] = p[n * 3 + c];
+                break;
+            default: break;
+        }
+    }
+}
+
+__device__ __forceinline__ f3 gain3_fwd(const float (&k)[3], f3 v) { return {clamp01(v.b * k[0]), clamp01(v.g * k[1]), clamp01(v.r * k[2])}; }
+__device__ __forceinline__ f3 gain3_bwd(const float (&k)[3], f3 x, f3 g, float *acc) {
+    g.b *= gate01(x.b * k[0]);
+    g.g *= gate01(x.g * k[1]);
+    g.r *= gate01(x.r * k[2]);
+    acc[0] += g.b * x.b;
+    acc[1] += g.g * x.g;
+    acc[2] += g.r * x.r;
+    return {g.b * k[0], g.g * k[1], g.r * k[2]};
+}
+
+template <bool WBQ>
+__global__ __launch_bounds__(256) void slot_mix_fwd_kernel(const risp_slot_mix_desc d, int hw4) {
+    const int n = blockIdx.y;
+    WbManualCtx wm; GammaCtx ga; GtmCtx gt; WbqCtx wq; float g3[3] = {0.f, 0.f, 0.f};
+    slot_contexts<WBQ>(d, n, wm, ga, gt, wq, g3);
+    const size_t base = (size_t)n * 3 * hw4;
+    const float4 *xb = reinterpret_cast<const float4 *>(d.x) + base;
+    float4 *yb = reinterpret_cast<float4 *>(d.y) + base;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
+        const float4 b = xb[i], g = xb[hw4 + i], r = xb[2 * hw4 + i];
+        const f3 px[4] = {{b.x, g.x, r.x}, {b.y, g.y, r.y}, {b.z, g.z, r.z}, {b.w, g.w, r.w}};
+        f3 s[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        for (int k = 0; k < d.K; ++k) {
+            const float w = d.w[k];
+            f3 o[4];
+            if (d.kind[k] == RISP_SLOT_TENSOR) {
+                const float4 *ob = reinterpret_cast<const float4 *>(d.ptr[k]) + base;
+                const float4 vb = ob[i], vg = ob[hw4 + i], vr = ob[2 * hw4 + i];
+                o[0] = {vb.x, vg.x, vr.x}; o[1] = {vb.y, vg.y, vr.y}; o[2] = {vb.z, vg.z, vr.z}; o[3] = {vb.w, vg.w, vr.w};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    switch (d.kind[k]) {
+                        case RISP_OP_WB_MANUAL: o[q] = wm.fwd(px[q]); break;
+                        case RISP_OP_GAMMA: o[q] = ga.fwd(px[q]); break;
+                        case RISP_OP_GTM_MANUAL: o[q] = gt.fwd(px[q]); break;
+                        case RISP_OP_WB_QUADRATIC:
+                            if constexpr (WBQ) o[q] = wq.fwd(px[q]); else o[q] = px[q];
+                            break;
+                        case RISP_OP_GAIN3: o[q] = gain3_fwd(g3, px[q]); break;
+                        default: o[q] = px[q]; break;                  // RISP_OP_SKIP
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[q].b += o[q].b * w;
+                s[q].g += o[q].g * w;
+                s[q].r += o[q].r * w;
+            }
+        }
+        yb[i] = make_float4(s[0].b, s[1].b, s[2].b, s[3].b);
+        yb[hw4 + i] = make_float4(s[0].g, s[1].g, s[2].g, s[3].g);
+        yb[2 * hw4 + i] = make_float4(s[0].r, s[1].r, s[2].r, s[3].r);
+    }
+}
+
+// Backward of the same: per operand the architecture term <gy, o_k>; tensors receive go_k = w_k gy; the element-wise
+// operators' input gradients ctx.bwd(x, w_k gy) are added in operand order into ONE gx; their parameter gradients are
+// reduced registers -> lanes -> waves -> one row of RISP_SLOT_ROW floats per workgroup, which slot_mix_finish_kernel adds
+// in index order (bit-repeatable; the block partition is that of the stand-alone backward kernels, so the parameter
+// gradients are the bits they produce).  Row layout: [K architecture terms | wb 3 | gamma 1 | gtm 3 | wbq 30 | gain 3].
+constexpr int SO_WM = RISP_MAX_MIX, SO_GA = SO_WM + 3, SO_GT = SO_GA + 1, SO_WQ = SO_GT + 3, SO_G3 = SO_WQ + 30;
+static_assert(SO_G3 + 3 == RISP_SLOT_ROW, "row layout");
+
+template <bool WBQ>
+__global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy,
+                                                           float *__restrict__ gx, float *__restrict__ part, int hw4) {
+    constexpr int NACC = WBQ ? RISP_SLOT_ROW : RISP_SLOT_ROW - 33;       // without WbQuadratic its 30 slots are not carried
+    constexpr int G3 = WBQ ? SO_G3 : SO_WQ;
+    __shared__ float red[RISP_SLOT_ROW * 4];
+    const int n = blockIdx.y;
+    WbManualCtx wm; GammaCtx ga; GtmCtx gt; WbqCtx wq; float g3[3] = {0.f, 0.f, 0.f};
+    slot_contexts<WBQ>(d, n, wm, ga, gt, wq, g3);
+    // operand index of each element-wise kind (-1: absent); the element-wise input gradients are added in KIND order
+    // (skip, white balance, gamma, tone curve, quadratic, gray-world gain) - a fixed order, whatever the operand order
+    int at[RISP_OP_GAIN3 + 1];
+#pragma unroll
+    for (int q = 0; q <= RISP_OP_GAIN3; ++q) at[q] = -1;
+    for (int k = 0; k < d.K; ++k)
+        if (d.kind[k] != RISP_SLOT_TENSOR) {
+#pragma unroll
+            for (int q = 0; q <= RISP_OP_GAIN3; ++q)
+                if (d.kind[k] == q) at[q] = k;
+        }
+    const size_t base = (size_t)n * 3 * hw4;
+    const float4 *xb = reinterpret_cast<const float4 *>(d.x) + base;
+    const float4 *gb = reinterpret_cast<const float4 *>(gy) + base;
+    float4 *ob = gx ? reinterpret_cast<float4 *>(gx) + base : nullptr;
+    float acc[NACC];              // [0, RISP_MAX_MIX): architecture terms by operand; then the parameter-gradient slots
+    float dotk[RISP_OP_GAIN3 + 1];   // architecture terms of the element-wise operands, by kind
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q <= RISP_OP_GAIN3; ++q) dotk[q] = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
+        const float4 db = gb[i], dg = gb[hw4 + i], dr = gb[2 * hw4 + i];
+        // ---- tensor operands: architecture term, and their gradient w_k gy
+#pragma unroll
+        for (int k = 0; k < RISP_MAX_MIX; ++k) {
+            if (k < d.K && d.kind[k] == RISP_SLOT_TENSOR) {
+                const float w = d.w[k];
+                const float4 *tb = reinterpret_cast<const float4 *>(d.ptr[k]) + base;
+                const float4 vb = tb[i], vg = tb[hw4 + i], vr = tb[2 * hw4 + i];
+                acc[k] += ((db.x * vb.x + db.y * vb.y) + (db.z * vb.z + db.w * vb.w)) +
+                          ((dg.x * vg.x + dg.y * vg.y) + (dg.z * vg.z + dg.w * vg.w)) +
+                          ((dr.x * vr.x + dr.y * vr.y) + (dr.z * vr.z + dr.w * vr.w));
+                if (d.go[k]) {
+                    float4 *gk = reinterpret_cast<float4 *>(d.go[k]) + base;
+                    gk[i] = make_float4(db.x * w, db.y * w, db.z * w, db.w * w);
+                    gk[hw4 + i] = make_float4(dg.x * w, dg.y * w, dg.z * w, dg.w * w);
+                    gk[2 * hw4 + i] = make_float4(dr.x * w, dr.y * w, dr.z * w, dr.w * w);
+                }
+            }
+        }
+        if (!ob) continue;                            // no element-wise operand
+        // ---- element-wise operands, kind by kind, pixel by pixel (straight-line code: few live values)
+        const float4 b = xb[i], g = xb[hw4 + i], r = xb[2 * hw4 + i];
+        const float pb[4] = {b.x, b.y, b.z, b.w}, pg[4] = {g.x, g.y, g.z, g.w}, pr[4] = {r.x, r.y, r.z, r.w};
+        const float qb[4] = {db.x, db.y, db.z, db.w}, qg[4] = {dg.x, dg.y, dg.z, dg.w}, qr[4] = {dr.x, dr.y, dr.z, dr.w};
+        float ob_[4], og_[4], or_[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f3 px = {pb[q], pg[q], pr[q]}, gq = {qb[q], qg[q], qr[q]};
+            f3 sx = {0.f, 0.f, 0.f};
+            bool first = true;
+            auto term = [&](int kind, f3 o, f3 t) {
+                dotk[kind] += (gq.b * o.b + gq.g * o.g) + gq.r * o.r;
+                if (first) sx = t;
+                else { sx.b += t.b; sx.g += t.g; sx.r += t.r; }
+                first = false;
+            };
+            auto up = [&](int kind) { const float w = d.w[at[kind]]; return f3{gq.b * w, gq.g * w, gq.r * w}; };
+            if (at[RISP_OP_SKIP] >= 0) term(RISP_OP_SKIP, px, up(RISP_OP_SKIP));
+            if (at[RISP_OP_WB_MANUAL] >= 0) term(RISP_OP_WB_MANUAL, wm.fwd(px), wm.bwd(px, up(RISP_OP_WB_MANUAL), acc + SO_WM));
+            if (at[RISP_OP_GAMMA] >= 0) term(RISP_OP_GAMMA, ga.fwd(px), ga.bwd(px, up(RISP_OP_GAMMA), acc + SO_GA));
+            if (at[RISP_OP_GTM_MANUAL] >= 0) term(RISP_OP_GTM_MANUAL, gt.fwd(px), gt.bwd(px, up(RISP_OP_GTM_MANUAL), acc + SO_GT));
+            if constexpr (WBQ) {
+                if (at[RISP_OP_WB_QUADRATIC] >= 0)
+                    term(RISP_OP_WB_QUADRATIC, wq.fwd(px), wq.bwd(px, up(RISP_OP_WB_QUADRATIC), acc + SO_WQ));
+            }
+            if (at[RISP_OP_GAIN3] >= 0) term(RISP_OP_GAIN3, gain3_fwd(g3, px), gain3_bwd(g3, px, up(RISP_OP_GAIN3), acc + G3));
+            ob_[q] = sx.b; og_[q] = sx.g; or_[q] = sx.r;
+        }
+        ob[i] = make_float4(ob_[0], ob_[1], ob_[2], ob_[3]);
+        ob[hw4 + i] = make_float4(og_[0], og_[1], og_[2], og_[3]);
+        ob[2 * hw4 + i] = make_float4(or_[0], or_[1], or_[2], or_[3]);
+    }
+    // the element-wise operands' architecture terms go to their operand's slot (wave-uniform scatter, unrolled compare)
+#pragma unroll
+    for (int q = 0; q <= RISP_OP_GAIN3; ++q) {
+#pragma unroll
+        for (int k = 0; k < RISP_MAX_MIX; ++k)
+            if (at[q] == k) acc[k] = dotk[q];
+    }
+    block_sum<NACC>(acc, red);
+    if (threadIdx.x == 0) {
+        float *row = part + ((size_t)n * gridDim.x + blockIdx.x) * RISP_SLOT_ROW;
+#pragma unroll
+        for (int j = 0; j < SO_WQ; ++j) row[j] = acc[j];
+        if constexpr (WBQ) {
+#pragma unroll
+            for (int j = 0; j < 30; ++j) row[SO_WQ + j] = acc[SO_WQ + j] * 10.f;       // WbqCtx::pscale
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) row[SO_G3 + j] = acc[G3 + j];
+    }
+}
+
+// one wave per output element; lane l adds the partial rows l, l + 64, ... in index order, a fixed shuffle tree adds the lanes.
+// Elements: K architecture terms (all rows), then per element-wise operand its (N, P) parameter-gradient block: the
+// image's own bx rows (GtmManual: every row into image 0, zeros elsewhere - its knots come from params[0] only).
+__global__ __launch_bounds__(256) void slot_mix_finish_kernel(const risp_slot_mix_desc d, const float *__restrict__ part,
+                                                              float *__restrict__ gw, int N, int bx) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int e = t;
+    if (e < d.K) {
+        float s = 0.f;
+        for (int i = lane; i < N * bx; i += 64) s += part[(size_t)i * RISP_SLOT_ROW + e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) gw[e] = s;
+        return;
+    }
+    e -= d.K;
+    for (int k = 0; k < d.K; ++k) {
+        int np = 0, off = 0;
+        switch (d.kind[k]) {
+            case RISP_OP_WB_MANUAL: np = 3; off = SO_WM; break;
+            case RISP_OP_GAMMA: np = 1; off = SO_GA; break;
+            case RISP_OP_GTM_MANUAL: np = 3; off = SO_GT; break;
+            case RISP_OP_WB_QUADRATIC: np = 30; off = SO_WQ; break;
+            case RISP_OP_GAIN3: np = 3; off = SO_G3; break;
+            default: break;
+        }
+        if (np == 0 || !d.gp[k]) continue;
+        if (e < N * np) {
+            const int row = e / np, j = e - row * np;
+            const bool whole = d.kind[k] == RISP_OP_GTM_MANUAL;
+            float s = 0.f;
+            if (!whole || row == 0) {
+                const int lo = whole ? 0 : row * bx, hi = whole ? N * bx : (row + 1) * bx;
+                for (int i = lo + lane; i < hi; i += 64) s += part[(size_t)i * RISP_SLOT_ROW + off + j];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) d.gp[k][e] = d.kind[k] == RISP_OP_WB_MANUAL ? s * d.pmul[k] : s;
+            return;
+        }
+        e -= N * np;
+    }
+}
+
+int check_slot(const risp_slot_mix_desc *d, const char *who, bool &wbq, bool &pointwise) {
+    RISP_CHECK_ARG(d && d->K >= 1 && d->K <= RISP_MAX_MIX && d->N >= 1 && d->N <= 65535 && d->HW > 0 && d->HW % 4 == 0 && d->y,
+                   "%s: bad descriptor", who);
+    int seen = 0;
+    wbq = pointwise = false;
+    for (int k = 0; k < d->K; ++k) {
+        const int kind = d->kind[k];
+        RISP_CHECK_ARG(kind == RISP_SLOT_TENSOR || (kind >= RISP_OP_SKIP && kind <= RISP_OP_GAIN3 && kind != RISP_OP_DEMOSAIC_NEAREST),
+                       "%s: operand %d: kind %d", who, k, kind);
+        RISP_CHECK_ARG(kind == RISP_OP_SKIP || d->ptr[k], "%s: operand %d: null pointer", who, k);
+        RISP_CHECK_ARG(kind != RISP_SLOT_TENSOR ? true : (reinterpret_cast<uintptr_t>(d->ptr[k]) & 15) == 0, "%s: operand %d unaligned", who, k);
+        if (kind != RISP_SLOT_TENSOR) {
+            RISP_CHECK_ARG(!(seen & (1 << kind)), "%s: two element-wise operands of kind %d (at most one each)", who, kind);
+            seen |= 1 << kind;
+            pointwise = true;
+            wbq |= kind == RISP_OP_WB_QUADRATIC;
+        }
+    }
+    RISP_CHECK_ARG(!pointwise || d->x, "%s: element-wise operands need the slot input x", who);
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->y)) & 15) == 0, "%s: unaligned x / y", who);
+    return 0;
+}
+
+int slot_bwd_blocks(int HW) {
+    int bx = (HW / 4 + 1023) / 1024;               // the block partition of risp_pointwise.hip::launch_bwd
+    return bx < 1 ? 1 : (bx > 32 ? 32 : bx);
+}
+
 }  // namespace
 
 extern "C" {
@@ -147,6 +425,39 @@ int risp_group_sum(const float *stack, float *out, int G, int N, int C, int HW, 
     hipLaunchKernelGGL(group_sum_kernel, dim3(bx, N * C), dim3(256), 0, (hipStream_t)stream, stack, out, G, N * C, HW / 4, gstats,
                        row, C, arg, 1.0f / (float)HW);
     RISP_LAUNCH_CHECK("risp_group_sum");
+    return 0;
+}
+
+size_t risp_slot_mix_scratch_floats(int N, int HW) { return (size_t)N * slot_bwd_blocks(HW) * RISP_SLOT_ROW; }
+
+int risp_slot_mix_fwd(const risp_slot_mix_desc *d, void *stream) {
+    bool wbq, pw;
+    if (check_slot(d, "risp_slot_mix_fwd", wbq, pw)) return 1;
+    const int hw4 = d->HW / 4;
+    int bx = (hw4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (wbq) hipLaunchKernelGGL(slot_mix_fwd_kernel<true>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, hw4);
+    else hipLaunchKernelGGL(slot_mix_fwd_kernel<false>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, hw4);
+    RISP_LAUNCH_CHECK("risp_slot_mix_fwd");
+    return 0;
+}
+
+int risp_slot_mix_bwd(const risp_slot_mix_desc *d, const float *gy, float *gx, float *gw, float *scratch, void *stream) {
+    bool wbq, pw;
+    if (check_slot(d, "risp_slot_mix_bwd", wbq, pw)) return 1;
+    RISP_CHECK_ARG(gy && gw && scratch && (gx || !pw) && ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0,
+                   "risp_slot_mix_bwd: null or unaligned argument");
+    const int hw4 = d->HW / 4, bx = slot_bwd_blocks(d->HW);
+    if (wbq) hipLaunchKernelGGL(slot_mix_bwd_kernel<true>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
+    else hipLaunchKernelGGL(slot_mix_bwd_kernel<false>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
+    int elems = d->K;
+    for (int k = 0; k < d->K; ++k) {
+        const int np = d->kind[k] == RISP_OP_WB_MANUAL || d->kind[k] == RISP_OP_GTM_MANUAL || d->kind[k] == RISP_OP_GAIN3 ? 3 :
+                       d->kind[k] == RISP_OP_GAMMA ? 1 : d->kind[k] == RISP_OP_WB_QUADRATIC ? 30 : 0;
+        if (np && d->gp[k]) elems += d->N * np;
+    }
+    hipLaunchKernelGGL(slot_mix_finish_kernel, dim3((elems + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, scratch, gw, d->N, bx);
+    RISP_LAUNCH_CHECK("risp_slot_mix_bwd");
     return 0;
 }
 

@@ -239,6 +239,106 @@ class _Mix(torch.autograd.Function):
         return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]), None, None) + tuple(gos)
 
 
+SLOT_KINDS = {'skip': OP_SKIP, 'wb_manual': OP_WB_MANUAL, 'gamma': OP_GAMMA, 'gtm_manual': OP_GTM_MANUAL,
+              'wb_quadratic': OP_WB_QUADRATIC, 'grayworld': OP_GAIN3}
+_SLOT_WIDTH = {OP_WB_MANUAL: 3, OP_GAMMA: 1, OP_GTM_MANUAL: 3, OP_WB_QUADRATIC: 30}
+
+
+class _SlotMix(torch.autograd.Function):
+    """y = sum_k w[k] o_k of one super-net slot with the element-wise operators evaluated on the fly (risp_slot_mix_fwd /
+    _bwd): operand k is a materialised tensor (kinds[k] == L.SLOT_TENSOR) or op(x, block) for an element-wise kind.
+    ``flat``: per operand the tensor / the (N,P) parameter block / nothing (skip, gray world)."""
+
+    @staticmethod
+    def forward(ctx, w, w_host, x, kinds, stacks, *flat):
+        x = _dev(x, 'img')
+        _check_bgr(x)
+        n, hw = x.shape[0], x.shape[2] * x.shape[3]
+        k = len(kinds)
+        w_host = [float(v) for v in (w_host if w_host is not None else w.detach().cpu().tolist())]
+        if len(w_host) != k or w.numel() != k or k > L.MIX_MAX:
+            raise ValueError('slot_mix: %d weights for %d operands (at most %d)' % (len(w_host), k, L.MIX_MAX))
+        d = L.SlotMixDesc()
+        d.K, d.N, d.HW = k, n, hw
+        keep, it, stats = [], iter(flat), None
+        for i, kind in enumerate(kinds):
+            d.kind[i], d.w[i], d.pmul[i] = kind, w_host[i], 1.0
+            if kind == L.SLOT_TENSOR:
+                t = _dev(next(it))
+                if t.shape != x.shape:
+                    raise ValueError('slot_mix: operand %d has shape %s, the slot input %s' % (i, tuple(t.shape), tuple(x.shape)))
+            elif kind == OP_SKIP:
+                t = None
+            elif kind == OP_GAIN3:                   # gray world: gains from the statistics of x (no parameters)
+                stats, _ = channel_stats(x, want_arg=False)
+                t = torch.empty((n, 3), device=x.device, dtype=torch.float32)
+                L.call('risp_grayworld_gains_fwd', _p(stats), _p(t), n, hw, _stream())
+            else:
+                t = _dev(next(it), 'params')
+                _check_params(t, n, _SLOT_WIDTH[kind], 'slot operand %d' % i)
+                if kind == OP_WB_MANUAL:
+                    d.pmul[i] = 5.0                   # the wrapper's params * 5 (tools_origin.py:214)
+            keep.append(t)
+            d.ptr[i] = t.data_ptr() if t is not None else None
+        y = torch.empty_like(x)
+        d.x, d.y = x.data_ptr(), y.data_ptr()
+        L.call('risp_slot_mix_fwd', C.byref(d), _stream())
+        ctx.save_for_backward(x, stats, *[t for t in keep if t is not None])
+        ctx.kinds, ctx.w_host, ctx.stacks, ctx.w_meta = tuple(kinds), w_host, stacks, (w.device, w.dtype)
+        ctx.has = [t is not None for t in keep]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, *rest = ctx.saved_tensors
+        kinds, k = ctx.kinds, len(ctx.kinds)
+        gy = _dev(gy, 'grad')
+        n, hw = x.shape[0], x.shape[2] * x.shape[3]
+        it = iter(rest)
+        keep = [next(it) if h else None for h in ctx.has]
+        dev = dict(device=gy.device, dtype=torch.float32)
+        d = L.SlotMixDesc()
+        d.K, d.N, d.HW = k, n, hw
+        d.x = x.data_ptr()
+        # gradient buffers: tensor operands of one grouped launch share a stacked buffer (convnets._stack_grads)
+        go = [None] * k
+        for members in (ctx.stacks or ()):
+            if all(kinds[i] == L.SLOT_TENSOR for i in members):
+                buf = torch.empty((len(members),) + tuple(x.shape), **dev)
+                for j, i in enumerate(members):
+                    go[i] = buf[j]
+        gp = [None] * k
+        pointwise = False
+        for i, kind in enumerate(kinds):
+            d.kind[i], d.w[i], d.pmul[i] = kind, ctx.w_host[i], 5.0 if kind == OP_WB_MANUAL else 1.0
+            d.ptr[i] = keep[i].data_ptr() if keep[i] is not None else None
+            if kind == L.SLOT_TENSOR:
+                if go[i] is None:
+                    go[i] = torch.empty_like(x)
+                d.go[i] = go[i].data_ptr()
+            else:
+                pointwise = True
+                if kind != OP_SKIP:
+                    gp[i] = torch.empty_like(keep[i])
+                    d.gp[i] = gp[i].data_ptr()
+        gx = torch.empty_like(x) if pointwise else None
+        gw = torch.empty(k, **dev)
+        scratch = torch.empty(L.load().risp_slot_mix_scratch_floats(n, hw), **dev)
+        L.call('risp_slot_mix_bwd', C.byref(d), _p(gy), _p(gx), _p(gw), _p(scratch), _stream())
+        for i, kind in enumerate(kinds):
+            if kind == OP_GAIN3:                     # gray world: the gains' gradient flows back through the channel means
+                gm = torch.empty((n, 3), **dev)
+                L.call('risp_grayworld_gains_bwd', _p(stats), _p(gp[i]), _p(gm), n, hw, _stream())
+                L.call('risp_stats_bwd', _p(gx), None, _p(gm), None, None, n * 3, hw, _stream())
+        grads = []
+        for i, kind in enumerate(kinds):
+            if kind == L.SLOT_TENSOR:
+                grads.append(go[i])
+            elif kind not in (OP_SKIP, OP_GAIN3):
+                grads.append(gp[i])
+        return (gw.to(device=ctx.w_meta[0], dtype=ctx.w_meta[1]), None, gx, None, None) + tuple(grads)
+
+
 class _PruneSoftmax(torch.autograd.Function):
     """post = pruned, renormalised softmax(alpha) of one super-net slot (risp_prune_softmax_fwd / _bwd)."""
 
@@ -433,6 +533,25 @@ class _HipImpl:
         return _Mix.apply(w, w_host, stacks, *outs)
 
     @staticmethod
+    def slot_mix(w, x, entries, w_host=None, stacks=None):
+        kinds, flat = [], []
+        for e in entries:
+            if e[0] == 'tensor':
+                kinds.append(L.SLOT_TENSOR)
+                flat.append(e[1])
+            else:
+                kinds.append(SLOT_KINDS[e[1]])
+                if e[1] not in ('skip', 'grayworld'):
+                    flat.append(e[2])
+        return _SlotMix.apply(w, w_host, x, tuple(kinds), stacks, *flat)
+
+    @staticmethod
+    def can_fuse_slot(x, names):
+        """element-wise operands can be evaluated inside the mixture kernel: BGR input, 16-byte planes, one of each kind"""
+        return (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and (x.shape[2] * x.shape[3]) % 4 == 0 and
+                x.data_ptr() % 16 == 0 and len(set(names)) == len(names) and all(nm in SLOT_KINDS for nm in names))
+
+    @staticmethod
     def prune_softmax(alpha, threshold, unavailable=None):
         return _PruneSoftmax.apply(alpha, threshold, unavailable)
 
@@ -565,6 +684,17 @@ def mix(w, outs, w_host=None, stacks=None):
     ``stacks``: lists of operand positions whose gradients should come back as consecutive slices of one buffer (the
     members of a grouped launch read them in place)."""
     return _IMPL.mix(w, outs, w_host, stacks)
+
+
+def slot_mix(w, x, entries, w_host=None, stacks=None):
+    """The mixture of a slot with its element-wise operators evaluated on the fly.  entries[k] = ('tensor', o_k) for a
+    materialised operand or ('op', name, block) with name in SLOT_KINDS and block the (N,P) parameter block the operator
+    module would receive (None for skip / grayworld).  Same value as running the modules and ``mix``."""
+    return _IMPL.slot_mix(w, x, entries, w_host, stacks)
+
+
+def can_fuse_slot(x, names):
+    return _IMPL.can_fuse_slot(x, names)
 
 
 def prune_softmax(alpha, threshold, unavailable=None):

@@ -60,6 +60,16 @@ class ParamBlocksDesc(C.Structure):
                 ('gstride', _i * PARAM_OPS_MAX)]
 
 
+MIX_MAX = 16
+SLOT_TENSOR = -1
+
+
+class SlotMixDesc(C.Structure):
+    """mirror of risp_slot_mix_desc"""
+    _fields_ = [('K', _i), ('N', _i), ('HW', _i), ('kind', _i * MIX_MAX), ('w', _fl * MIX_MAX), ('pmul', _fl * MIX_MAX),
+                ('ptr', _f * MIX_MAX), ('go', _f * MIX_MAX), ('gp', _f * MIX_MAX), ('x', _f), ('y', _f)]
+
+
 def _pw(n_extra=0):
     # forward: (x, p, y, N, HW, stream); backward (n_extra = 3): (x, p, gy, gx, gp, scratch, N, HW, stream)
     return [_f] * (3 + n_extra) + [_i, _i, _s]
@@ -89,6 +99,9 @@ SIGNATURES = {
     'risp_mix_fwd': (_i, [_pp, C.POINTER(C.c_float), _i, _f, _z, _s]),
     'risp_mix_scratch_floats': (_z, []),
     'risp_mix_bwd': (_i, [_pp, C.POINTER(C.c_float), _i, _f, _pp, _f, _f, _z, _s]),
+    'risp_slot_mix_fwd': (_i, [C.POINTER(SlotMixDesc), _s]),
+    'risp_slot_mix_scratch_floats': (_z, [_i, _i]),
+    'risp_slot_mix_bwd': (_i, [C.POINTER(SlotMixDesc), _f, _f, _f, _f, _s]),
     'risp_param_grad_scratch_floats': (_z, [_i]),
     'risp_conv_wpack_floats': (_z, [_i, _i, _i]),
     'risp_conv_pack_weights': (_i, [_f, _i, _i, _i, _i, _f, _s]),

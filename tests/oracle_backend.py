@@ -26,6 +26,17 @@ class OracleImpl:
     srcnn_res_group = staticmethod(lambda x, pvs, ms, cache: [OracleImpl.srcnn_res(x, pv, m) for pv, m in zip(pvs, ms)])
     srcnn_demosaic_group = staticmethod(lambda x, ms, cache, record=None: [OracleImpl.srcnn_demosaic(x, m) for m in ms])
 
+    can_fuse_slot = staticmethod(lambda x, names: x.dim() == 4 and x.shape[1] == 3 and len(set(names)) == len(names))
+
+    @staticmethod
+    def slot_mix(w, x, entries, w_host=None, stacks=None):
+        # the fused slot kernel is a traffic matter of the HIP path; on the seam: the operators one by one, then the mixture
+        ops = {'skip': lambda p: x, 'wb_manual': lambda p: OracleImpl.wb_manual(x, p * 5), 'gamma': lambda p: O.gamma_manual(x, p),
+               'gtm_manual': lambda p: O.gtm_manual(x, p), 'wb_quadratic': lambda p: O.wb_quadratic(x, p),
+               'grayworld': lambda p: O.grayworld(x)}
+        outs = [e[1] if e[0] == 'tensor' else ops[e[1]](e[2]) for e in entries]
+        return OracleImpl.mix(w, outs)
+
     @staticmethod
     def mix(w, outs, w_host=None, stacks=None):
         y = 0
