@@ -217,7 +217,7 @@ static_assert(SO_G3 + 3 == RISP_SLOT_ROW, "row layout");
 template <bool WBQ>
 __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy,
                                                            float *__restrict__ gx, float *__restrict__ part, int hw4) {
-    constexpr int NACC = WBQ ? RISP_SLOT_ROW : RISP_SLOT_ROW - 33;       // without WbQuadratic its 30 slots are not carried
+    constexpr int NACC = WBQ ? RISP_SLOT_ROW : RISP_SLOT_ROW - 30;       // without WbQuadratic its 30 slots are not carried
     constexpr int G3 = WBQ ? SO_G3 : SO_WQ;
     __shared__ float red[RISP_SLOT_ROW * 4];
     const int n = blockIdx.y;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void slot_mix_finish_kernel(const risp_slot_mi
 }
 
 int check_slot(const risp_slot_mix_desc *d, const char *who, bool &wbq, bool &pointwise) {
-    RISP_CHECK_ARG(d && d->K >= 1 && d->K <= RISP_MAX_MIX && d->N >= 1 && d->N <= 65535 && d->HW > 0 && d->HW % 4 == 0 && d->y,
+    RISP_CHECK_ARG(d && d->K >= 1 && d->K <= RISP_MAX_MIX && d->N >= 1 && d->N <= 65535 && d->HW > 0 && d->HW % 4 == 0,
                    "%s: bad descriptor", who);
     int seen = 0;
     wbq = pointwise = false;
@@ -433,6 +433,7 @@ size_t risp_slot_mix_scratch_floats(int N, int HW) { return (size_t)N * slot_bwd
 int risp_slot_mix_fwd(const risp_slot_mix_desc *d, void *stream) {
     bool wbq, pw;
     if (check_slot(d, "risp_slot_mix_fwd", wbq, pw)) return 1;
+    RISP_CHECK_ARG(d->y, "risp_slot_mix_fwd: null output");
     const int hw4 = d->HW / 4;
     int bx = (hw4 + 255) / 256;
     if (bx > 64) bx = 64;
