@@ -208,6 +208,19 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             main.wait_stream(s)
         return outs
 
+    def _select(self, post, index, k):
+        """post[index] for the surviving ops.  A leading run is a view; anything else goes through index_select with a
+        cached device index (indexing with a Python list uploads the list on every call and sorts in its backward)."""
+        if len(index) == k:
+            return post
+        if index == list(range(len(index))):
+            return post[:len(index)]
+        cache = self.__dict__.setdefault('_index_cache', {})
+        key = (tuple(index), str(post.device))
+        if key not in cache:
+            cache[key] = torch.tensor(index, dtype=torch.long, device=post.device)
+        return post.index_select(0, cache[key])
+
     def forward(self, x):
         n = x.size(0)
         self.middle_results = []
@@ -247,7 +260,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             if token is not None:       # value token of this slot's output
                 token = (token, slot, alpha.data_ptr(), alpha._version, tuple((p.data_ptr(), p._version) for p in live_pars))
             outs = self._run_jobs(jobs, len(index), x, args)
-            sel = post if len(index) == len(weights) else post[index]
+            sel = self._select(post, index, len(weights))
             stacks = [pos for pos, _ in jobs if len(pos) > 1]
             if fused:
                 entries = [('op', fused[i], args[i]) if i in fused else ('tensor', outs[i]) for i in range(len(index))]

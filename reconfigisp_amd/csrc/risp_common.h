@@ -95,6 +95,21 @@ __device__ __forceinline__ void lds_dma16(const float *src, float *dst_wave_base
                  : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(src), "s"(lds_dst), "s"(mask) : "memory");
 }
 
+// Workgroups per image of the element-wise BACKWARD kernels (stand-alone risp_*_bwd and the fused slot mixture share it, so
+// both cut an image into the same partial sums and give the same parameter-gradient bits): >= 4 vectors per thread so the
+// block reduction amortises, but enough workgroups for the chip when the batch is small (the per-GPU batch of the 8-GPU
+// search is 4 images: 16 per image were 64 workgroups on 256 CUs).
+inline int risp_bwd_blocks(int N, int HW) {
+    const int hw4 = HW / 4;
+    int bx = (hw4 + 1023) / 1024;
+    const int want = (512 + N - 1) / (N > 0 ? N : 1);          // ~512 workgroups in flight
+    if (bx < want) bx = want;
+    const int most = (hw4 + 255) / 256;                        // at least one vector per thread
+    if (bx > most) bx = most;
+    if (bx > 64) bx = 64;
+    return bx < 1 ? 1 : bx;
+}
+
 struct f3 {
     float b, g, r;
 };

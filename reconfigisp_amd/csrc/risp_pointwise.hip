@@ -102,10 +102,7 @@ template <class Ctx>
 int launch_bwd(const char *name, const float *x, const float *p, const float *gy, float *gx, float *gp, float *scratch,
                int N, int HW, void *stream) {
     RISP_CHECK_ARG(x && p && gy && gx && gp && scratch && N > 0 && HW > 0 && HW % 4 == 0, "%s: bad arguments", name);
-    const int hw4 = HW / 4;
-    int bx = (hw4 + 1023) / 1024;  // >= 4 vectors per thread so the reduction amortises
-    if (bx < 1) bx = 1;
-    if (bx > 32) bx = 32;
+    const int hw4 = HW / 4, bx = risp_bwd_blocks(N, HW);
     hipLaunchKernelGGL(bgr_bwd_kernel<Ctx>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, p, gy, gx, scratch, hw4);
     const int rows = N;                                // gp is (N, NP): rows no image maps to (GtmManual: all but row 0) get 0
     hipLaunchKernelGGL(param_finish_kernel<Ctx>, dim3((rows * Ctx::NP + 3) / 4), dim3(256), 0, (hipStream_t)stream, scratch,
@@ -293,7 +290,7 @@ int risp_gain3_bwd(const float *x, const float *k, const float *gy, float *gx, f
     return launch_bwd<Gain3Ctx>("risp_gain3_bwd", x, k, gy, gx, gk, scratch, N, HW, s);
 }
 
-size_t risp_param_grad_scratch_floats(int N) { return (size_t)(N > 0 ? N : 0) * 32 * 30; }
+size_t risp_param_grad_scratch_floats(int N) { return (size_t)(N > 0 ? N : 0) * 64 * 30; }     // risp_bwd_blocks <= 64 rows of <= 30
 
 static int chain_launch(const ChainArgs &a, void *stream) {
     const bool wide = (a.W % 4 == 0);

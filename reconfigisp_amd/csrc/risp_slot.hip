@@ -385,11 +385,6 @@ int check_slot(const risp_slot_mix_desc *d, const char *who, bool &wbq, bool &po
     return 0;
 }
 
-int slot_bwd_blocks(int HW) {
-    int bx = (HW / 4 + 1023) / 1024;               // the block partition of risp_pointwise.hip::launch_bwd
-    return bx < 1 ? 1 : (bx > 32 ? 32 : bx);
-}
-
 }  // namespace
 
 extern "C" {
@@ -428,7 +423,7 @@ int risp_group_sum(const float *stack, float *out, int G, int N, int C, int HW, 
     return 0;
 }
 
-size_t risp_slot_mix_scratch_floats(int N, int HW) { return (size_t)N * slot_bwd_blocks(HW) * RISP_SLOT_ROW; }
+size_t risp_slot_mix_scratch_floats(int N, int HW) { return (size_t)N * risp_bwd_blocks(N, HW) * RISP_SLOT_ROW; }
 
 int risp_slot_mix_fwd(const risp_slot_mix_desc *d, void *stream) {
     bool wbq, pw;
@@ -448,7 +443,7 @@ int risp_slot_mix_bwd(const risp_slot_mix_desc *d, const float *gy, float *gx, f
     if (check_slot(d, "risp_slot_mix_bwd", wbq, pw)) return 1;
     RISP_CHECK_ARG(gy && gw && scratch && (gx || !pw) && ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0,
                    "risp_slot_mix_bwd: null or unaligned argument");
-    const int hw4 = d->HW / 4, bx = slot_bwd_blocks(d->HW);
+    const int hw4 = d->HW / 4, bx = risp_bwd_blocks(d->N, d->HW);
     if (wbq) hipLaunchKernelGGL(slot_mix_bwd_kernel<true>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
     else hipLaunchKernelGGL(slot_mix_bwd_kernel<false>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
     int elems = d->K;
