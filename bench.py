@@ -207,7 +207,10 @@ def cpu_baseline(bay, arch, point_s=3.0, min_iters=10):
 
     def rate(threads, seconds, min_reps):
         torch.set_num_threads(threads)
-        run()
+        t0 = time.perf_counter()
+        run()                                           # warm-up repetition, also the guard below
+        if time.perf_counter() - t0 > 4 * seconds:      # pathological point (hundreds of threads on small ops): one rep is the rate
+            return 1, time.perf_counter() - t0
         reps, t0 = 0, time.perf_counter()
         while reps < min_reps or time.perf_counter() - t0 < seconds:
             run()
@@ -220,6 +223,8 @@ def cpu_baseline(bay, arch, point_s=3.0, min_iters=10):
         for th in points:
             reps, dt = rate(th, point_s, 1)
             sweep[th] = reps / dt
+            if sweep[th] < 0.5 * max(sweep.values()):   # past the knee: more threads only oversubscribe these small ops
+                break
         best = max(sweep, key=sweep.get)
         reps, dt = rate(best, point_s, min_iters)
     pix = n * bay.shape[2] * bay.shape[3]
