@@ -18,11 +18,12 @@ __device__ __forceinline__ void lds_dma16(const float *src, float *dst_wave_base
                  : "=&s"(keep_m0) : "v"(src), "s"(lds_dst) : "memory");
 }
 
-template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false>
-__global__ __launch_bounds__(256, 3) void stages(const float *__restrict__ src, float *__restrict__ dst, float *out, int tiles,
+template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24>
+__global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restrict__ src, float *__restrict__ dst, float *out, int tiles,
                                                  float seed) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // 2 stages x 6144 floats (24 KB each)
-    for (int i = threadIdx.x; i < 12288; i += 256) {
+    constexpr int STG = PIECES * 256;                 // floats per LDS stage
+    for (int i = threadIdx.x; i < 2 * STG; i += 64 * NW) {
         unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
         lds[i] = (float)(int)h * (1.0f / 2147483648.0f) * seed;
@@ -37,14 +38,14 @@ __global__ __launch_bounds__(256, 3) void stages(const float *__restrict__ src, 
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
         const float *gsrc = src + ((size_t)(blockIdx.x * tiles + tile) % (L2SRC ? 4 : 4096)) * 16 * 6144;   // L2SRC: 1.5 MB, cache resident
         for (int ch = 0; ch < 16; ++ch) {
-            const float *cur = lds + (ch & 1) * 6144;
+            const float *cur = lds + (ch & 1) * STG;
             if (BAR) __syncthreads();
             if (DMA) {                                   // the next chunk's tile + weight slab: 24 x 1 KB, 6 per wave
-                float *nxt = lds + ((ch + 1) & 1) * 6144;
+                float *nxt = lds + ((ch + 1) & 1) * STG;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const int id = wave * 6 + j;
-                    lds_dma16(gsrc + (size_t)((ch + 1) & 15) * 6144 + id * 256 + lane * 4, nxt + id * 256);
+                for (int j = 0; j < (PIECES + NW - 1) / NW; ++j) {
+                    const int id = wave + NW * j;
+                    if (id < PIECES) lds_dma16(gsrc + (size_t)((ch + 1) & 15) * 6144 + (id % 24) * 256 + lane * 4, nxt + id * 256);
                 }
             }
             if (TRF == 2) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 3) void stages(const float *__restrict__ src, 
             if (DMA) __builtin_amdgcn_s_waitcnt(0x0070);
         }
         if (EPI) {                                       // 4 rows x 128 pixels x 32 couts: 64 KB per workgroup, 16-byte stores
-            float *o = dst + ((size_t)(blockIdx.x * tiles + tile) % 8192) * 16384 + wave * 4096;
+            float *o = dst + ((size_t)(blockIdx.x * tiles + tile) % 2048) * 65536 + wave * 4096;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -116,23 +117,24 @@ __global__ __launch_bounds__(256, 3) void stages(const float *__restrict__ src, 
     }
 }
 
-template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false>
+template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24>
 void run(const char *what, const float *src, float *dst, float *out) {
-    const int blocks = 256 * 3 * 2, tiles = 48;
+    const int blocks = 256 * (12 / NW) * 2, tiles = 48;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((stages<BAR, DMA, TRF, EPI, L2SRC>), dim3(blocks), dim3(256), 2 * 6144 * 4, 0, src, dst, out, tiles, 1.0f);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&stages<BAR, DMA, TRF, EPI, L2SRC, NW, PIECES>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PIECES * 1024);
+        hipLaunchKernelGGL((stages<BAR, DMA, TRF, EPI, L2SRC, NW, PIECES>), dim3(blocks), dim3(64 * NW), 2 * PIECES * 1024, 0, src, dst, out, tiles, 1.0f);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
     }
-    const double flops = (double)blocks * 4 * tiles * 16 * 36 * (32.0 * 32 * 2 * 2);
+    const double flops = (double)blocks * NW * tiles * 16 * 36 * (32.0 * 32 * 2 * 2);
     printf("%-52s %8.3f ms  %7.1f TFLOP/s  (%.3f of 157.3)\n", what, best, flops / best / 1e9, flops / best / 1e9 / 157.3);
 }
 
@@ -153,5 +155,10 @@ int main() {
     run<true, true, 1, true>("+ barrier + LDS-DMA + transform + store epilogue", src, dst, out);
     run<true, true, 2, true>("+ barrier + LDS-DMA + packed transform + epilogue", src, dst, out);
     run<false, false, 0, true>("matrix stream + store epilogue", src, dst, out);
+    // one 12-wave workgroup per CU instead of three 4-wave ones: a 12-row tile and ONE weight slab = 40 pieces per chunk
+    run<true, true, 1, true, false, 12, 40>("12-wave workgroup, 40 pieces / chunk, everything", src, dst, out);
+    run<true, true, 1, false, false, 12, 40>("12-wave workgroup, 40 pieces / chunk, no epilogue", src, dst, out);
+    run<true, true, 1, true, false, 8, 31>("8-wave workgroup (both cout blocks), 31 pieces, everything", src, dst, out);
+    run<true, true, 1, true, false, 4, 12>("4-wave workgroup, 12 pieces / chunk (half the staging), everything", src, dst, out);
     return 0;
 }
