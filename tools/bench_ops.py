@@ -21,7 +21,7 @@ ones = lambda v: torch.full((n,), float(v)).cuda()
 
 
 REPS = int(os.environ.get('RISP_OPS_REPS', '0'))   # short runs for a rocprofv3 kernel trace (tools/profile_ops.sh)
-ONLY = os.environ.get('RISP_OPS_ONLY', '')
+ONLY = os.environ.get('RISP_OPS_ONLY', '')               # run only the cases whose name contains this
 
 
 def timed(fn, reps=100):
@@ -97,3 +97,28 @@ def mixb(k):
     y = F.mix(wm, oo[k % 2], [1.0 / K] * K)
     torch.autograd.grad(y, [wm] + oo[k % 2], gy[k])
 case('mix forward + backward, 8 operands', 12 * (K + 1) + 12 * (2 * K + 1), mixb, 50)
+
+# ---- the mixture of an sRGB slot with its element-wise operators evaluated in the kernel (functional.slot_mix): 9 tensor
+# operands (the CNN proxies) + gamma, gray world, skip, manual white balance, quadratic white balance, tone curve
+T9 = [[torch.rand_like(bgr[0]) for _ in range(9)] for _ in range(2)]
+order = ['gamma', 'T', 'T', 'T', 'grayworld', 'T', 'T', 'T', 'T', 'skip', 'wb_manual', 'T', 'wb_quadratic', 'gtm_manual', 'T']
+w15 = torch.softmax(torch.zeros(15), 0).cuda()
+blocks = {'gamma': pg, 'wb_manual': pw, 'wb_quadratic': pq, 'gtm_manual': pt}
+
+
+def entries(k, ts, grad=False):
+    it = iter(ts)
+    return [('tensor', next(it)) if o == 'T' else ('op', o, blocks.get(o)) for o in order]
+
+
+with torch.no_grad():
+    # algorithmic bytes: x + 9 tensors read, y written
+    case('slot mixture fused forward, 9 tensors + 6 element-wise', 12 * 11, lambda k: F.slot_mix(w15, bgr[k], entries(k, T9[k % 2]), [1 / 15.] * 15), 50)
+wq = w15.clone().requires_grad_(True)
+xs = [b.clone().requires_grad_(True) for b in bgr]
+tt = [[t.clone().requires_grad_(True) for t in T9[s]] for s in range(2)]
+def slotb(k):
+    y = F.slot_mix(wq, xs[k], entries(k, tt[k % 2]), [1 / 15.] * 15)
+    torch.autograd.grad(y, [wq, xs[k]] + tt[k % 2], gy[k])
+# forward as above; backward: gy, x, 9 tensors read; 9 tensor gradients + gx written
+case('slot mixture fused forward + backward', 12 * 11 + 12 * (2 + 9 + 9 + 1), slotb, 50)
