@@ -268,11 +268,16 @@ int risp_conv_wino5_chunk(void);
 size_t risp_conv_wino5_wpack_floats(int cin, int cout);
 int risp_conv2d_wino5(const risp_conv_desc *d, void *stream);
 
-/* The same operator for a 9x9 layer over exactly 3 input channels and 33..64 output channels - SRCNNRes' first layer with its
- * broadcast planes folded out (srcnn_res_arch.py:18, 41-46): the reduction index k = ci * 81 + ky * 9 + kx is linear, so the
- * matrix instruction's two k-slots hold consecutive k and 3 channels cost 122 instructions per tile instead of the 162 that
- * channel PAIRS cost in risp_conv2d.  wpack: [244][64] floats, row k = w[co][ci][ky][kx] over co (rows >= 243 and columns >=
- * cout zero), 16-byte aligned.  load_mode PLAIN, W % 4 == 0, 16-byte aligned tensors; epilogue RELU | NOBIAS | CASEBIAS. */
+/* The same operator for the FIRST layers of the proxies - few input channels, the whole weight matrix staged once per
+ * workgroup - with a LINEAR reduction index k = (ci * ksize + ky) * ksize + kx, so that the matrix instruction's two k-slots
+ * hold consecutive k (3 channels of a 9x9 layer: 122 instructions per tile instead of the 162 that channel PAIRS cost in
+ * risp_conv2d):  9x9 3 -> cout (SRCNNRes with its broadcast planes folded out, srcnn_res_arch.py:18, 41-46), 3x3 3 -> cout
+ * (path_14l_bgr_arch.py:40-43) with load_mode PLAIN;  9x9 4 -> cout (srcnn_demosaic_arch.py:14-16, 39-43) and 3x3 4 -> cout
+ * (path_14l_bayer_arch.py:37-40, 70-75) with load_mode UNSHUFFLE2 (x = the (N,1,2H,2W) mosaic).  cout <= 64.
+ * wpack: [cout block][2 ceil(cin k k / 2)][B] floats, B = risp_conv_k3_cout_block(cin, ksize) (32 or 64), entry [b][k][c] =
+ * w[b B + c][ci][ky][kx], zero beyond the layer, 16-byte aligned.  W % 4 == 0, 16-byte aligned tensors; epilogue RELU |
+ * NOBIAS | CASEBIAS. */
+int risp_conv_k3_cout_block(int cin, int ksize);
 size_t risp_conv_k3_wpack_floats(int cin, int cout, int ksize);
 int risp_conv2d_k3(const risp_conv_desc *d, void *stream);
 

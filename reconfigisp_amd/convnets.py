@@ -103,12 +103,14 @@ def small_weights(w, transpose=False, keep=None):
 
 
 def k3_weights(w):
-    """[244][64] linear-k weights of ``risp_conv2d_k3`` from a (cout <= 64, 3, 9, 9) layer (include/risp.h)."""
+    """Linear-k weights of ``risp_conv2d_k3`` from a (cout <= 64, cin, k, k) first layer: [cout block][2 ceil(cin k k / 2)]
+    [block width] with row r = w[co][ci][ky][kx] at r = (ci k + ky) k + kx (include/risp.h)."""
     co, ci, k = w.shape[0], w.shape[1], w.shape[2]
-    rows = 2 * ((ci * k * k + 1) // 2)
-    p = torch.zeros((rows, 32 * ((co + 31) // 32)), device=w.device, dtype=w.dtype)
+    cp = L.load().risp_conv_k3_cout_block(ci, k)
+    rows, ncb = 2 * ((ci * k * k + 1) // 2), (co + cp - 1) // cp
+    p = torch.zeros((rows, ncb * cp), device=w.device, dtype=w.dtype)
     p[:ci * k * k, :co] = w.reshape(co, -1).t()
-    return p
+    return p.view(rows, ncb, cp).permute(1, 0, 2).contiguous()
 
 
 K3 = os.environ.get('RISP_CONV_K3', '1') != '0'      # A/B switch: 0 = the 9x9 3 -> 64 layer on the general kernel
@@ -145,6 +147,8 @@ class PackedConv:
         L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
         self.wino_fwd = self.wino_bwd = None
         self.wino_entry = self.wino43_fwd = self.wino43_bwd = None
+        # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
+        self.k3 = k3_weights(w) if (self.k in (3, 9) and self.cin in (3, 4) and self.cout <= 64) else None
         if self.k == 3 and WINOGRAD:
             self.wino_fwd, self.wino_bwd, self.wino_entry = _wino3_pack(w, False), _wino3_pack(w, True), 'risp_conv2d_wino3'
             if WINO_F43:                              # inference forward and every backward-data pass (see conv())
@@ -207,7 +211,6 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
 # bench.py sets this to [0.0] to count the FLOPs the launches ISSUE on the matrix cores (diagnostic; None = off)
 MFMA_ISSUED = None
 _TAPS = {'risp_conv2d_wino3': (12, 2), 'risp_conv2d_wino43': (18, 4), 'risp_conv2d_wino5': (30, 2)}
-_K3_SLOTS = 244          # risp_conv2d_k3: reduction slots per output (243 real)
 
 
 def _issued_flops(entry, cin, cout, k, pixels):
@@ -215,7 +218,7 @@ def _issued_flops(entry, cin, cout, k, pixels):
     multiplies k*k taps per pixel, the Winograd-x kernels 12 / 18 / 30 transformed taps per 2 / 4 / 2 pixels; output
     channels are padded to a multiple of 32 (the MFMA tile), input channels to the kernel's pair granularity."""
     if entry == 'risp_conv2d_k3':
-        return 2.0 * _K3_SLOTS * ((cout + 31) // 32 * 32) * pixels
+        return 2.0 * (2 * ((cin * k * k + 1) // 2)) * ((cout + 31) // 32 * 32) * pixels
     taps, per = _TAPS.get(entry, (k * k, 1))
     return 2.0 * taps * (cin + cin % 2) * ((cout + 31) // 32 * 32) * pixels / per
 
@@ -257,9 +260,10 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
                 (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
                  (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
     wpack = wino if use_wino else (pc.bwd if transpose else pc.fwd)
-    if (K3 and getattr(pc, 'k3', None) is not None and not transpose and load == LOAD_PLAIN and w % 4 == 0 and h >= 8 and w >= 8
+    if (K3 and getattr(pc, 'k3', None) is not None and not transpose and w % 4 == 0 and h >= pc.k - 1 and w >= pc.k - 1
+            and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
             and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS)) and (x.data_ptr() | out.data_ptr()) % 16 == 0):
-        wpack, entry, use_wino = pc.k3, 'risp_conv2d_k3', True      # linear-k 9x9 over 3 channels (risp_conv_k3.hip)
+        wpack, entry, use_wino = pc.k3, 'risp_conv2d_k3', True      # first layers: the linear-k kernel (risp_conv_k3.hip)
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wpack),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
@@ -426,7 +430,6 @@ class SrcnnResFold:
         w1 = _dev(conv1.weight.detach(), 'weight')                    # (64, 12+P, 9, 9)
         self.k = w1.shape[2]
         self.img = PackedConv(w1[:, :3].contiguous(), conv1.bias)
-        self.img.k3 = k3_weights(w1[:, :3]) if (self.k == 9 and 32 < w1.shape[0] <= 64) else None
         self.rcase, self.wconst = srcnn_fold_tables(w1)
         self.bwd_img = SmallConv(w1, None, transpose=True, keep=3)
         self.tail = SmallConv(conv3.weight, conv3.bias)

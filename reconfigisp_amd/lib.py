@@ -111,6 +111,7 @@ SIGNATURES = {
     'risp_conv2d_small': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_small_groups': (_i, [C.POINTER(ConvDesc)]),
     'risp_conv2d_small_split': (_i, [C.POINTER(ConvDesc), _f, _i, _s]),
+    'risp_conv_k3_cout_block': (_i, [_i, _i]),
     'risp_conv_k3_wpack_floats': (_z, [_i, _i, _i]),
     'risp_conv2d_k3': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_rect_sums': (_i, [_f, _f, _i, _i, _i, _i, _s]),

@@ -417,3 +417,33 @@ def test_linear_k_9x9_over_three_channels(cout, hw):
     finally:
         CN.K3 = True
     assert_close(launch(packs[0], x, None, 0), general, rtol=1e-5, floor=1.0, what='k3 vs general kernel')
+
+
+@pytest.mark.parametrize('hw', [(8, 8), (16, 32), (20, 36), (40, 72), (128, 128)])
+@pytest.mark.parametrize('k,cin,cout', [(3, 3, 64), (3, 4, 64), (9, 4, 64), (9, 4, 40), (3, 4, 24), (9, 3, 20)])
+def test_linear_k_first_layers(k, cin, cout, hw):
+    """risp_conv2d_k3 on every first-layer form (path_14l_bgr_arch.py:40-43, path_14l_bayer_arch.py:37-40 + :70-75,
+    srcnn_demosaic_arch.py:14-16 + :39-43, srcnn_res_arch.py:18): 3 plain channels or the 4 planes of the space-to-depth
+    mosaic, bias + ReLU, against PyTorch; the launch really is the linear-k kernel."""
+    from reconfigisp_amd import convnets as CN
+    from reconfigisp_amd import lib as L
+    h, w = hw
+    n = 3
+    wt, b = rnd(cout, cin, k, k, seed=60 + k + cin) * 0.1, rnd(cout, seed=61) * 0.1
+    pc = CN.PackedConv(wt, b)
+    assert pc.k3 is not None
+    if cin == 4:
+        bay = rnd(n, 1, 2 * h, 2 * w, seed=62)
+        src, load, planes = bay, CN.LOAD_UNSHUFFLE2, TF.pixel_unshuffle(bay, 2)
+    else:
+        src = planes = rnd(n, 3, h, w, seed=63)
+        load = CN.LOAD_PLAIN
+    calls = []
+    real = L.call
+    L.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    try:
+        y = CN.conv(src, pc, n, h, w, load=load, epi=CN.EPI_RELU)
+    finally:
+        L.call = real
+    assert calls == ['risp_conv2d_k3'], calls
+    assert_close(y, torch.relu(TF.conv2d(planes, wt, b, padding=k // 2)), what='linear-k %dx%d %d->%d' % (k, k, cin, cout))
