@@ -245,10 +245,16 @@ class DartsModel(BaseModel):
         dalpha, dp = grads[:len(v_alphas)], grads[len(v_alphas):]
         hessian = self.compute_hessian(dp)
         with torch.no_grad():
+            # the reference's per-alpha `torch.isnan(h).any()` (:260-263) is a device synchronisation each: one transfer
+            # for all of them (every synchronisation drains the launch queue)
+            live = [h for h in hessian if h is not None]
+            bad = torch.stack([torch.isnan(h).any() for h in live]).tolist() if live else []
+            nan_flag = iter(bad)
             for idx, (alpha, da, h) in enumerate(zip(self.netG_attr.alphas, dalpha, hessian), start=1):
+                has_nan = next(nan_flag) if h is not None else False
                 if da is None or h is None:
                     alpha.grad = torch.zeros_like(alpha)
-                elif torch.isnan(h).any():
+                elif has_nan:
                     print('Warning: NaN in hessian, for the {}-th alpha'.format(idx))
                     alpha.grad = torch.zeros_like(alpha)
                 else:
@@ -258,7 +264,9 @@ class DartsModel(BaseModel):
     def compute_hessian(self, dp):
         """(dalpha L_trn(p + eps dp) - dalpha L_trn(p - eps dp)) / 2. * eps, eps = 0.01/||dp||."""
         norm = torch.cat([w.view(-1) for w in dp if w is not None]).norm()
-        eps = 0. if norm < 1e-6 else 0.01 / norm
+        # eps = 0 if norm < 1e-6 else 0.01 / norm (:276-277) without reading norm back: the comparison on the host is a
+        # device synchronisation in the middle of the iteration
+        eps = torch.where(norm < 1e-6, torch.zeros_like(norm), 0.01 / norm)
         params = self.netG_attr.trainable_params
 
         live = [(p, d) for p, d in zip(params, dp) if len(p) > 0 and d is not None]

@@ -221,21 +221,38 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             cache[key] = torch.tensor(index, dtype=torch.long, device=post.device)
         return post.index_select(0, cache[key])
 
+    def _mixture_weights(self):
+        """(post, host weights) of every slot.  post = pruned, renormalised softmax(alpha) (one launch per slot); the host
+        copy (the reference's .item(): a device synchronisation) is kept per VALUE of alpha - four of the five forwards of
+        a DARTS iteration see unchanged logits (in-place updates bump _version) - and the slots whose copy is stale are
+        fetched with ONE device-to-host transfer for the whole network instead of one per slot: each transfer drains the
+        launch queue, and at the per-GPU batch of the 8-GPU search the host needs ~0.2 ms to refill it."""
+        posts, keys, stale = [], [], []
+        for slot, (mods, alpha) in enumerate(zip(self.all_modules, self.all_alphas)):
+            unavailable = self._unavailable(mods, alpha.device)
+            posts.append(F.prune_softmax(alpha, self.threshold, unavailable))
+            keys.append((alpha._version, alpha.data_ptr(), self.threshold, unavailable is None))
+            cached = self._weight_cache.get(slot)
+            if cached is None or cached[0] != keys[slot]:
+                stale.append(slot)
+        if stale:
+            flat = torch.cat([posts[s].detach() for s in stale]).cpu().tolist() if len(stale) > 1 else \
+                posts[stale[0]].detach().cpu().tolist()
+            at = 0
+            for s in stale:
+                k = posts[s].numel()
+                self._weight_cache[s] = (keys[s], flat[at: at + k])
+                at += k
+        return posts, [self._weight_cache[s][1] for s in range(len(posts))]
+
     def forward(self, x):
         n = x.size(0)
         self.middle_results = []
         token = (x.data_ptr(), x._version, tuple(x.shape)) if self._reuse is not None else None
+        posts, host_weights = self._mixture_weights()
         for slot, (mods, pars, alpha) in enumerate(zip(self.all_modules, self.all_params, self.all_alphas)):
-            # softmax -> strict-< prune against threshold * max (detached) -> renormalise by the detached sum: one launch
-            unavailable = self._unavailable(mods, alpha.device)
-            post = F.prune_softmax(alpha, self.threshold, unavailable)
-            # host copy of the weights (the reference's .item(): a device synchronisation) - once per VALUE of alpha:
-            # four of the five forwards of a DARTS iteration see unchanged logits (in-place updates bump _version)
-            key = (alpha._version, alpha.data_ptr(), self.threshold, unavailable is None)
-            cached = self._weight_cache.get(slot)
-            if cached is None or cached[0] != key:
-                cached = self._weight_cache[slot] = (key, post.detach().cpu().tolist())
-            weights = cached[1]
+            # softmax -> strict-< prune against threshold * max (detached) -> renormalise by the detached sum (:185-193)
+            post, weights = posts[slot], host_weights[slot]
             self.pruned_paths[slot] = sum(1 for w in weights if w == 0.0)
 
             index, pruned_pars, live_pars = [], [], []

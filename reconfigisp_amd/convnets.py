@@ -294,7 +294,7 @@ class PackCache:
         self._key, self._packs = None, None
 
     def get(self, module, build):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in module.parameters())      # (a device move changes data_ptr)
         if key != self._key:
             self._packs, self._key = build(), key
         return self._packs
