@@ -30,6 +30,8 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restri
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // shader clock during the run: cycles (s_memtime) per 100 MHz tick (s_memrealtime), stamped by one wave of every 97th block
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int tile = 0; tile < tiles; ++tile) {
         f32x16 acc[6];
 #pragma unroll
@@ -115,6 +117,10 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restri
             if (s == 12345.678f) out[0] = s;
         }
     }
+    if (threadIdx.x == 0 && blockIdx.x % 97 == 0) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        out[1 + blockIdx.x / 97] = (float)((double)(c1 - c0) / (double)(r1 - r0) * 0.1);       // GHz
+    }
 }
 
 template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24>
@@ -135,14 +141,22 @@ void run(const char *what, const float *src, float *dst, float *out) {
         if (rep && ms < best) best = ms;
     }
     const double flops = (double)blocks * NW * tiles * 16 * 36 * (32.0 * 32 * 2 * 2);
-    printf("%-52s %8.3f ms  %7.1f TFLOP/s  (%.3f of 157.3)\n", what, best, flops / best / 1e9, flops / best / 1e9 / 157.3);
+    float ghz[64];
+    hipMemcpy(ghz, out + 1, sizeof(float) * 16, hipMemcpyDeviceToHost);
+    float med[16];
+    int n = 0;
+    for (int i = 0; i < 16 && i * 97 < blocks; ++i) med[n++] = ghz[i];
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (med[j] < med[i]) { float t = med[i]; med[i] = med[j]; med[j] = t; }
+    const double clk = n ? med[n / 2] : 0.0, at_clk = 65536.0 * clk * 1e9 / 1e12;       // 1024 SIMDs x 64 FLOP per cycle
+    printf("%-52s %8.3f ms  %7.1f TFLOP/s  (%.3f of 157.3)  clock %.2f GHz -> %.3f of the %.0f TFLOP/s at that clock\n", what, best,
+           flops / best / 1e9, flops / best / 1e9 / 157.3, clk, flops / best / 1e9 / at_clk, at_clk);
 }
 
 int main() {
     float *src, *dst, *out;
     hipMalloc(&src, (size_t)4096 * 16 * 6144 * 4);      // 1.6 GB of tiles + slabs
     hipMalloc(&dst, (size_t)8192 * 16384 * 4);          // 512 MB of outputs
-    hipMalloc(&out, 4);
+    hipMalloc(&out, 4 * 128);
     hipMemset(src, 0, (size_t)4096 * 16 * 6144 * 4);
     run<false, false, 0, false>("matrix stream + LDS operand reads", src, dst, out);
     run<true, false, 0, false>("+ barrier per chunk", src, dst, out);
