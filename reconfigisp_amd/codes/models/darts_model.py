@@ -190,7 +190,14 @@ class DartsModel(BaseModel):
         """p' = p - lr_meta * (momentum * buf + dL_trn/dp) written into netV; alphas copied."""
         loss = self._loss(self.netG, self.img, self.gt, self.glb_flag, self.cri_pix)[0]
         params = self.netG_attr.trainable_parameters
-        grads = list(torch.autograd.grad(loss, params, allow_unused=True))
+        only = getattr(self.netG_attr, 'params_only_backward', None) if self.step_reuse else None
+        if only:
+            only(True)            # nobody consumes the input gradient of the first parametrised slot in this pass
+        try:
+            grads = list(torch.autograd.grad(loss, params, allow_unused=True))
+        finally:
+            if only:
+                only(False)
         if self.sync_arch_grads:
             self._allreduce_mean(grads)
         # the reference's per-parameter loop (darts_model.py:208-218) as list-wide launches: same operations in the

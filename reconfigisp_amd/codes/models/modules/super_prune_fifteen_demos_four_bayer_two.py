@@ -130,6 +130,15 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             for m in mods:
                 m.__dict__.pop('_risp_reuse', None)
 
+    def params_only_backward(self, on):
+        """While on: the next backward pass is asked for the PARAMETER gradients only (DartsModel.virtual_step,
+        darts_model.py:204 `autograd.grad(loss, trainable_parameters)`).  The slots below the first parametrised one hold no
+        parameters, so the input gradient of that slot's operators feeds nothing: the grouped SRCNNRes backward skips its
+        9x9 64->3 backward-data convolution and the member sum (autograd already skips the nodes that lead only to alphas)."""
+        first = next((s for s, pars in enumerate(self.all_params) if any(p.numel() for p in pars)), None)
+        if first is not None:
+            self.__dict__.setdefault('_group_cache', {}).setdefault(first, {})['skip_gx'] = bool(on)
+
     def _record(self, slot, k, token, mod):
         """the reuse record of op k of `slot` for this input token (None outside a scope / for ops with parameters)"""
         if self._reuse is None or token is None:

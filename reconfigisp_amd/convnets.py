@@ -678,7 +678,7 @@ class _SrcnnResGroupFn(torch.autograd.Function):
     """G SRCNNRes members on one shared input: outputs (y_0, ..., y_{G-1}), each (N,3,H,W) - slices of one buffer."""
 
     @staticmethod
-    def forward(ctx, x, gp, grouped, *pvs):
+    def forward(ctx, x, gp, grouped, flags, *pvs):
         x = _dev(x, 'img')
         n, _, h, w = x.shape
         G = gp.G
@@ -706,7 +706,7 @@ class _SrcnnResGroupFn(torch.autograd.Function):
                 conv_small(t2[s], c1.fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, out=y[s], split=split)
             _count(3 + 3 * G)
         ctx.save_for_backward(t1, t2, arg, x)
-        ctx.gp, ctx.dims, ctx.grouped = gp, (n, h, w), grouped
+        ctx.gp, ctx.dims, ctx.grouped, ctx.flags = gp, (n, h, w), grouped, flags
         return tuple(y.view(G, n, 3, h, w).unbind(0))
 
     @staticmethod
@@ -715,7 +715,16 @@ class _SrcnnResGroupFn(torch.autograd.Function):
         gp, (n, h, w), G = ctx.gp, ctx.dims, ctx.gp.G
         gy = _stack_grads(gys, x)                       # (G*N,3,H,W)
         dev = dict(device=gy.device, dtype=torch.float32)
-        if ctx.grouped:
+        # the caller may know that nobody will consume this node's input gradient (DartsModel.virtual_step asks for the
+        # parameter gradients only and the slots below the first parametrised one have none: flags['skip_gx']); autograd
+        # cannot tell a custom Function that - needs_input_grad is a property of the forward graph
+        want_gx = not (ctx.flags is not None and ctx.flags.get('skip_gx'))
+        if ctx.grouped and not want_gx:
+            g2 = conv(gy, gp.c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2, group=(G, 0))
+            g1 = conv(g2, gp.c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1, group=(G, 0))
+            gxs = None
+            _count(2)
+        elif ctx.grouped:
             g2 = conv(gy, gp.c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2, group=(G, 0))
             g1 = conv(g2, gp.c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1, group=(G, 0))
             gxs = conv_small(g1, gp.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3, group=(G, 0))
@@ -735,11 +744,13 @@ class _SrcnnResGroupFn(torch.autograd.Function):
         row = 9 + max(gp.P)
         gconst = torch.empty((G * n, row), **dev)       # min, mean, max planes, then the members' parameters
         L.call('risp_srcnn_const_grad_group', _p(rs), C.byref(gp.desc(n, h * w)), _p(gconst), row, _stream())
-        gx = torch.empty((n, 3, h, w), **dev)
-        L.call('risp_group_sum', _p(gxs), _p(gx), G, n, 3, h * w, _p(gconst), row, _p(arg), _stream())
-        _count(3)
+        gx = None
+        if gxs is not None:
+            gx = torch.empty((n, 3, h, w), **dev)
+            L.call('risp_group_sum', _p(gxs), _p(gx), G, n, 3, h * w, _p(gconst), row, _p(arg), _stream())
+        _count(3 if gxs is not None else 2)
         gpvs = tuple(gconst[g * n:(g + 1) * n, 9:9 + gp.P[g]] if gp.P[g] else None for g in range(G))
-        return (gx, None, None) + gpvs
+        return (gx, None, None, None) + gpvs
 
 
 def _small_split(x, sc, n_total, h, w, epi, add_c):
@@ -756,7 +767,7 @@ def srcnn_res_group(x, pvs, packs_list, cache):
     gp = cache.get('srcnn_res')
     if gp is None or gp[0] != key:
         gp = cache['srcnn_res'] = (key, SrcnnResGroup(packs_list))
-    return list(_SrcnnResGroupFn.apply(x, gp[1], GROUP_LAUNCH, *pvs))
+    return list(_SrcnnResGroupFn.apply(x, gp[1], GROUP_LAUNCH, cache, *pvs))
 
 
 class SrcnnDemosaicGroup:
