@@ -74,6 +74,7 @@ class DartsModel(BaseModel):
             self.lr_meta = t['lr_meta']
             self.sync_arch_grads = bool(t.get('sync_arch_grads', True)) if hasattr(t, 'get') else True
             self.step_reuse = bool(t.get('step_reuse', True)) if hasattr(t, 'get') else True
+            self.weight_step_alpha_grads = bool(t.get('weight_step_alpha_grads', False)) if hasattr(t, 'get') else False
             self.optimizer_G = torch.optim.SGD(self.netG_attr.trainable_parameters, t['lr_G'],
                                                momentum=self.momentum_G)
             self.optimizer_alpha = torch.optim.Adam(self.netG_attr.alphas, lr=t['lr_G'],
@@ -177,7 +178,26 @@ class DartsModel(BaseModel):
         l_pix, self.output, self.latency, self.latency_term = self._loss(self.netG, self.img, self.gt,
                                                                          self.glb_flag, self.cri_pix)
         self.optimizer_G.zero_grad()
-        l_pix.backward()
+        if self.weight_step_alpha_grads:
+            l_pix.backward()
+        else:
+            # The weight step uses the gradients of the module parameters only (optimizer_G, :86-88).  The reference's
+            # l_pix.backward() (:173) also accumulates d loss / d alpha into alpha.grad, which nothing reads: the next
+            # optimize_alphas() starts with optimizer_alpha.zero_grad() (:226).  Asking for what is used lets autograd skip
+            # every node that leads only to alphas - the backward of the demosaic proxies and of the first sRGB slot's
+            # Path-Restore - and the grouped backward its unneeded input gradient.  Parameters, alphas, losses and outputs
+            # are unchanged; only that transient alpha.grad is not written (train.weight_step_alpha_grads: true restores it).
+            params = [p for p in self.netG_attr.trainable_parameters if p.numel()]
+            only = getattr(self.netG_attr, 'params_only_backward', None)
+            if only:
+                only(True)
+            try:
+                grads = torch.autograd.grad(l_pix, params, allow_unused=True)
+            finally:
+                if only:
+                    only(False)
+            for p, g in zip(params, grads):
+                p.grad = g
         self._allreduce_mean([p.grad for p in self.netG_attr.trainable_parameters])
         self.optimizer_G.step()
         self.log_dict['loss'] = l_pix.item()

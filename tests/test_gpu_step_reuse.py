@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 T = lambda a: torch.from_numpy(np.asarray(a))
 
 
-def _run(reuse, iters=2):
+def _run(reuse, iters=2, alpha_grads=False):
     from reconfigisp_amd import convnets as CN
     from reconfigisp_amd.codes.models import create_model
     g = load_golden('darts_step')
     opt = darts_opt(torch.device('cuda'))
     opt['train']['step_reuse'] = reuse
+    opt['train']['weight_step_alpha_grads'] = alpha_grads
     torch.manual_seed(0)
     model = create_model(opt)
     seed_darts(model)
@@ -85,3 +86,18 @@ def test_reuse_scope_misses_when_the_input_or_a_parameter_changes():
         net.end_reuse()
     assert torch.equal(c, net(bay.mul(2.0)).detach()) and not torch.equal(c, ref)
     assert torch.equal(d, net(bay).detach())
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+def test_weight_step_without_alpha_gradients_changes_no_result():
+    """optimize_parameters asks autograd for the module parameters' gradients only (the reference's l_pix.backward() also
+    fills alpha.grad, which nothing reads: models/darts_model.py:173, 226): alphas, parameters, losses over two iterations are
+    the same bits either way; with the reference's form the transient alpha.grad is written."""
+    lean, calls_lean, m_lean = _run(True)
+    full, calls_full, m_full = _run(True, alpha_grads=True)
+    for a, b in zip(lean, full):
+        assert torch.equal(a, b)
+    assert calls_lean < calls_full
+    # after the weight step: the lean form leaves alpha.grad at what optimize_alphas set, the reference's form adds d loss / d alpha
+    ga, gb = m_lean.netG.alpha_step1.grad, m_full.netG.alpha_step1.grad
+    assert ga is not None and gb is not None and not torch.equal(ga, gb)
