@@ -83,6 +83,24 @@ def wino5_weights(w, transpose, ck):
     return _wino_blocked_pack(torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype), ck)
 
 
+_W45_G = ((1, 0, 0, 0, 0), (1, 1, 1, 1, 1), (1, -1, 1, -1, 1), (1, 2, 4, 8, 16), (1, -2, 4, -8, 16),
+          (1, 1 / 2, 1 / 4, 1 / 8, 1 / 16), (1, -1 / 2, 1 / 4, -1 / 8, 1 / 16), (0, 0, 0, 0, 1))
+_W45_S = (1., -18., -18., 360., 360., 45. / 16., 45. / 16., 1.)
+
+
+def wino45_weights(w, transpose, ck=4):
+    """[cout block of 32][chunk of ``ck`` cin][ky][t][ci][32] Winograd F(4,5)-along-x weights of a 5x5 layer
+    (include/risp.h: risp_conv2d_wino45).  Pure tensor algebra (computed in fp64, stored in the dtype of ``w``)."""
+    if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
+        w = w.flip(2, 3).transpose(0, 1)
+    g = torch.tensor(_W45_G, dtype=torch.float64, device=w.device) / torch.tensor(_W45_S, dtype=torch.float64,
+                                                                                  device=w.device)[:, None]
+    return _wino_blocked_pack(torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype), ck)
+
+
+WINO_F45 = os.environ.get('RISP_WINO_F45', '1') != '0'       # 5x5: F(4,5) where cin % 4 == 0 (default), else F(2,5)
+
+
 def _wino5_pack(w, transpose):
     return wino5_weights(w, transpose, L.load().risp_conv_wino5_chunk())
 
@@ -147,6 +165,7 @@ class PackedConv:
         L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
         self.wino_fwd = self.wino_bwd = None
         self.wino_entry = self.wino43_fwd = self.wino43_bwd = None
+        self.wino45_fwd = self.wino45_bwd = None
         # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
         self.k3 = k3_weights(w) if (self.k in (3, 9) and self.cin in (3, 4) and self.cout <= 64) else None
         if self.k == 3 and WINOGRAD:
@@ -156,6 +175,9 @@ class PackedConv:
                 self.wino43_fwd, self.wino43_bwd = wino43_weights(w, False, ck43), wino43_weights(w, True, ck43)
         elif self.k == 5 and WINOGRAD:
             self.wino_fwd, self.wino_bwd, self.wino_entry = _wino5_pack(w, False), _wino5_pack(w, True), 'risp_conv2d_wino5'
+            if WINO_F45:                              # launches with cin % 4 == 0 take F(4,5) (see conv())
+                self.wino45_fwd = wino45_weights(w, False) if self.cin % 4 == 0 else None
+                self.wino45_bwd = wino45_weights(w, True) if self.cout % 4 == 0 else None
 
 
 class SmallConv:
@@ -210,7 +232,7 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
 
 # bench.py sets this to [0.0] to count the FLOPs the launches ISSUE on the matrix cores (diagnostic; None = off)
 MFMA_ISSUED = None
-_TAPS = {'risp_conv2d_wino3': (12, 2), 'risp_conv2d_wino43': (18, 4), 'risp_conv2d_wino5': (30, 2)}
+_TAPS = {'risp_conv2d_wino3': (12, 2), 'risp_conv2d_wino43': (18, 4), 'risp_conv2d_wino5': (30, 2), 'risp_conv2d_wino45': (40, 4)}
 
 
 def _issued_flops(entry, cin, cout, k, pixels):
@@ -256,6 +278,9 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     elif pc.wino43_fwd is not None and not transpose and (infer or F43_TRAIN):
         # (inference: always F(4,3), so that a tile's result never depends on the batch it travels in)
         wino, entry = pc.wino43_fwd, 'risp_conv2d_wino43'
+    w45 = getattr(pc, 'wino45_bwd' if transpose else 'wino45_fwd', None)
+    if w45 is not None and WINO_F45:                  # 5x5 layers whose launch has cin % 4 == 0: F(4,5), 2/3 of F(2,5)'s matrix work
+        wino, entry = w45, 'risp_conv2d_wino45'
     use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
                 (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
                  (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
@@ -618,7 +643,7 @@ class _Stacked:
 
 
 def stack_packed(pcs):
-    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3'), ('cin', 'cout', 'k', 'wino_entry'))
+    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd'), ('cin', 'cout', 'k', 'wino_entry'))
 
 
 def stack_small(scs):

@@ -937,6 +937,202 @@ __global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_c
     w43_epilogue<WGS == 3 ? 1 : 4>(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);   // 3 workgroups per CU: 168 registers
 }
 
+// ---------------------------------------------------------------------------------------------------
+// F(4,5) along x with LDS-DMA staging (round 3): four outputs of a 5-tap filter row from 8 products - 40 "taps" per pixel
+// QUAD where F(2,5) issues 30 per pixel PAIR, i.e. 2/3 of its matrix instructions (SRCNNRes' 64 -> 32 layer and its
+// backward are a third of a search step, srcnn_res_arch.py:20).  Interpolation points 0, +-1, +-2, +-1/2, inf; the row
+// scalings sit in the packed weights so that the on-the-fly input transform has small coefficients and shares its even
+// and odd halves between a point and its negative (26 vector instructions per 8 matrix instructions):
+//     V0 = (d0 - d6) + 5.25 (d4 - d2)                      V7 = (d7 - d1) + 5.25 (d3 - d5)
+//     V1,2 = E1 +- O1,  E1 = 4 (d2 + d6) - 17 d4,           O1 = 4 (d1 + d5) - 17 d3
+//     V3,4 = E3 +- 2 O3, E3 = d2 - 5 d4 + 4 d6,             O3 = d1 - 5 d3 + 4 d5
+//     V5,6 = 2 E5 +- O5, E5 = 4 d2 - 5 d4 + d6,             O5 = 4 d1 - 5 d3 + d5        (d_j = x[4q - 2 + j])
+//     y0 = m0 + (m1+m2) + (m3+m4) + (m5+m6)                 y1 = (m1-m2) + 2 (m3-m4) + (m5-m6) / 2
+//     y2 = (m1+m2) + 4 (m3+m4) + (m5+m6) / 4                y3 = (m1-m2) + 8 (m3-m4) + (m5-m6) / 8 + m7
+// fp32 emulation of a 64-channel row (random weights, activations in [0,1)): rms / max error 1.7e-7 / 1.8e-6 of max|y|
+// against 1.5e-7 / 1.1e-6 for F(2,5) and 1.0e-7 / 8e-7 for the direct convolution.
+// Tile, operand reads (three ds_read_b128 per lane and group) and store epilogue (four pixels of a cout row per lane = one
+// 16-byte store) are those of conv_wino43_glds_kernel; 8 accumulator tiles (128 registers) -> two workgroups per CU;
+// per chunk of 4 input channels 17 pieces of input tile (4 x 8 x 136 floats) + 20 of weight slab (40 x 4 x 32).
+constexpr int W45IH = WTH + 4, W45TAPS = 40;
+
+template <int EB = 4>
+__device__ __forceinline__ void w45_epilogue(const risp_conv_desc &d, const f32x16 (&acc)[8], int n, int cb, int oy, int ox,
+                                             int half) {
+    if (!(oy < d.H && ox < d.W)) return;
+    const int epi = d.epilogue;
+    const size_t hw = (size_t)d.H * d.W, pix = (size_t)oy * d.W + ox;
+    const bool has_add = (epi & RISP_EPI_ADD) != 0, has_mask = (epi & RISP_EPI_MASK) != 0;
+    auto co_of = [&](int e) { return cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half; };
+    float bias[16];
+    if (!(epi & RISP_EPI_NOBIAS)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co_of(e);
+            bias[e] = d.bias[co < d.cout ? co : d.cout - 1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias[e] = 0.f;
+    }
+    float4 av[2][EB], mv[2][EB];
+    auto load_batch = [&](int b, int slot) {
+        if (has_add) {
+#pragma unroll
+            for (int i = 0; i < EB; ++i) {
+                const int co = co_of(EB * b + i);
+                const int cc = co < d.add_c ? co : d.add_c - 1;               // clamped: always a valid address
+                av[slot][i] = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + cc) * hw + pix);
+            }
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int i = 0; i < EB; ++i) {
+                const int co = co_of(EB * b + i);
+                const int cc = co < d.cout ? co : d.cout - 1;
+                mv[slot][i] = *reinterpret_cast<const float4 *>(d.mask + ((size_t)n * d.cout + cc) * hw + pix);
+            }
+        }
+    };
+    load_batch(0, 0);
+#pragma unroll
+    for (int b = 0; b < 16 / EB; ++b) {
+        const int slot = b & 1;
+        if (b + 1 < 16 / EB) load_batch(b + 1, slot ^ 1);
+#pragma unroll
+        for (int i = 0; i < EB; ++i) {
+            const int e = EB * b + i, co = co_of(e);
+            const float a12 = acc[1][e] + acc[2][e], s12 = acc[1][e] - acc[2][e], a34 = acc[3][e] + acc[4][e],
+                        s34 = acc[3][e] - acc[4][e], a56 = acc[5][e] + acc[6][e], s56 = acc[5][e] - acc[6][e];
+            const float bb = bias[e];
+            float4 o = make_float4(acc[0][e] + a12 + a34 + a56 + bb, s12 + 2.f * s34 + 0.5f * s56 + bb,
+                                   a12 + 4.f * a34 + 0.25f * a56 + bb, s12 + 8.f * s34 + 0.125f * s56 + acc[7][e] + bb);
+            if (has_add && co < d.add_c) {
+                const float4 a = av[slot][i];
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            if (epi & RISP_EPI_RELU) {
+                o.x = o.x > 0.f ? o.x : 0.f;
+                o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f;
+                o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            if (has_mask) {
+                const float4 m = mv[slot][i];
+                o.x = m.x > 0.f ? o.x : 0.f;
+                o.y = m.y > 0.f ? o.y : 0.f;
+                o.z = m.z > 0.f ? o.z : 0.f;
+                o.w = m.w > 0.f ? o.w : 0.f;
+            }
+            if (co < d.cout) *reinterpret_cast<float4 *>(d.y + ((size_t)n * d.cout + co) * hw + pix) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino45_glds_kernel(const risp_conv_desc d_in, int ncb) {
+    constexpr int CK = 4, CP = 32, STAGES = 2;
+    constexpr int XN = CK * W45IH * W43WP, WN = W45TAPS * CK * CP;      // floats: 4352, 5120
+    constexpr int XI = XN / 256, WI = WN / 256, PIECES = XI + WI, PER_WAVE = (PIECES + 3) / 4;     // 17 + 20 wave-instructions per chunk
+    constexpr int STAGE = PIECES * 256;
+    static_assert(XN % 256 == 0 && WN % 256 == 0, "staging layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // [STAGES][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * W43TW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const risp_conv_desc d = risp_conv_group_view(d_in, n);
+    const int nchunks = d.cin / CK;
+    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // zero the whole staging area once (lanes outside the image are masked out of every transfer and keep their zeros)
+    for (int v = tid; v < STAGES * STAGE / 4; v += 256) reinterpret_cast<float4 *>(smem)[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // this wave's DMA slots: id = wave + 4 j; ids 0..16 input tile, 17..36 weight slab
+    const float *src0[PER_WAVE];
+    unsigned long long mask[PER_WAVE];
+    int step[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int id = wave + 4 * j;
+        bool ok = false;
+        src0[j] = xn;
+        step[j] = 0;
+        if (id < XI) {
+            const int v = id * 64 + lane;
+            const int cl = v / (W45IH * (W43WP / 4)), rem = v - cl * (W45IH * (W43WP / 4));
+            const int iy = rem / (W43WP / 4), q = rem - iy * (W43WP / 4);
+            const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * q;
+            ok = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            src0[j] = xn + ((size_t)cl * d.H + gy) * d.W + gx;
+            step[j] = CK * (int)hw;
+        } else if (id < PIECES) {
+            ok = true;
+            src0[j] = wpack + 4 * ((id - XI) * 64 + lane);
+            step[j] = WN;
+        }
+        mask[j] = __builtin_amdgcn_ballot_w64(ok);
+    }
+    auto issue = [&](int ch, int buf) {
+        float *stage = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int id = wave + 4 * j;
+            if (id < PIECES) lds_dma16(src0[j] + (size_t)ch * step[j], stage + id * 256, mask[j]);     // wave-uniform branch
+        }
+    };
+
+    __syncthreads();                                   // zeros in place before the first DMA lands
+    if (nchunks > 0) issue(0, 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's transfers of chunk ch have landed
+        __builtin_amdgcn_s_barrier();                  // ... for every wave; the other buffer is free
+        if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
+        const float *sx = smem + buf * STAGE, *sw = sx + XN;
+        const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (half * W45IH + wave) * W43WP) + l31;
+        const float *aw = sw + half * CP + l31;
+        constexpr int NG = 5 * (CK / 2);
+        float opa[2][8];
+        f32x4 opd[2][3];
+        auto load_group = [&](int g, int slot) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+            const f32x4 *dp = bx + (2 * cp * W45IH + ky) * (W43WP / 4);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) opd[slot][j] = dp[j];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) opa[slot][t] = aw[((ky * 8 + t) * CK + 2 * cp) * CP];
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot = g & 1;
+            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(opd[slot][0]), "+v"(opd[slot][2]));
+            const float d0 = opd[slot][0].z, d1 = opd[slot][0].w, d2 = opd[slot][1].x, d3 = opd[slot][1].y, d4 = opd[slot][1].z,
+                        d5 = opd[slot][1].w, d6 = opd[slot][2].x, d7 = opd[slot][2].y;
+            const float e1 = __builtin_fmaf(4.f, d2 + d6, -17.f * d4), o1 = __builtin_fmaf(4.f, d1 + d5, -17.f * d3);
+            const float e3 = __builtin_fmaf(4.f, d6, __builtin_fmaf(-5.f, d4, d2)), o3 = __builtin_fmaf(4.f, d5, __builtin_fmaf(-5.f, d3, d1));
+            const float e5 = __builtin_fmaf(4.f, d2, __builtin_fmaf(-5.f, d4, d6)), o5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+            const float bv[8] = {__builtin_fmaf(5.25f, d4 - d2, d0 - d6), e1 + o1, e1 - o1, __builtin_fmaf(2.f, o3, e3),
+                                 __builtin_fmaf(-2.f, o3, e3), __builtin_fmaf(2.f, e5, o5), __builtin_fmaf(2.f, e5, -o5),
+                                 __builtin_fmaf(5.25f, d3 - d5, d7 - d1)};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    w45_epilogue<4>(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);
+}
+
 template <int CK, int CB>
 int launch_wino(const risp_conv_desc &d, hipStream_t s) {
     constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * 32 * CB;
@@ -1095,6 +1291,43 @@ int risp_conv2d_wino5(const risp_conv_desc *dp, void *stream) {
 #endif
     hipLaunchKernelGGL(conv_wino5_kernel<W5CK>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
     RISP_LAUNCH_CHECK("risp_conv2d_wino5");
+    return 0;
+}
+
+int risp_conv_wino45_chunk(void) { return 4; }
+
+size_t risp_conv_wino45_wpack_floats(int cin, int cout) {
+    return (size_t)((cout + 31) / 32) * ((cin + 3) / 4) * W45TAPS * 4 * 32;
+}
+
+int risp_conv2d_wino45(const risp_conv_desc *dp, void *stream) {
+    RISP_CHECK_ARG(dp, "risp_conv2d_wino45: null descriptor");
+    const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino45: null tensor");
+    RISP_CHECK_GROUP(d, "risp_conv2d_wino45");
+    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cin % 4 == 0 && d.cout > 0 && d.cout <= 64 &&
+                       d.ksize == 5 && (size_t)d.N * ((d.cout + 31) / 32) <= 65535,
+                   "risp_conv2d_wino45: needs a 5x5 layer, cin %% 4 == 0, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)",
+                   d.N, d.H, d.W, d.cin, d.cout, d.ksize);
+    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_wino45: only plain loads");
+    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
+                   "risp_conv2d_wino45: epilogue %d not supported", d.epilogue);
+    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_wino45: bias missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_wino45: add tensor missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_wino45: mask tensor missing");
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
+                     reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
+                   "risp_conv2d_wino45: tensors must be 16-byte aligned");
+    const int ncb = (d.cout + 31) / 32;
+    const size_t lds = sizeof(float) * 2 * (4 * W45IH * W43WP + W45TAPS * 4 * 32);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino45_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+        risp_set_error("risp_conv2d_wino45: cannot raise the dynamic LDS limit to %zu bytes", lds);
+        return 2;
+    }
+    dim3 grid((d.W + W43TW - 1) / W43TW, (d.H + WTH - 1) / WTH, d.N * ncb);
+    hipLaunchKernelGGL(conv_wino45_glds_kernel, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
+    RISP_LAUNCH_CHECK("risp_conv2d_wino45");
     return 0;
 }
 

@@ -169,3 +169,41 @@ def test_srcnn_broadcast_planes_fold(P, hw):
     gref, = torch.autograd.grad(full, cv, g)
     got = rect_sums(g, k).reshape(n, -1) @ wconst
     assert torch.allclose(got, gref, rtol=1e-10, atol=1e-10)
+
+
+def wino45_emulate(x, pack, ck, cout):
+    """What conv_wino45_glds_kernel computes from its pack: F(4,5), four outputs per quad from 8 products per filter row
+    (the input transform and the output combination exactly as the kernel writes them)."""
+    n, cin, h, w = x.shape
+    nq = (w + 3) // 4
+    xp = TF.pad(x, (2, 4 * nq - w + 6, 2, 2))
+    d = [xp[:, :, :, j:j + 4 * nq:4] for j in range(8)]                  # d_j = x[4q - 2 + j]
+    e1, o1 = 4 * (d[2] + d[6]) - 17 * d[4], 4 * (d[1] + d[5]) - 17 * d[3]
+    e3, o3 = d[2] - 5 * d[4] + 4 * d[6], d[1] - 5 * d[3] + 4 * d[5]
+    e5, o5 = 4 * d[2] - 5 * d[4] + d[6], 4 * d[1] - 5 * d[3] + d[5]
+    v = torch.stack([(d[0] - d[6]) + 5.25 * (d[4] - d[2]), e1 + o1, e1 - o1, e3 + 2 * o3, e3 - 2 * o3, 2 * e5 + o5, 2 * e5 - o5,
+                     (d[7] - d[1]) + 5.25 * (d[3] - d[5])], dim=-1)     # (n,ci,h+4,quads,8)
+    ncb, nch = pack.shape[0], pack.shape[1]
+    u = pack.permute(0, 5, 1, 4, 2, 3).reshape(ncb * 32, nch * ck, 5, 8)[:cout, :cin]     # (co, ci, ky, t)
+    m = torch.zeros(n, cout, h, nq, 8, dtype=x.dtype)
+    for ky in range(5):
+        m += torch.einsum('nchqt,oct->nohqt', v[:, :, ky:ky + h], u[:, :, ky])
+    a12, s12, a34, s34, a56, s56 = (m[..., 1] + m[..., 2], m[..., 1] - m[..., 2], m[..., 3] + m[..., 4], m[..., 3] - m[..., 4],
+                                    m[..., 5] + m[..., 6], m[..., 5] - m[..., 6])
+    y = torch.stack([m[..., 0] + a12 + a34 + a56, s12 + 2 * s34 + 0.5 * s56, a12 + 4 * a34 + 0.25 * a56,
+                     s12 + 8 * s34 + 0.125 * s56 + m[..., 7]], dim=-1)
+    return y.reshape(n, cout, h, 4 * nq)[..., :w]
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 32), (32, 64), (8, 3), (4, 40)])
+def test_winograd45_pack_forward_and_backward_data(cin, cout):
+    wt = rnd(cout, cin, 5, 5, seed=21)
+    x = rnd(2, cin, 6, 10, seed=22).requires_grad_(True)
+    ref = TF.conv2d(x, wt, None, padding=2)
+    got = wino45_emulate(x.detach(), CN.wino45_weights(wt, False, 4), 4, cout)
+    assert torch.allclose(got, ref.detach(), rtol=1e-9, atol=1e-9)
+    if cout % 4 == 0:
+        gy = rnd(2, cout, 6, 10, seed=23)
+        gref, = torch.autograd.grad(ref, x, gy)
+        got = wino45_emulate(gy, CN.wino45_weights(wt, True, 4), 4, cin)
+        assert torch.allclose(got, gref, rtol=1e-9, atol=1e-9)
