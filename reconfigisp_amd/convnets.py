@@ -176,8 +176,9 @@ class PackedConv:
         elif self.k == 5 and WINOGRAD:
             self.wino_fwd, self.wino_bwd, self.wino_entry = _wino5_pack(w, False), _wino5_pack(w, True), 'risp_conv2d_wino5'
             if WINO_F45:                              # launches with cin % 4 == 0 take F(4,5) (see conv())
-                self.wino45_fwd = wino45_weights(w, False) if self.cin % 4 == 0 else None
-                self.wino45_bwd = wino45_weights(w, True) if self.cout % 4 == 0 else None
+                ok45 = lambda c: c % 4 == 0 or c < 4        # the launch's input channels: whole chunks of 4, or one partial chunk
+                self.wino45_fwd = wino45_weights(w, False) if ok45(self.cin) else None
+                self.wino45_bwd = wino45_weights(w, True) if ok45(self.cout) else None
 
 
 class SmallConv:

@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_glds_kernel(const risp_con
     const int l31 = lane & 31, half = lane >> 5;
     const int x0 = blockIdx.x * W43TW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
     const risp_conv_desc d = risp_conv_group_view(d_in, n);
-    const int nchunks = d.cin / CK;
+    const int nchunks = (d.cin + CK - 1) / CK;         // cin % 4 != 0 only with a single chunk (cin < 4): see the masks below
     const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
     const size_t hw = (size_t)d.H * d.W;
     const float *xn = d.x + (size_t)n * d.cin * hw;
@@ -1070,8 +1070,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_glds_kernel(const risp_con
             const int cl = v / (W45IH * (W43WP / 4)), rem = v - cl * (W45IH * (W43WP / 4));
             const int iy = rem / (W43WP / 4), q = rem - iy * (W43WP / 4);
             const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * q;
-            ok = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-            src0[j] = xn + ((size_t)cl * d.H + gy) * d.W + gx;
+            // (the masks are the same in every chunk; a channel beyond cin exists only when the layer is ONE chunk)
+            ok = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cl < d.cin;
+            src0[j] = xn + ((size_t)(cl < d.cin ? cl : 0) * d.H + gy) * d.W + gx;
             step[j] = CK * (int)hw;
         } else if (id < PIECES) {
             ok = true;
@@ -1305,9 +1306,9 @@ int risp_conv2d_wino45(const risp_conv_desc *dp, void *stream) {
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino45: null tensor");
     RISP_CHECK_GROUP(d, "risp_conv2d_wino45");
-    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cin % 4 == 0 && d.cout > 0 && d.cout <= 64 &&
+    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && (d.cin % 4 == 0 || d.cin < 4) && d.cout > 0 && d.cout <= 64 &&
                        d.ksize == 5 && (size_t)d.N * ((d.cout + 31) / 32) <= 65535,
-                   "risp_conv2d_wino45: needs a 5x5 layer, cin %% 4 == 0, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)",
+                   "risp_conv2d_wino45: needs a 5x5 layer, cin %% 4 == 0 or cin < 4, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)",
                    d.N, d.H, d.W, d.cin, d.cout, d.ksize);
     RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_wino45: only plain loads");
     RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
