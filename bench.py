@@ -370,6 +370,13 @@ def search_step_leg(device, rank, world, global_batch=32, size=256, n_step=2, it
         out.update(one_gpu=one, speedup_vs_one_gpu=round(one['s_per_step'] / out['s_per_step'], 3))
     else:
         out.update(n_gpus=1, per_rank_batch=global_batch, steps_per_s=round(1.0 / one['s_per_step'], 3), **one)
+        if global_batch % 8 == 0 and global_batch >= 8:
+            # what ONE rank of the 8-GPU configuration computes per iteration (its shard of the same global batch), timed on
+            # this GPU without collectives: the compute-side ceiling of the 8-GPU speed-up, NOT a measurement of it
+            sec8, _, _, _ = search_step_times(device, 0, 1, False, global_batch // 8, size, n_step, max(iters, 5))
+            out['rank_of_8_shard'] = {'batch': global_batch // 8, 's_per_step': round(sec8, 4),
+                                      'compute_ceiling_of_8_gpu_speedup': round(sec1 / sec8, 2),
+                                      'note': 'one GPU, no collectives: an upper bound, not an 8-GPU measurement'}
     return out
 
 
