@@ -18,7 +18,7 @@ __device__ __forceinline__ void lds_dma16(const float *src, float *dst_wave_base
                  : "=&s"(keep_m0) : "v"(src), "s"(lds_dst) : "memory");
 }
 
-template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24>
+template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24, bool SPREAD = false>
 __global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restrict__ src, float *__restrict__ dst, float *out, int tiles,
                                                  float seed) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // 2 stages x 6144 floats (24 KB each)
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restri
         for (int ch = 0; ch < 16; ++ch) {
             const float *cur = lds + (ch & 1) * STG;
             if (BAR) __syncthreads();
-            if (DMA) {                                   // the next chunk's tile + weight slab: 24 x 1 KB, 6 per wave
+            if (DMA && !SPREAD) {                        // the next chunk's tile + weight slab: 24 x 1 KB, 6 per wave
                 float *nxt = lds + ((ch + 1) & 1) * STG;
 #pragma unroll
                 for (int j = 0; j < (PIECES + NW - 1) / NW; ++j) {
@@ -79,6 +79,11 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restri
             } else
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
+                if (DMA && SPREAD) {                     // one piece per group, from inside the matrix-instruction stream
+                    float *nxt = lds + ((ch + 1) & 1) * STG;
+                    const int id = wave + NW * g;
+                    if (id < PIECES) lds_dma16(gsrc + (size_t)((ch + 1) & 15) * 6144 + (id % 24) * 256 + lane * 4, nxt + id * 256);
+                }
                 const float4 q0 = *reinterpret_cast<const float4 *>(&cur[(4 * lane + 256 * g) & 4092]);
                 const float4 q1 = *reinterpret_cast<const float4 *>(&cur[(4 * lane + 256 * g + 4) & 4092]);
                 float b6[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restri
     }
 }
 
-template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24>
+template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24, bool SPREAD = false>
 void run(const char *what, const float *src, float *dst, float *out) {
     const int blocks = 256 * (12 / NW) * 2, tiles = 48;
     hipEvent_t e0, e1;
@@ -132,8 +137,8 @@ void run(const char *what, const float *src, float *dst, float *out) {
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&stages<BAR, DMA, TRF, EPI, L2SRC, NW, PIECES>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PIECES * 1024);
-        hipLaunchKernelGGL((stages<BAR, DMA, TRF, EPI, L2SRC, NW, PIECES>), dim3(blocks), dim3(64 * NW), 2 * PIECES * 1024, 0, src, dst, out, tiles, 1.0f);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&stages<BAR, DMA, TRF, EPI, L2SRC, NW, PIECES, SPREAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PIECES * 1024);
+        hipLaunchKernelGGL((stages<BAR, DMA, TRF, EPI, L2SRC, NW, PIECES, SPREAD>), dim3(blocks), dim3(64 * NW), 2 * PIECES * 1024, 0, src, dst, out, tiles, 1.0f);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -169,6 +174,9 @@ int main() {
     run<true, true, 1, true>("+ barrier + LDS-DMA + transform + store epilogue", src, dst, out);
     run<true, true, 2, true>("+ barrier + LDS-DMA + packed transform + epilogue", src, dst, out);
     run<false, false, 0, true>("matrix stream + store epilogue", src, dst, out);
+    run<true, true, 0, false, false, 4, 24, true>("+ barrier + LDS-DMA, one piece per group (spread)", src, dst, out);
+    run<true, true, 1, false, false, 4, 24, true>("+ barrier + LDS-DMA spread + input transform", src, dst, out);
+    run<true, true, 1, true, false, 4, 24, true>("+ barrier + LDS-DMA spread + transform + epilogue", src, dst, out);
     // one 12-wave workgroup per CU instead of three 4-wave ones: a 12-row tile and ONE weight slab = 40 pieces per chunk
     run<true, true, 1, true, false, 12, 40>("12-wave workgroup, 40 pieces / chunk, everything", src, dst, out);
     run<true, true, 1, false, false, 12, 40>("12-wave workgroup, 40 pieces / chunk, no epilogue", src, dst, out);
