@@ -18,6 +18,7 @@
 // [12][CK][cout] are staged in ping-pong LDS buffers; the global loads of the next chunk are issued from inside
 // the MFMA stream.  The B operands of the four transform points come from ONE pair of LDS reads (d0..d3) and
 // four vector subtractions/additions.
+#include <cstdlib>
 #include "risp_common.h"
 
 #ifndef RISP_W43G_ABL
@@ -938,6 +939,137 @@ __global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_c
 }
 
 // ---------------------------------------------------------------------------------------------------
+// F(4,3), BOTH cout blocks of a 33..64-cout layer in one wave (round 3).  tools/mfma_valu.hip: a vector instruction beside
+// the fp32 matrix stream costs its own 4-5 cycles of matrix time whatever the tile form (the fp32 matrix and vector
+// pipes do not overlap), and an LDS-DMA piece ~60; so what is worth halving is the work PER MATRIX INSTRUCTION.  Here a
+// wave keeps 12 accumulator tiles (one output row of 128 pixels x 64 couts): the transformed B operands of a group
+// (14 vector instructions) now feed 12 matrix instructions instead of 6, and the input tile is staged once per 64 couts
+// (13 + 2 x 9 = 31 pieces per chunk where two workgroups of conv_wino43_glds_kernel take 48).  192 accumulator registers:
+// two workgroups per CU, so the operand registers are kept to one set - the A operands of the second cout block are read
+// while the first block's six matrix instructions run, the next group's rows and first-block A operands during the
+// second's.  Same packed weights, same arithmetic per output as conv_wino43_glds_kernel: bit-identical results.
+#ifndef RISP_W43_B2
+#define RISP_W43_B2 1
+#endif
+#ifndef RISP_W43_B2_EB
+#define RISP_W43_B2_EB 1       // epilogue prefetch depth of cout block 0 (all 192 accumulator registers still live)
+#endif
+#ifndef RISP_W43_B2_EB1
+#define RISP_W43_B2_EB1 4      // ... of cout block 1 (block 0's accumulators are dead by then)
+#endif
+__global__ __launch_bounds__(256, 2) void conv_wino43_b2_kernel(const risp_conv_desc d) {
+    constexpr int CK = 4, CP = 32;
+    constexpr int XN = CK * WIH * W43WP, WN = W43TAPS * CK * CP;       // floats: 3264, 2304
+    constexpr int XI = 13, WI = 9, NP = XI + 2 * WI, PER_WAVE = (NP + 3) / 4;       // 31 wave-instructions per chunk
+    constexpr int STAGE = NP * 256;                                     // floats per stage: tile pieces, slab of block 0, slab of block 1
+    static_assert(XN <= XI * 256 && WN == WI * 256, "staging layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // [2][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int x0 = blockIdx.x * W43TW, y0 = blockIdx.y * WTH, n = blockIdx.z;
+    const int nchunks = d.cin / CK;
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+
+    f32x16 acc[2][6];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][t][e] = 0.f;
+
+    // zero the input-tile part of both stages once: lanes outside the image are masked out of every DMA and keep it
+    for (int v = tid; v < 2 * XI * 64; v += 256)
+        reinterpret_cast<float4 *>(smem + (v >= XI * 64 ? STAGE - XI * 256 : 0))[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float *src0[PER_WAVE];
+    unsigned long long mask[PER_WAVE];
+    int step[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int id = wave + 4 * j;
+        bool ok;
+        if (id < XI) {
+            const int v = id * 64 + lane;
+            const int cl = v / (WIH * (W43WP / 4)), rem = v - cl * (WIH * (W43WP / 4));
+            const int iy = rem / (W43WP / 4), q = rem - iy * (W43WP / 4);
+            const int gy = y0 + iy - 1, gx = x0 - 4 + 4 * q;
+            ok = v < XN / 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            src0[j] = xn + ((size_t)cl * d.H + gy) * d.W + gx;
+            step[j] = CK * (int)hw;
+        } else {
+            const int wb = id - XI < WI ? 0 : 1;                       // cout block of this slab piece
+            ok = id < NP;
+            src0[j] = d.wpack + (size_t)wb * nchunks * WN + 4 * ((id - XI - wb * WI) * 64 + lane);
+            step[j] = WN;
+        }
+        mask[j] = __builtin_amdgcn_ballot_w64(ok);
+    }
+    auto issue = [&](int ch, int buf) {
+        float *stage = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int id = wave + 4 * j;
+            if (id < NP) lds_dma16(src0[j] + (size_t)ch * step[j], stage + id * 256, mask[j]);      // wave-uniform guard (piece 31 does not exist)
+        }
+    };
+
+    __syncthreads();                                   // zeros in place before the first DMA lands
+    issue(0, 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's pieces of chunk ch have landed
+        __builtin_amdgcn_s_barrier();                  // ... every wave's; the other stage is free
+        if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
+        const float *sx = smem + buf * STAGE, *sw = sx + XI * 256;
+        const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (half * WIH + wave) * W43WP) + l31;
+        const float *aw = sw + half * CP + l31;
+        constexpr int NG = 3 * (CK / 2);
+        float opa[2][6];
+        f32x4 opd[3];
+        auto load_rows = [&](int g) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+            const f32x4 *dp = bx + (2 * cp * WIH + ky) * (W43WP / 4);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) opd[j] = dp[j];
+        };
+        auto load_a = [&](int g, int b) {
+            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) opa[b][t] = aw[b * WN + ((ky * 6 + t) * CK + 2 * cp) * CP];
+        };
+        load_rows(0);
+        load_a(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            load_a(g, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(opd[0]), "+v"(opd[2]));
+            const float d0 = opd[0].w, d1 = opd[1].x, d2 = opd[1].y, d3 = opd[1].z, d4 = opd[1].w, d5 = opd[2].x;
+            const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
+            const float bv[6] = {__builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4)), __builtin_fmaf(4.f, s12, -s34),
+                                 __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
+                                 __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[0][t], bv[t], acc[0][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NG) {
+                load_rows(g + 1);
+                load_a(g + 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[1][t], bv[t], acc[1][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    w43_epilogue<RISP_W43_B2_EB>(d, acc[0], n, 0, y0 + wave, x0 + 4 * l31, half);
+    w43_epilogue<RISP_W43_B2_EB1>(d, acc[1], n, 1, y0 + wave, x0 + 4 * l31, half);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // F(4,5) along x with LDS-DMA staging (round 3): four outputs of a 5-tap filter row from 8 products - 40 "taps" per pixel
 // QUAD where F(2,5) issues 30 per pixel PAIR, i.e. 2/3 of its matrix instructions (SRCNNRes' 64 -> 32 layer and its
 // backward are a third of a search step, srcnn_res_arch.py:20).  Interpolation points 0, +-1, +-2, +-1/2, inf; the row
@@ -1223,6 +1355,12 @@ int risp_conv2d_wino43(const risp_conv_desc *dp, void *stream) {
     constexpr int XN = W43CK * WIH * W43WP, WN = W43TAPS * W43CK * 32;
     dim3 grid((d.W + W43TW - 1) / W43TW, (d.H + WTH - 1) / WTH, d.N * ncb);
 #ifndef RISP_W43_NO_GLDS
+    static const bool b2 = [] { const char *e = getenv("RISP_W43_B2"); return e ? atoi(e) != 0 : RISP_W43_B2 != 0; }();   // A/B switch (tools/ab_env.sh)
+    if (b2 && d.cin % 4 == 0 && ncb == 2) {            // both cout blocks per wave: 12 accumulator tiles, 2 workgroups per CU
+        hipLaunchKernelGGL(conv_wino43_b2_kernel, dim3(grid.x, grid.y, d.N), dim3(256), sizeof(float) * 2 * 31 * 256, (hipStream_t)stream, d);
+        RISP_LAUNCH_CHECK("risp_conv2d_wino43");
+        return 0;
+    }
     if (d.cin % 4 == 0) {                              // LDS-DMA staging, 2 LDS stages, 3 workgroups per CU (see the kernel)
 #ifndef RISP_W43_GLDS
 #define RISP_W43_GLDS 2

@@ -315,6 +315,40 @@ def test_inference_dispatch_f43(cin, cout, hw, monkeypatch):
                      what='mask infer=%s' % infer)
 
 
+@pytest.mark.parametrize('cout', [64, 33])
+@pytest.mark.parametrize('hw', [(8, 8), (20, 36), (33, 32), (64, 256), (6, 260)])
+def test_f43_both_cout_blocks_in_one_wave_equals_per_block_launches(cout, hw):
+    """conv_wino43_b2_kernel keeps both 32-cout blocks of a 33..64-cout layer in one wave (one input transform feeds twelve
+    matrix instructions); per output it performs the one-block kernel's arithmetic in the same order, so the layer launched
+    as two separate 32-cout layers (the one-block kernel) must give the same bits - forward and backward-data packs, every
+    epilogue."""
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n, cin = 3, 64
+    wt, b = rnd(cout, cin, 3, 3, seed=81) * 0.05, rnd(cout, seed=82) * 0.1
+    x, add, mask = rnd(n, cin, h, w, seed=83), rnd(n, cout, h, w, seed=84), rnd(n, cout, h, w, seed=85)
+    whole = CN.PackedConv(wt, b)
+    parts = [(CN.PackedConv(wt[lo:hi].contiguous(), b[lo:hi].contiguous()), lo, hi) for lo, hi in ((0, 32), (32, cout))]
+    for kw in (dict(), dict(epi=CN.EPI_RELU), dict(epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=cout), dict(epi=CN.EPI_MASK, mask=mask)):
+        y = CN.conv(x, whole, n, h, w, infer=True, **kw)
+        for pc, lo, hi in parts:
+            kws = dict(kw)
+            if 'add' in kws:
+                kws.update(add=add[:, lo:hi].contiguous(), add_c=hi - lo)
+            if 'mask' in kws:
+                kws.update(mask=mask[:, lo:hi].contiguous())
+            yp = CN.conv(x, pc, n, h, w, infer=True, **kws)
+            assert torch.equal(y[:, lo:hi], yp), 'forward %s couts %d..%d' % (kw.get('epi'), lo, hi)
+    if cout == 64:                                        # backward-data of a cin-64 layer with 64 couts is a 64 -> 64 layer again
+        gy = rnd(n, cout, h, w, seed=86)
+        gx = CN.conv(gy, whole, n, h, w, transpose=True, epi=CN.EPI_MASK, mask=x)
+        wt_t = wt.flip(2, 3).transpose(0, 1).contiguous()                    # the same backward-data as a forward layer
+        for lo, hi in ((0, 32), (32, 64)):
+            pc = CN.PackedConv(wt_t[lo:hi].contiguous(), torch.zeros(hi - lo, device='cuda'))
+            gp = CN.conv(gy, pc, n, h, w, infer=True, epi=CN.EPI_MASK, mask=x[:, lo:hi].contiguous())
+            assert torch.equal(gx[:, lo:hi], gp), 'backward-data cins %d..%d' % (lo, hi)
+
+
 # ---------------------------------------------------------------------------------------------------
 # randomized layer shapes through the dispatching wrappers (direct / F(2,3) / F(4,3) / F(2,5) / small-cout kernels)
 import os
