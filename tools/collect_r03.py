@@ -32,13 +32,14 @@ vals = dict(re.findall(r'(\w+)\s+avg/launch\s+(\d+)', pmc))
 us = re.search(r'kernel avg us ([\d.]+)', pmc)
 busy = float(vals['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024 / (float(vals['GRBM_GUI_ACTIVE']) / 8)
 open('profiles/r03_conv3x3_64to64_pmc.txt', 'w').write(
-    '# tools/conv_pmc.sh r03 (conv_wino43_glds_kernel<2,3>, 64->64 3x3 on 64 x 128 x 128, MI355X; profiled runs are serialised and slower than back-to-back launches).\n'
-    "# The kernel is unchanged since round 2 (the 8-wave both-cout-blocks variant of round 3 was slower and is not kept, DESIGN.md 4.3a'').\n" + pmc + '''
+    '# tools/conv_pmc.sh r03 (conv_wino43_b2_kernel, 64->64 3x3 on 64 x 128 x 128, MI355X; profiled runs are serialised and slower than back-to-back launches).\n'
+    "# Round 3's two-block kernel (DESIGN.md 4.3a'''): both cout blocks of the layer in one wave, 12 accumulator tiles, two workgroups per CU.\n" + pmc + '''
 # derived: matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) = %.3f (r02: 0.676, r01: 0.563); LDS bank conflicts %s;
 #          the counter is 64 cycles x 9 437 184 MFMA instructions; GRBM_GUI_ACTIVE / 8 / %s us = %.2f GHz under the profiler.
-#          Back to back in one process (tools/ab_wino43.py, round 3): 360-365 us = 106-107 issued TFLOP/s = 0.68 of the 157.3 TFLOP/s nameplate.
-#          Why not more: profiles/r03_mfma_ceiling.txt - the bare instruction stream of this loop runs 147 TFLOP/s at 2.38 GHz; its 6 LDS-DMA
-#          pieces per wave and chunk cost 16 %%, its 14-fma input transform 15 %%, both 23 %%, the store epilogue 5 %% more = 107 TFLOP/s.
+#          Back to back in one process (tools/ab_wino43.py, round 3): 350 us on this shape (one-block kernel 364), 684 us on 32 x 256 x 256 (733)
+#          = 110-113 issued TFLOP/s = 0.70-0.72 of the 157.3 TFLOP/s nameplate.  SQ_INSTS_VALU 41.0M (one-block kernel 59.5M): the input transform now
+#          feeds twelve matrix instructions.  Why not more: profiles/r03_mfma_ceiling.txt - every vector instruction costs its 4-5 cycles and every
+#          LDS-DMA piece ~60 cycles of matrix time (the fp32 matrix and vector pipes do not overlap), the store epilogue ~5-10 %%.
 ''' % (busy, vals.get('SQ_LDS_BANK_CONFLICT', '?'), us.group(1), float(vals['GRBM_GUI_ACTIVE']) / 8 / float(us.group(1)) / 1e3))
 if os.path.exists('gpurun_out/ops_r03/summary.txt'):
     shutil.copy('gpurun_out/ops_r03/summary.txt', 'profiles/r03_ops_kernel_stats.txt')
