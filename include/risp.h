@@ -281,11 +281,14 @@ int risp_conv_k3_cout_block(int cin, int ksize);
 size_t risp_conv_k3_wpack_floats(int cin, int cout, int ksize);
 int risp_conv2d_k3(const risp_conv_desc *d, void *stream);
 
-/* 5x5 layers with F(4,5) along x (0.4 of the matrix-core work of risp_conv2d, 2/3 of risp_conv2d_wino5): wpack [cout block of
- * 32][chunk of 4 cin][ky][t][ci][32] with U_t = (G g)_t / s_t, G rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16)
- * (1,-2,4,-8,16) (1,1/2,1/4,1/8,1/16) (1,-1/2,1/4,-1/8,1/16) (0,0,0,0,1), s = (1, -18, -18, 360, 360, 45/16, 45/16, 1),
- * applied to filter row g = w[co][ci][ky][0..4].  cin % 4 == 0 or cin < 4; otherwise the restrictions of risp_conv2d_wino3. */
+/* 5x5 layers with F(4,5) along x (0.4 of the matrix-core work of risp_conv2d, 2/3 of risp_conv2d_wino5): U_t = (G g)_t / s_t,
+ * G rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16) (1,-2,4,-8,16) (1,1/2,1/4,1/8,1/16) (1,-1/2,1/4,-1/8,1/16)
+ * (0,0,0,0,1), s = (1, -18, -18, 360, 360, 45/16, 45/16, 1), applied to filter row g = w[co][ci][ky][0..4].  wpack, as
+ * risp_conv_wino45_layout() says: 0 = [cout block of 32][chunk of 4 cin][ky][t][ci][32]; 1 = [cout block of 32][chunk of 4 cin]
+ * [ky][point group 2][cout block of 16: 2][ci 4][cout 16][4 points] (the kernel with two output rows per wave).  cin % 4 == 0 or
+ * cin < 4; otherwise the restrictions of risp_conv2d_wino3. */
 int risp_conv_wino45_chunk(void);
+int risp_conv_wino45_layout(void);
 size_t risp_conv_wino45_wpack_floats(int cin, int cout);
 int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
 

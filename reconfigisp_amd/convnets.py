@@ -88,14 +88,27 @@ _W45_G = ((1, 0, 0, 0, 0), (1, 1, 1, 1, 1), (1, -1, 1, -1, 1), (1, 2, 4, 8, 16),
 _W45_S = (1., -18., -18., 360., 360., 45. / 16., 45. / 16., 1.)
 
 
-def wino45_weights(w, transpose, ck=4):
-    """[cout block of 32][chunk of ``ck`` cin][ky][t][ci][32] Winograd F(4,5)-along-x weights of a 5x5 layer
-    (include/risp.h: risp_conv2d_wino45).  Pure tensor algebra (computed in fp64, stored in the dtype of ``w``)."""
+def wino45_weights(w, transpose, ck=4, layout=None):
+    """Winograd F(4,5)-along-x weights of a 5x5 layer (include/risp.h: risp_conv2d_wino45), pure tensor algebra computed in
+    fp64 and stored in the dtype of ``w``.  ``layout`` (default: what the library's kernel reads, ``risp_conv_wino45_layout``):
+    0 = [cout block of 32][chunk of 4 cin][ky][t][ci][32]; 1 = [cout block of 32][chunk of 4 cin][ky][point group 2]
+    [cout block of 16: 2][ci 4][cout 16][4 points] (the two-rows-per-wave kernel: one ds_read_b128 = the A operands of four points)."""
     if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
         w = w.flip(2, 3).transpose(0, 1)
     g = torch.tensor(_W45_G, dtype=torch.float64, device=w.device) / torch.tensor(_W45_S, dtype=torch.float64,
                                                                                   device=w.device)[:, None]
-    return _wino_blocked_pack(torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype), ck)
+    u = torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype)              # (co, ci, ky, t)
+    if layout is None:
+        layout = L.load().risp_conv_wino45_layout()
+    if layout == 0:
+        return _wino_blocked_pack(u, ck)
+    assert ck == 4
+    co, ci = u.shape[0], u.shape[1]
+    ncb, nch = (co + 31) // 32, (ci + 3) // 4
+    p = torch.zeros((ncb * 32, nch * 4, 5, 8), device=u.device, dtype=u.dtype)
+    p[:co, :ci] = u
+    #        (ncb, mb, m, nch, k, ky, pg, pt) -> (ncb, nch, ky, pg, mb, k, m, pt)
+    return p.view(ncb, 2, 16, nch, 4, 5, 2, 4).permute(0, 3, 5, 6, 1, 4, 2, 7).contiguous()
 
 
 WINO_F45 = os.environ.get('RISP_WINO_F45', '1') != '0'       # 5x5: F(4,5) where cin % 4 == 0 (default), else F(2,5)

@@ -1266,6 +1266,217 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_glds_kernel(const risp_con
     w45_epilogue<4>(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// F(4,5) with TWO output rows per wave on 16x16x4 tiles (round 3).  A vector instruction costs its own 4-5 cycles of matrix
+// time (tools/mfma_valu.hip) and F(4,5)'s input transform is 26 of them per staged row: in conv_wino45_glds_kernel a wave
+// owns one output row and transforms the 5 input rows under it - 26 x 5 per 5 x 8 matrix instructions of 64 cycles, ~23 %
+// on top of the matrix time.  Here the wave owns two output rows x 64 pixels x 32 couts (v_mfma_f32_16x16x4_f32: 2 rows x
+// 8 points x 2 cout blocks of 16 = 32 accumulator tiles of 4 registers) and walks its SIX input rows once: each
+// transformed row feeds output row 0 with filter row ky = i and output row 1 with ky = i - 1, 26 x 6 vector instructions
+// per 160 matrix instructions of 32 cycles - 40 % fewer per matrix cycle.  Same workgroup tile (4 rows x 128 pixels), same
+// staging (17 + 20 LDS-DMA pieces per 4-channel chunk), same interpolation points and output transform; K = 4 per
+// instruction instead of 2 + 2, so results differ from the one-row kernel by fp32 rounding only.
+// Weight slab of a chunk (risp.h, layout 1): [ky 5][point group 2][cout block of 16: 2][cin 4][cout 16][4 points] - a lane
+// (cout m = lane & 15, cin k = lane >> 4) reads the A operands of four points with one conflict-free ds_read_b128.
+#ifndef RISP_W45_R2
+#define RISP_W45_R2 1
+#endif
+template <int EB>
+__device__ __forceinline__ void w45r2_epilogue(const risp_conv_desc &d, const f32x4 (&acc)[2][8][2], int n, int cb, int oy0, int ox,
+                                               int kk) {
+    if (!(oy0 < d.H && ox < d.W)) return;
+    const int epi = d.epilogue;
+    const size_t hw = (size_t)d.H * d.W;
+    const bool has_add = (epi & RISP_EPI_ADD) != 0, has_mask = (epi & RISP_EPI_MASK) != 0;
+    // item i = (rr * 2 + mb) * 4 + e: output row oy0 + rr, cout cb * 32 + mb * 16 + 4 * kk + e
+    auto co_of = [&](int i) { return cb * 32 + ((i >> 2) & 1) * 16 + 4 * kk + (i & 3); };
+    auto pix_of = [&](int i) {
+        const int oy = oy0 + (i >> 3);
+        return (size_t)(oy < d.H ? oy : d.H - 1) * d.W + ox;                // clamped: always a valid address
+    };
+    float bias[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int co = co_of(j);
+        bias[j] = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co < d.cout ? co : d.cout - 1];
+    }
+    float4 av[2][EB], mv[2][EB];
+    auto load_batch = [&](int b, int slot) {
+        if (has_add) {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                const int i = EB * b + j, co = co_of(i);
+                av[slot][j] = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + (co < d.add_c ? co : d.add_c - 1)) * hw + pix_of(i));
+            }
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                const int i = EB * b + j, co = co_of(i);
+                mv[slot][j] = *reinterpret_cast<const float4 *>(d.mask + ((size_t)n * d.cout + (co < d.cout ? co : d.cout - 1)) * hw + pix_of(i));
+            }
+        }
+    };
+    load_batch(0, 0);
+#pragma unroll
+    for (int b = 0; b < 16 / EB; ++b) {
+        const int slot = b & 1;
+        if (b + 1 < 16 / EB) load_batch(b + 1, slot ^ 1);
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const int i = EB * b + j, rr = i >> 3, mb = (i >> 2) & 1, e = i & 3, co = co_of(i);
+            const float m0 = acc[rr][0][mb][e], m1 = acc[rr][1][mb][e], m2 = acc[rr][2][mb][e], m3 = acc[rr][3][mb][e],
+                        m4 = acc[rr][4][mb][e], m5 = acc[rr][5][mb][e], m6 = acc[rr][6][mb][e], m7 = acc[rr][7][mb][e];
+            const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4, a56 = m5 + m6, s56 = m5 - m6;
+            const float bb = bias[i & 7];
+            float4 o = make_float4(m0 + a12 + a34 + a56 + bb, s12 + 2.f * s34 + 0.5f * s56 + bb, a12 + 4.f * a34 + 0.25f * a56 + bb,
+                                   s12 + 8.f * s34 + 0.125f * s56 + m7 + bb);
+            if (has_add && co < d.add_c) {
+                const float4 a = av[slot][j];
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            if (epi & RISP_EPI_RELU) {
+                o.x = o.x > 0.f ? o.x : 0.f;
+                o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f;
+                o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            if (has_mask) {
+                const float4 m = mv[slot][j];
+                o.x = m.x > 0.f ? o.x : 0.f;
+                o.y = m.y > 0.f ? o.y : 0.f;
+                o.z = m.z > 0.f ? o.z : 0.f;
+                o.w = m.w > 0.f ? o.w : 0.f;
+            }
+            if (co < d.cout && oy0 + rr < d.H) *reinterpret_cast<float4 *>(d.y + ((size_t)n * d.cout + co) * hw + pix_of(i)) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino45_r2_kernel(const risp_conv_desc d_in, int ncb) {
+    constexpr int CK = 4, CP = 32;
+    constexpr int XN = CK * W45IH * W43WP, WN = W45TAPS * CK * CP;      // floats: 4352, 5120
+    constexpr int XI = XN / 256, WI = WN / 256, PIECES = XI + WI, PER_WAVE = (PIECES + 3) / 4;     // 17 + 20 wave-instructions per chunk
+    constexpr int STAGE = PIECES * 256;
+    static_assert(XN % 256 == 0 && WN % 256 == 0, "staging layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // [2][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 15, kk = lane >> 4, rp = wave >> 1, xh = wave & 1;
+    const int x0 = blockIdx.x * W43TW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
+    const risp_conv_desc d = risp_conv_group_view(d_in, n);
+    const int nchunks = (d.cin + CK - 1) / CK;         // cin % 4 != 0 only with a single chunk (cin < 4): see the masks below
+    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
+    const size_t hw = (size_t)d.H * d.W;
+    const float *xn = d.x + (size_t)n * d.cin * hw;
+
+    f32x4 acc[2][8][2];                                 // [output row][point][cout block of 16]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[r][t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // zero the input-tile part of both stages once (lanes outside the image are masked out of every transfer and keep it)
+    for (int v = tid; v < 2 * XI * 64; v += 256)
+        reinterpret_cast<float4 *>(smem + (v >= XI * 64 ? STAGE - XI * 256 : 0))[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float *src0[PER_WAVE];
+    unsigned long long mask[PER_WAVE];
+    int step[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int id = wave + 4 * j;
+        bool ok = false;
+        src0[j] = xn;
+        step[j] = 0;
+        if (id < XI) {
+            const int v = id * 64 + lane;
+            const int cl = v / (W45IH * (W43WP / 4)), rem = v - cl * (W45IH * (W43WP / 4));
+            const int iy = rem / (W43WP / 4), qq = rem - iy * (W43WP / 4);
+            const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * qq;
+            ok = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cl < d.cin;
+            src0[j] = xn + ((size_t)(cl < d.cin ? cl : 0) * d.H + gy) * d.W + gx;
+            step[j] = CK * (int)hw;
+        } else if (id < PIECES) {
+            ok = true;
+            src0[j] = wpack + 4 * ((id - XI) * 64 + lane);
+            step[j] = WN;
+        }
+        mask[j] = __builtin_amdgcn_ballot_w64(ok);
+    }
+    auto issue = [&](int ch, int buf) {
+        float *stage = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int id = wave + 4 * j;
+            if (id < PIECES) lds_dma16(src0[j] + (size_t)ch * step[j], stage + id * 256, mask[j]);     // wave-uniform branch
+        }
+    };
+
+    __syncthreads();                                   // zeros in place before the first DMA lands
+    if (nchunks > 0) issue(0, 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's transfers of chunk ch have landed
+        __builtin_amdgcn_s_barrier();                  // ... for every wave; the other stage is free
+        if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
+        const float *sx = smem + buf * STAGE;
+        // the lane's channel kk, quad 16 xh + q: staged row 2 rp + i, 16-byte slots Q, Q + 1, Q + 2 (d_j = x[4 Q - 2 + j] = slot value 2 + j)
+        const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (kk * W45IH + 2 * rp) * W43WP) + 16 * xh + q;
+        const f32x4 *aw = reinterpret_cast<const f32x4 *>(sx + XN) + lane;          // [ky][point group][cout block][64 lanes] x 4 points
+        f32x4 opa[2][2][2];                              // [set][point group][cout block]: filter rows ky = i (set i & 1) and i - 1
+        f32x4 opd[3];
+        auto load_row = [&](int i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) opd[j] = bx[i * (W43WP / 4) + j];
+        };
+        auto load_a = [&](int ky) {
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) opa[ky & 1][pg][b] = aw[((ky * 2 + pg) * 2 + b) * 64];
+        };
+        load_row(0);
+        load_a(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(opd[0]), "+v"(opd[2]));
+            const float d0 = opd[0].z, d1 = opd[0].w, d2 = opd[1].x, d3 = opd[1].y, d4 = opd[1].z, d5 = opd[1].w, d6 = opd[2].x,
+                        d7 = opd[2].y;
+            const float e1 = __builtin_fmaf(4.f, d2 + d6, -17.f * d4), o1 = __builtin_fmaf(4.f, d1 + d5, -17.f * d3);
+            const float e3 = __builtin_fmaf(4.f, d6, __builtin_fmaf(-5.f, d4, d2)), o3 = __builtin_fmaf(4.f, d5, __builtin_fmaf(-5.f, d3, d1));
+            const float e5 = __builtin_fmaf(4.f, d2, __builtin_fmaf(-5.f, d4, d6)), o5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+            const float bv[8] = {__builtin_fmaf(5.25f, d4 - d2, d0 - d6), e1 + o1, e1 - o1, __builtin_fmaf(2.f, o3, e3),
+                                 __builtin_fmaf(-2.f, o3, e3), __builtin_fmaf(2.f, e5, o5), __builtin_fmaf(2.f, e5, -o5),
+                                 __builtin_fmaf(5.25f, d3 - d5, d7 - d1)};
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < 6) load_row(i + 1);              // the raw row is consumed: the next one lands during the matrix instructions
+            __builtin_amdgcn_sched_barrier(0);
+            if (i >= 1) {                                // output row 1, filter row ky = i - 1
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[1][t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[(i - 1) & 1][t >> 2][b][t & 3], bv[t], acc[1][t][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < 5) load_a(i + 1);                // into the set ky = i - 1 just left
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 5) {                                 // output row 0, filter row ky = i
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[0][t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(opa[i & 1][t >> 2][b][t & 3], bv[t], acc[0][t][b], 0, 0, 0);
+            }
+        }
+    }
+    w45r2_epilogue<4>(d, acc, n, cb, y0 + 2 * rp, x0 + 4 * (16 * xh + q), kk);
+}
+
 template <int CK, int CB>
 int launch_wino(const risp_conv_desc &d, hipStream_t s) {
     constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * 32 * CB;
@@ -1435,6 +1646,8 @@ int risp_conv2d_wino5(const risp_conv_desc *dp, void *stream) {
 
 int risp_conv_wino45_chunk(void) { return 4; }
 
+int risp_conv_wino45_layout(void) { return RISP_W45_R2 ? 1 : 0; }
+
 size_t risp_conv_wino45_wpack_floats(int cin, int cout) {
     return (size_t)((cout + 31) / 32) * ((cin + 3) / 4) * W45TAPS * 4 * 32;
 }
@@ -1459,13 +1672,13 @@ int risp_conv2d_wino45(const risp_conv_desc *dp, void *stream) {
                    "risp_conv2d_wino45: tensors must be 16-byte aligned");
     const int ncb = (d.cout + 31) / 32;
     const size_t lds = sizeof(float) * 2 * (4 * W45IH * W43WP + W45TAPS * 4 * 32);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino45_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
+    const auto kernel = RISP_W45_R2 ? &conv_wino45_r2_kernel : &conv_wino45_glds_kernel;      // the two read different slab layouts
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         risp_set_error("risp_conv2d_wino45: cannot raise the dynamic LDS limit to %zu bytes", lds);
         return 2;
     }
     dim3 grid((d.W + W43TW - 1) / W43TW, (d.H + WTH - 1) / WTH, d.N * ncb);
-    hipLaunchKernelGGL(conv_wino45_glds_kernel, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
     RISP_LAUNCH_CHECK("risp_conv2d_wino45");
     return 0;
 }

@@ -129,6 +129,7 @@ SIGNATURES = {
     'risp_conv_wino5_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino5': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wino45_chunk': (_i, []),
+    'risp_conv_wino45_layout': (_i, []),
     'risp_conv_wino45_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino45': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wgrad_scratch_floats': (_z, [_i]),

@@ -171,7 +171,7 @@ def test_srcnn_broadcast_planes_fold(P, hw):
     assert torch.allclose(got, gref, rtol=1e-10, atol=1e-10)
 
 
-def wino45_emulate(x, pack, ck, cout):
+def wino45_emulate(x, pack, ck, cout, layout=0):
     """What conv_wino45_glds_kernel computes from its pack: F(4,5), four outputs per quad from 8 products per filter row
     (the input transform and the output combination exactly as the kernel writes them)."""
     n, cin, h, w = x.shape
@@ -184,7 +184,10 @@ def wino45_emulate(x, pack, ck, cout):
     v = torch.stack([(d[0] - d[6]) + 5.25 * (d[4] - d[2]), e1 + o1, e1 - o1, e3 + 2 * o3, e3 - 2 * o3, 2 * e5 + o5, 2 * e5 - o5,
                      (d[7] - d[1]) + 5.25 * (d[3] - d[5])], dim=-1)     # (n,ci,h+4,quads,8)
     ncb, nch = pack.shape[0], pack.shape[1]
-    u = pack.permute(0, 5, 1, 4, 2, 3).reshape(ncb * 32, nch * ck, 5, 8)[:cout, :cin]     # (co, ci, ky, t)
+    if layout == 0:                                 # [cb][chunk][ky][t][ci][32]
+        u = pack.permute(0, 5, 1, 4, 2, 3).reshape(ncb * 32, nch * ck, 5, 8)[:cout, :cin]     # (co, ci, ky, t)
+    else:                                           # [cb][chunk][ky][point group][cout block of 16][ci][cout 16][4 points]
+        u = pack.permute(0, 4, 6, 1, 5, 2, 3, 7).reshape(ncb * 32, nch * ck, 5, 8)[:cout, :cin]
     m = torch.zeros(n, cout, h, nq, 8, dtype=x.dtype)
     for ky in range(5):
         m += torch.einsum('nchqt,oct->nohqt', v[:, :, ky:ky + h], u[:, :, ky])
@@ -200,10 +203,11 @@ def test_winograd45_pack_forward_and_backward_data(cin, cout):
     wt = rnd(cout, cin, 5, 5, seed=21)
     x = rnd(2, cin, 6, 10, seed=22).requires_grad_(True)
     ref = TF.conv2d(x, wt, None, padding=2)
-    got = wino45_emulate(x.detach(), CN.wino45_weights(wt, False, 4), 4, cout)
-    assert torch.allclose(got, ref.detach(), rtol=1e-9, atol=1e-9)
-    if cout % 4 == 0 or cout < 4:
-        gy = rnd(2, cout, 6, 10, seed=23)
-        gref, = torch.autograd.grad(ref, x, gy)
-        got = wino45_emulate(gy, CN.wino45_weights(wt, True, 4), 4, cin)
-        assert torch.allclose(got, gref, rtol=1e-9, atol=1e-9)
+    for layout in (0, 1):                           # the one-row kernel's slab and the two-row kernel's
+        got = wino45_emulate(x.detach(), CN.wino45_weights(wt, False, 4, layout), 4, cout, layout)
+        assert torch.allclose(got, ref.detach(), rtol=1e-9, atol=1e-9)
+        if cout % 4 == 0 or cout < 4:
+            gy = rnd(2, cout, 6, 10, seed=23)
+            gref, = torch.autograd.grad(ref, x, gy, retain_graph=True)
+            got = wino45_emulate(gy, CN.wino45_weights(wt, True, 4, layout), 4, cin, layout)
+            assert torch.allclose(got, gref, rtol=1e-9, atol=1e-9)

@@ -57,13 +57,13 @@ print('%-58s %9s %8s %8s %8s' % ('layer (kernel)', 'us', 'TFLOP/s', 'of peak', '
 rows = [
     ('9x9 3->64 forward, case table + ReLU (conv_lin_kernel)', 2 * 244 * 64, 4 * (3 / G + 64),
      lambda: CN.conv(x, img, n, h, w, epi=CN.EPI_RELU | CN.EPI_CASEBIAS, cvals=table, group=(G, L.GROUP_SHARED_X))),
-    ('5x5 64->32 forward F(4,5) (conv_wino45_glds_kernel)', 2 * 10 * 64 * 32, 4 * (64 + 32),
+    ('5x5 64->32 forward F(4,5) (conv_wino45_r2_kernel)', 2 * 10 * 64 * 32, 4 * (64 + 32),
      lambda: CN.conv(t1, c2s, n, h, w, epi=CN.EPI_RELU, group=(G, 0))),
     ('5x5 32->3 forward + residual (conv_small_kernel<5>)', 2 * 25 * 32 * 4, 4 * (32 + 3 / G + 3),
      lambda: CN.conv_small(t2, tail, n, h, w, epi=CN.EPI_ADD, add=x, add_c=3, group=(G, L.GROUP_SHARED_ADD))),
-    ('5x5 3->32 backward-data + mask F(4,5) (conv_wino45_glds_kernel)', 2 * 10 * 4 * 32, 4 * (3 + 32 + 32),
+    ('5x5 3->32 backward-data + mask F(4,5) (conv_wino45_r2_kernel)', 2 * 10 * 4 * 32, 4 * (3 + 32 + 32),
      lambda: CN.conv(gy, c3s, n, h, w, transpose=True, epi=CN.EPI_MASK, mask=t2, group=(G, 0))),
-    ('5x5 32->64 backward-data + mask F(4,5) (conv_wino45_glds)', 2 * 10 * 32 * 64, 4 * (32 + 64 + 64),
+    ('5x5 32->64 backward-data + mask F(4,5) (conv_wino45_r2_kernel)', 2 * 10 * 32 * 64, 4 * (32 + 64 + 64),
      lambda: CN.conv(g2, c2s, n, h, w, transpose=True, epi=CN.EPI_MASK, mask=t1, group=(G, 0))),
     ('9x9 64->3 backward-data + residual (conv_small_kernel<9>)', 2 * 81 * 64 * 4, 4 * (64 + 3 + 3),
      lambda: CN.conv_small(g1, bwd_img, n, h, w, epi=CN.EPI_ADD, add=gy, add_c=3, group=(G, 0))),
