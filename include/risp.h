@@ -233,7 +233,8 @@ int risp_conv2d(const risp_conv_desc *d, void *stream);
  * srcnn_demosaic_arch.py:21): a direct vector-FMA kernel - the matrix-core kernel above pads cout to 32.
  * wpack: [cin][k][k][P] floats, P = risp_conv_small_cout_pad(cout) = 4 or 12 (couts zero-padded), 16-byte
  * aligned - the layer's weights w[co][ci][ky][kx] for a forward layer, w[ci_b][co_b][k-1-ky][k-1-kx] for a
- * backward-data layer.  load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout % 4 == 0;
+ * backward-data layer.  cout == 3 (every proxy tail): [cin][k + 1][k][4] = (w0, w1, w2[ky], w2[ky - 1]) with w2[-1] = 0 and
+ * row k = (0, 0, 0, w2[k - 1]) - the fourth lane of the packed FMAs then serves the third cout of a second output row.  load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout % 4 == 0;
  * ksize in {3,5,9} (9 only for cout <= 4). */
 int risp_conv_small_cout_pad(int cout);
 size_t risp_conv_small_wpack_floats(int cin, int cout, int ksize);

@@ -119,18 +119,24 @@ def _wino5_pack(w, transpose):
 
 
 def small_weights(w, transpose=False, keep=None):
-    """[cin][k][k][P] weights of ``risp_conv2d_small`` (P = 4 for cout <= 4, else 12) from a layer's (cout,cin,k,k)
-    tensor; ``transpose``: the backward-data layer of a FORWARD weight (roles swapped, taps rotated by 180 degrees)
-    restricted to its first ``keep`` input channels."""
+    """Weights of ``risp_conv2d_small`` from a layer's (cout,cin,k,k) tensor: [cin][k][k][P] with P = 4 for cout <= 4, else 12
+    (couts zero-padded) - except for cout == 3, whose pack is [cin][k + 1][k][4] = (w0, w1, w2[ky], w2[ky - 1]), row k =
+    (0, 0, 0, w2[k - 1]): the fourth slot carries the third cout's weight of the filter row above, so that one packed FMA
+    serves cout 2 of two output rows (include/risp.h).  ``transpose``: the backward-data layer of a FORWARD weight (roles
+    swapped, taps rotated by 180 degrees) restricted to its first ``keep`` input channels."""
     if transpose:
         w = w[:, :keep].flip(2, 3).permute(0, 2, 3, 1)                # [cin_b = cout_f][ky][kx][cout_b = cin_f]
     else:
         w = w.permute(1, 2, 3, 0)                                      # [cin][ky][kx][cout]
-    if w.shape[3] > 12:
-        raise ValueError('small-cout layer: %d output channels (at most 12)' % w.shape[3])
-    pack = torch.zeros((w.shape[0], w.shape[1], w.shape[2], 4 if w.shape[3] <= 4 else 12), device=w.device, dtype=w.dtype)
-    pack[..., :w.shape[3]] = w
-    return pack, w.shape[3]
+    cout = w.shape[3]
+    if cout > 12:
+        raise ValueError('small-cout layer: %d output channels (at most 12)' % cout)
+    rows = w.shape[1] + (1 if cout == 3 else 0)
+    pack = torch.zeros((w.shape[0], rows, w.shape[2], 4 if cout <= 4 else 12), device=w.device, dtype=w.dtype)
+    pack[:, :w.shape[1], :, :cout] = w
+    if cout == 3:
+        pack[:, 1:, :, 3] = w[..., 2]
+    return pack, cout
 
 
 def k3_weights(w):
@@ -201,7 +207,7 @@ class SmallConv:
 
     def __init__(self, weight, bias=None, transpose=False, keep=None):
         self.wpack, self.cout = small_weights(_dev(weight.detach(), 'weight'), transpose, keep)
-        self.cin, self.k = self.wpack.shape[0], self.wpack.shape[1]
+        self.cin, self.k = self.wpack.shape[0], self.wpack.shape[2]
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 

@@ -37,8 +37,18 @@ template <int KS> struct SmallCfg { static constexpr int CCH = KS == 9 ? 3 : 4; 
 // the 1024-tile grid of a grouped launch at the per-GPU batch of the 8-GPU search is then ONE round of workgroups
 // instead of 768 + 256 (9x9 64 -> 3 on 32 x 256 x 256: 1050 -> 873 us).  The 5x5 form loses (44 bytes of scratch in
 // the loop: 215 -> 277 us) and keeps its 165 registers.
-template <int KS, int NP, int SPY>
-__global__ __launch_bounds__(256, (NP == 2 && KS != 5 ? 4 : (NP == 2 ? 3 : 2))) void conv_small_kernel(const risp_conv_desc d_in, int groups, float *__restrict__ partial) {
+// C3 (cout == 3, two output rows per thread): the fourth lane of the packed FMAs is not left idle.  The layer's pack then
+// has k + 1 filter rows and its fourth slot holds the THIRD cout's weight of the row above - (w0, w1, w2[ky], w2[ky - 1]),
+// row k = (0, 0, 0, w2[k - 1]) - so that at tile row r ONE packed FMA per pixel and tap serves cout 2 of both output rows
+// (lane x: row 0 with w2[r], lane y: row 1 with w2[r - 1]; the zero slots add 0) beside the two (c0, c1) FMAs of the
+// rows: 12 instead of 16 per pixel quad and tap, the same products in the same order per output.  The other forms read
+// such a pack too (their "cout 3" collects w2[ky - 1] products and is never stored).
+#ifndef RISP_SMALL_C3_5X5_WAVES
+#define RISP_SMALL_C3_5X5_WAVES 4
+#endif
+template <int KS, int NP, int SPY, bool C3 = false>
+__global__ __launch_bounds__(256, (NP == 2 && (KS != 5 || (C3 && RISP_SMALL_C3_5X5_WAVES == 4)) ? 4 : (NP == 2 ? 3 : 2))) void conv_small_kernel(const risp_conv_desc d_in, int groups, float *__restrict__ partial) {
+    static_assert(!C3 || (NP == 2 && SPY == 2), "C3: four-lane form of a 3-cout layer on two output rows");
     constexpr int SY = 16 * SPY;
     constexpr int P = KS / 2, TH_ = SY + 2 * P, CCH = SmallCfg<KS>::CCH, ROWV = STW / 4;
     extern __shared__ float4 lds4[];                       // [CCH][TH_][STW]
@@ -55,6 +65,8 @@ __global__ __launch_bounds__(256, (NP == 2 && KS != 5 ? 4 : (NP == 2 ? 3 : 2))) 
     const f32x2 *__restrict__ wp = reinterpret_cast<const f32x2 *>(d.wpack);        // [cin][KS][KS][NP] cout pairs
     const bool vecw = (W & 3) == 0;
 
+    const int wrows = (NP == 2 && d.cout == 3) ? KS + 1 : KS;                      // filter rows in the pack (see C3)
+    // C3: acc[r][p][0] = (c0, c1) of output row r; acc[0][p][1] = c2 of (row 0, row 1); acc[1][p][1] unused
     f32x2 acc[SPY][SPX][NP];
 #pragma unroll
     for (int r = 0; r < SPY; ++r)
@@ -104,12 +116,30 @@ __global__ __launch_bounds__(256, (NP == 2 && KS != 5 ? 4 : (NP == 2 ? 3 : 2))) 
         if (PIPE && c0 + CCH < cend) fetch(c0 + CCH);
         const int cn = cend - c0 < CCH ? cend - c0 : CCH;
         for (int c = 0; c < cn; ++c) {
-            const f32x2 *wch = wp + (size_t)(c0 + c) * KS * KS * NP;               // wave-uniform -> scalar loads
+            const f32x2 *wch = wp + (size_t)(c0 + c) * wrows * KS * NP;            // wave-uniform -> scalar loads
 #pragma unroll
             for (int r = 0; r < KS + SPY - 1; ++r) {                               // tile row ly + r
                 const float4 *row = lds4 + ((c * TH_ + ly + r) * STW + lx) / 4;
                 const float4 r0 = row[0], r1 = row[1], r2 = row[2];
                 const float a[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                if constexpr (C3) {
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const f32x2 w2p = wch[(r * KS + kx) * 2 + 1];              // (w2[r], w2[r - 1]); rows 0 and KS carry the zeros
+                        f32x2 wa = {0.f, 0.f}, wb = {0.f, 0.f};
+                        if (r < KS) wa = wch[(r * KS + kx) * 2];                   // (c0, c1) of filter row r     -> output row 0
+                        if (r >= 1) wb = wch[((r - 1) * KS + kx) * 2];             // (c0, c1) of filter row r - 1 -> output row 1
+#pragma unroll
+                        for (int p = 0; p < SPX; ++p) {
+                            const float av = a[HPAD - P + kx + p];
+                            const f32x2 a2 = {av, av};
+                            if (r < KS) acc[0][p][0] = __builtin_elementwise_fma(a2, wa, acc[0][p][0]);
+                            if (r >= 1) acc[1][p][0] = __builtin_elementwise_fma(a2, wb, acc[1][p][0]);
+                            acc[0][p][1] = __builtin_elementwise_fma(a2, w2p, acc[0][p][1]);
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int o = 0; o < SPY; ++o) {                                    // output row o sees it as filter row r - o
                     const int ky = r - o;
@@ -147,7 +177,7 @@ __global__ __launch_bounds__(256, (NP == 2 && KS != 5 ? 4 : (NP == 2 ? 3 : 2))) 
                         float *pp = partial + (((size_t)grp * d.N + n) * d.cout + co) * plane + (size_t)oy * W + ox;
 #pragma unroll
                         for (int p = 0; p < SPX; ++p)
-                            if (full || ox + p < W) pp[p] = co & 1 ? acc[o][p][co >> 1].y : acc[o][p][co >> 1].x;
+                            if (full || ox + p < W) pp[p] = (C3 && co == 2) ? (o ? acc[0][p][1].y : acc[0][p][1].x) : (co & 1 ? acc[o][p][co >> 1].y : acc[o][p][co >> 1].x);
                     }
                 }
             }
@@ -196,7 +226,7 @@ __global__ __launch_bounds__(256, (NP == 2 && KS != 5 ? 4 : (NP == 2 ? 3 : 2))) 
             const float b = (epi & RISP_EPI_NOBIAS) ? 0.f : d.bias[co];
             float v[SPX];
 #pragma unroll
-            for (int p = 0; p < SPX; ++p) v[p] = (co & 1 ? acc[o][p][co >> 1].y : acc[o][p][co >> 1].x) + b;
+            for (int p = 0; p < SPX; ++p) v[p] = ((C3 && co == 2) ? (o ? acc[0][p][1].y : acc[0][p][1].x) : (co & 1 ? acc[o][p][co >> 1].y : acc[o][p][co >> 1].x)) + b;
             if ((epi & RISP_EPI_ADD) && co < d.add_c) {
                 const float *ap = d.add + ((size_t)n * d.add_c + co) * plane + pix;
 #pragma unroll
@@ -362,19 +392,29 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(const risp_conv_desc 
     d.y[i] = v;
 }
 
+#ifndef RISP_SMALL_C3
+#define RISP_SMALL_C3 1       // A/B switch (tools/ab_build.sh): 0 = 3-cout layers on the general form (same pack)
+#endif
 template <int KS, int NP>
 int launch_small(const risp_conv_desc &d, float *scratch, int groups, hipStream_t s) {
     constexpr int P = KS / 2;
     const int tiles_x = (d.W + SX - 1) / SX;
     if (groups <= 1 && (size_t)tiles_x * ((d.H + 31) / 32) * d.N >= 384) {          // enough 64 x 32 tiles for every CU
         const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (32 + 2 * P) * STW;
-        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N), dim3(256), lds, s, d, 1, nullptr);
+        if (RISP_SMALL_C3 && NP == 2 && d.cout == 3)
+            hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2, NP == 2>), dim3(tiles_x, (d.H + 31) / 32, d.N), dim3(256), lds, s, d, 1, nullptr);
+        else
+            hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N), dim3(256), lds, s, d, 1, nullptr);
     } else if (groups > 1 && (size_t)tiles_x * ((d.H + 31) / 32) * d.N * groups >= 256) {
         // channel groups on the 64 x 32 tile (two output rows per thread: each LDS row read feeds both rows' taps):
         // 9x9 64 -> 3 on 4 x 256 x 256, 4 groups: 127 -> 118 us, 8 groups: 136 -> 114 us (tools/ab_small.py)
         const size_t lds = sizeof(float) * SmallCfg<KS>::CCH * (32 + 2 * P) * STW;
-        hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N * groups), dim3(256), lds, s, d, groups,
-                           scratch);
+        if (RISP_SMALL_C3 && NP == 2 && d.cout == 3)
+            hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2, NP == 2>), dim3(tiles_x, (d.H + 31) / 32, d.N * groups), dim3(256), lds, s, d, groups,
+                               scratch);
+        else
+            hipLaunchKernelGGL((conv_small_kernel<KS, NP, 2>), dim3(tiles_x, (d.H + 31) / 32, d.N * groups), dim3(256), lds, s, d, groups,
+                               scratch);
         const size_t total = (size_t)d.N * d.cout * d.H * d.W;
         hipLaunchKernelGGL(small_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d, groups, scratch);
     } else {
@@ -398,7 +438,7 @@ extern "C" {
 int risp_conv_small_cout_pad(int cout) { return cout <= 4 ? 4 : 12; }
 
 size_t risp_conv_small_wpack_floats(int cin, int cout, int ksize) {
-    return (size_t)cin * ksize * ksize * risp_conv_small_cout_pad(cout);
+    return (size_t)cin * (ksize + (cout == 3 ? 1 : 0)) * ksize * risp_conv_small_cout_pad(cout);     // cout == 3: k + 1 filter rows (see C3)
 }
 
 // Channel groups worth using for this layer on this grid (1 = none): small grids with many input channels, where one

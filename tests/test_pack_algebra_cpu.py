@@ -111,8 +111,30 @@ def test_winograd43_pack_forward_and_backward_data(cin, cout, ck):
 
 
 def small_emulate(x, pack, cout, k):
-    w = pack[..., :cout].permute(3, 0, 1, 2)                  # back to (cout, cin, k, k)
+    w = pack[:, :k, :, :cout].permute(3, 0, 1, 2)             # back to (cout, cin, k, k)
     return TF.conv2d(x, w, None, padding=k // 2)
+
+
+def small_emulate_c3(x, pack, k):
+    """The four-lane form of a 3-cout layer (conv_small_kernel<.., C3>): per pair of output rows (2j, 2j + 1) and tile row r,
+    lane 3 of the packed FMA pairs the third cout of row 2j (pack slot 2 of filter row r) with that of row 2j + 1 (slot 3 of
+    filter row r = the third cout's weight of filter row r - 1)."""
+    n, cin, h, w = x.shape
+    p = k // 2
+    xp = TF.pad(x, (p, p, p, p + 1))
+    out = torch.zeros(n, 3, h + (h & 1), w, dtype=x.dtype)
+    for y in range(0, h, 2):
+        for r in range(k + 1):
+            rowv = xp[:, :, y + r]                                          # tile row r of this row pair: (n, cin, w + 2p)
+            for kx in range(k):
+                a = rowv[:, :, kx:kx + w]
+                if r < k:
+                    out[:, :2, y] += torch.einsum('ncw,co->now', a, pack[:, r, kx, :2])
+                if r >= 1:
+                    out[:, :2, y + 1] += torch.einsum('ncw,co->now', a, pack[:, r - 1, kx, :2])
+                out[:, 2, y] += torch.einsum('ncw,c->nw', a, pack[:, r, kx, 2])
+                out[:, 2, y + 1] += torch.einsum('ncw,c->nw', a, pack[:, r, kx, 3])
+    return out[:, :, :h]
 
 
 @pytest.mark.parametrize('k', [3, 5, 9])
@@ -121,12 +143,18 @@ def test_small_cout_pack_forward_and_backward_data(k):
     x = rnd(2, 7, 9, 11, seed=5).requires_grad_(True)
     ref = TF.conv2d(x, wf[:3], None, padding=k // 2)            # a 3-cout forward layer
     pack, cout = CN.small_weights(wf[:3].float())
-    assert cout == 3 and pack.shape == (7, k, k, 4) and pack[..., 3].abs().max() == 0
-    assert torch.allclose(small_emulate(x.detach(), CN.small_weights(wf[:3])[0], 3, k), ref.detach(), rtol=1e-10, atol=1e-10)
+    assert cout == 3 and pack.shape == (7, k + 1, k, 4)         # 3 couts: k + 1 filter rows, slot 3 = the third cout of the row above
+    assert torch.equal(pack[:, 1:, :, 3], pack[:, :k, :, 2]) and pack[:, 0, :, 3].abs().max() == 0 and pack[:, k, :, :3].abs().max() == 0
+    pack3 = CN.small_weights(wf[:3])[0]
+    assert torch.allclose(small_emulate(x.detach(), pack3, 3, k), ref.detach(), rtol=1e-10, atol=1e-10)
+    assert torch.allclose(small_emulate_c3(x.detach(), pack3, k), ref.detach(), rtol=1e-10, atol=1e-10)
     gy = rnd(2, 16, 9, 11, seed=6)
     gref, = torch.autograd.grad(TF.conv2d(x, wf, None, padding=k // 2), x, gy)
     pack, cout = CN.small_weights(wf, transpose=True, keep=3)   # backward-data restricted to 3 input channels
     assert torch.allclose(small_emulate(gy, pack, cout, k), gref[:, :3], rtol=1e-10, atol=1e-10)
+    assert torch.allclose(small_emulate_c3(gy, pack, k), gref[:, :3], rtol=1e-10, atol=1e-10)
+    pack4, cout4 = CN.small_weights(wf[:4])
+    assert cout4 == 4 and pack4.shape == (7, k, k, 4)
     pack12, cout12 = CN.small_weights(wf[:12])
     assert cout12 == 12 and pack12.shape == (7, k, k, 12)
     with pytest.raises(ValueError):
