@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: in-process A/B of builds of risp_conv_wino.hip with different -D flags (interleaved rounds) on one
 64 -> 64 3x3 layer through risp_conv2d_wino43 (F(4,3)), or - RISP_AB_ENTRY=wino5 - one 64 -> 32 5x5 layer through
-risp_conv2d_wino5 (F(2,5)).  python tools/ab_wino43.py "" "-DRISP_W43_NO_GLDS" ...
+risp_conv2d_wino5 (F(2,5)), or - RISP_AB_ENTRY=wino45 - through risp_conv2d_wino45 (F(4,5)).  python tools/ab_wino43.py "" "-DRISP_W43_NO_GLDS" ...
 [env RISP_AB_SHAPE="n h w", RISP_AB_EPI=1 for the residual + ReLU epilogue of a Path-Restore block, RISP_AB_CH="cin cout"]"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,9 +24,10 @@ for i, v in enumerate(variants):
 from reconfigisp_amd import lib as L
 from reconfigisp_amd import convnets as CN
 n, h, w = (int(v) for v in os.environ.get('RISP_AB_SHAPE', '64 128 128').split())
-W5 = os.environ.get('RISP_AB_ENTRY') == 'wino5'
+W45 = os.environ.get('RISP_AB_ENTRY') == 'wino45'                 # F(4,5): the pack follows each build's risp_conv_wino45_layout()
+W5 = os.environ.get('RISP_AB_ENTRY') == 'wino5' or W45
 K = 5 if W5 else 3
-ENTRY = 'risp_conv2d_wino5' if W5 else 'risp_conv2d_wino43'
+ENTRY = 'risp_conv2d_wino45' if W45 else ('risp_conv2d_wino5' if W5 else 'risp_conv2d_wino43')
 cin, cout = (int(v) for v in os.environ.get('RISP_AB_CH', '64 32' if W5 else '64 64').split())
 torch.manual_seed(0)
 wt = torch.randn(cout, cin, K, K, device='cuda') * (0.05 if K == 3 else 0.02)
@@ -39,7 +40,10 @@ ref = torch.nn.functional.conv2d(x[:2], wt, b, padding=K // 2)
 ref = torch.relu(ref + res_in[:2]) if full_epi else torch.relu(ref)
 pack = CN.wino5_weights(wt, False, 4) if W5 else CN.wino43_weights(wt, False, 4)
 res = {k: [] for k in libs}
+packs = {}
 for name, l in libs.items():
+    if W45:
+        pack = packs[name] = CN.wino45_weights(wt, False, 4, l.risp_conv_wino45_layout())
     getattr(l, ENTRY).restype, getattr(l, ENTRY).argtypes = L.SIGNATURES[ENTRY]
     l.risp_last_error.restype = C.c_char_p
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=K, load_mode=0, cin_img=0,
@@ -64,4 +68,4 @@ for rnd in range(7):
 flop = 2.0 * cin * cout * K * K * n * h * w
 for k, v in res.items():
     m = sorted(v)[len(v) // 2]
-    print('%-40s median %.1f us  min %.1f   (%.1f algorithmic TFLOP/s, %.1f issued)' % (k, m, min(v), flop / m / 1e6, flop * (0.6 if W5 else 0.5) / m / 1e6))
+    print('%-40s median %.1f us  min %.1f   (%.1f algorithmic TFLOP/s, %.1f issued)' % (k, m, min(v), flop / m / 1e6, flop * (0.4 if W45 else (0.6 if W5 else 0.5)) / m / 1e6))
