@@ -951,6 +951,9 @@ __global__ __launch_bounds__(256, WGS) void conv_wino43_glds_kernel(const risp_c
 #ifndef RISP_W43_B2
 #define RISP_W43_B2 1
 #endif
+#ifndef RISP_W43B2_ABL
+#define RISP_W43B2_ABL 0     // diagnostic builds (tools/ab_wino43.py; outputs wrong, only the time matters): 1 no barrier, 2 no epilogue, 3 no transfers after the first chunk, 5 no input transform
+#endif
 #ifndef RISP_W43_B2_EB
 #define RISP_W43_B2_EB 1       // epilogue prefetch depth of cout block 0 (all 192 accumulator registers still live)
 #endif
@@ -1021,8 +1024,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino43_b2_kernel(const risp_conv_
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's pieces of chunk ch have landed
+#if RISP_W43B2_ABL != 1
         __builtin_amdgcn_s_barrier();                  // ... every wave's; the other stage is free
+#endif
+#if RISP_W43B2_ABL != 3
         if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
+#endif
         const float *sx = smem + buf * STAGE, *sw = sx + XI * 256;
         const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (half * WIH + wave) * W43WP) + l31;
         const float *aw = sw + half * CP + l31;
@@ -1053,7 +1060,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino43_b2_kernel(const risp_conv_
                                  __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
                                  __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
 #pragma unroll
-            for (int t = 0; t < 6; ++t) acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[0][t], bv[t], acc[0][t], 0, 0, 0);
+            for (int t = 0; t < 6; ++t)
+#if RISP_W43B2_ABL == 5
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[0][t], opd[t >> 1][t & 1], acc[0][t], 0, 0, 0);
+#else
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[0][t], bv[t], acc[0][t], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < NG) {
                 load_rows(g + 1);
@@ -1061,11 +1073,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino43_b2_kernel(const risp_conv_
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[1][t], bv[t], acc[1][t], 0, 0, 0);
+            for (int t = 0; t < 6; ++t)
+#if RISP_W43B2_ABL == 5
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[1][t], opd[t >> 1][t & 1], acc[1][t], 0, 0, 0);
+#else
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[1][t], bv[t], acc[1][t], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#if RISP_W43B2_ABL == 2
+    if (acc[0][0][0] == 123.456f)
+#endif
     w43_epilogue<RISP_W43_B2_EB>(d, acc[0], n, 0, y0 + wave, x0 + 4 * l31, half);
+#if RISP_W43B2_ABL == 2
+    if (acc[1][0][0] == 123.456f)
+#endif
     w43_epilogue<RISP_W43_B2_EB1>(d, acc[1], n, 1, y0 + wave, x0 + 4 * l31, half);
 }
 
