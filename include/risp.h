@@ -256,7 +256,9 @@ int risp_conv2d_wino3(const risp_conv_desc *d, void *stream);
 
 /* 3x3 layers with F(4,3) along x (half the matrix-core work of risp_conv2d): wpack [cout block of 32][chunk of
  * risp_conv_wino43_chunk() cin][ky][t][ci][32], U_t = (G g)_t, G rows (1/4,0,0) (1/6,1/6,1/6) (1/6,-1/6,1/6)
- * (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1).  Same restrictions as risp_conv2d_wino3. */
+ * (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1).  Same restrictions as risp_conv2d_wino3.  Layers with 33..64 couts and
+ * cin % 4 == 0 run both cout blocks in one wave (same results bit for bit); the environment variable RISP_W43_B2=0, read
+ * once per process, keeps them on the one-block kernel (A/B diagnostics - the only environment the library reads). */
 int risp_conv_wino43_chunk(void);
 size_t risp_conv_wino43_wpack_floats(int cin, int cout);
 int risp_conv2d_wino43(const risp_conv_desc *d, void *stream);
