@@ -155,6 +155,30 @@ def test_small_cout_forward_and_backward_data(cin, cout, k, hw):
     assert_close(got, gref[:, :keep], what='small bwd-data')
 
 
+@pytest.mark.parametrize('k,cin', [(3, 16), (5, 12), (9, 6)])
+def test_small_three_couts_on_four_lanes(k, cin):
+    """conv_small_kernel's C3 form (3 couts: the fourth lane of the packed FMA carries the third cout of the thread's second
+    output row) is what grids of >= 384 tiles and the channel split on 64 x 32 tiles launch; small test images never reach it.
+    Ragged image (odd height, last tile column partial), every epilogue, and the same layer through the one-row form
+    (inference: no split, small grid) - the four-lane form adds exact zeros only, so the two agree to the bit."""
+    from reconfigisp_amd import convnets as CN
+    h, w = 33, 132
+    wt, b = rnd(3, cin, k, k, seed=31) * 0.1, rnd(3, seed=32) * 0.1
+    sc = CN.SmallConv(wt, b)
+    n = 64                                                 # 3 x 2 tiles x 64 images = 384 tiles: the full-grid form
+    x, add, mask = rnd(n, cin, h, w, seed=33), rnd(n, 3, h, w, seed=34), rnd(n, 3, h, w, seed=35)
+    lin = TF.conv2d(x, wt, b, padding=k // 2)
+    y = CN.conv_small(x, sc, n, h, w, infer=True)
+    assert_close(y, lin, what='plain')
+    assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=3, infer=True), torch.relu(lin + add), what='add+relu')
+    assert_close(CN.conv_small(x, sc, n, h, w, epi=CN.EPI_MASK, mask=mask, infer=True), lin * (mask > 0), what='mask')
+    one_row = torch.cat([CN.conv_small(x[i:i + 8], sc, 8, h, w, infer=True) for i in range(0, n, 8)])      # 48 tiles: 64 x 16 form
+    assert torch.equal(y, one_row)
+    m = 8                                                  # channel split on 64 x 32 tiles: 3 x 2 x 8 images x 8 groups
+    ys = CN.conv_small(x[:m], sc, m, h, w, epi=CN.EPI_ADD, add=add[:m], add_c=3, split=min(8, cin // 2))
+    assert_close(ys, lin[:m] + add[:m], what='split')
+
+
 @pytest.mark.parametrize('hw', [(16, 32), (33, 30), (40, 72)])
 def test_small_cout_epilogues(hw):
     from reconfigisp_amd import convnets as CN
