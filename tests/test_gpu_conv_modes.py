@@ -155,6 +155,29 @@ def test_small_cout_forward_and_backward_data(cin, cout, k, hw):
     assert_close(got, gref[:, :keep], what='small bwd-data')
 
 
+@pytest.mark.parametrize('cin,cout', [(64, 32), (32, 64), (32, 3), (8, 40)])
+@pytest.mark.parametrize('hw', [(33, 36), (7, 132), (1, 8), (2, 260), (130, 128)])
+def test_f45_two_rows_per_wave_ragged(cin, cout, hw):
+    """conv_wino45_r2_kernel: a wave owns two output rows - odd heights (the second row of the last pair does not exist), a
+    single row, widths that leave the last 64-pixel half of a tile partly or wholly outside the image; forward with every
+    epilogue, and the backward-data pack (for 32 -> 3 that is the 3 -> 32 launch with a partial channel chunk)."""
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n = 3
+    wt, b = rnd(cout, cin, 5, 5, seed=91) * 0.05, rnd(cout, seed=92) * 0.1
+    pc = CN.PackedConv(wt, b)
+    x, add, mask = rnd(n, cin, h, w, seed=93), rnd(n, cout, h, w, seed=94), rnd(n, cout, h, w, seed=95)
+    if pc.wino45_fwd is not None:
+        lin = TF.conv2d(x, wt, b, padding=2)
+        assert_close(CN.conv(x, pc, n, h, w), lin, what='plain')
+        assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=cout), torch.relu(lin + add), what='add+relu')
+        assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_MASK, mask=mask), lin * (mask > 0), what='mask')
+    if pc.wino45_bwd is not None:
+        gy, xm = rnd(n, cout, h, w, seed=96), rnd(n, cin, h, w, seed=97)
+        ref = TF.conv_transpose2d(gy, wt, padding=2) * (xm > 0)
+        assert_close(CN.conv(gy, pc, n, h, w, transpose=True, epi=CN.EPI_MASK, mask=xm), ref, what='bwd-data + mask')
+
+
 @pytest.mark.parametrize('k,cin', [(3, 16), (5, 12), (9, 6)])
 def test_small_three_couts_on_four_lanes(k, cin):
     """conv_small_kernel's C3 form (3 couts: the fourth lane of the packed FMA carries the third cout of the thread's second
