@@ -1301,6 +1301,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_glds_kernel(const risp_con
 // instruction instead of 2 + 2, so results differ from the one-row kernel by fp32 rounding only.
 // Weight slab of a chunk (risp.h, layout 1): [ky 5][point group 2][cout block of 16: 2][cin 4][cout 16][4 points] - a lane
 // (cout m = lane & 15, cin k = lane >> 4) reads the A operands of four points with one conflict-free ds_read_b128.
+#ifndef RISP_W45R2_ABL
+#define RISP_W45R2_ABL 0     // diagnostic builds (tools/ab_wino43.py, RISP_AB_ENTRY=wino45; outputs wrong): 2 no epilogue, 3 no transfers after the first chunk, 5 no input transform
+#endif
 #ifndef RISP_W45_R2
 #define RISP_W45_R2 1
 #endif
@@ -1444,7 +1447,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_r2_kernel(const risp_conv_
         const int buf = ch & 1;
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's transfers of chunk ch have landed
         __builtin_amdgcn_s_barrier();                  // ... for every wave; the other stage is free
+#if RISP_W45R2_ABL != 3
         if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
+#endif
         const float *sx = smem + buf * STAGE;
         // the lane's channel kk, quad 16 xh + q: staged row 2 rp + i, 16-byte slots Q, Q + 1, Q + 2 (d_j = x[4 Q - 2 + j] = slot value 2 + j)
         const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (kk * W45IH + 2 * rp) * W43WP) + 16 * xh + q;
@@ -1472,9 +1477,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_r2_kernel(const risp_conv_
             const float e1 = __builtin_fmaf(4.f, d2 + d6, -17.f * d4), o1 = __builtin_fmaf(4.f, d1 + d5, -17.f * d3);
             const float e3 = __builtin_fmaf(4.f, d6, __builtin_fmaf(-5.f, d4, d2)), o3 = __builtin_fmaf(4.f, d5, __builtin_fmaf(-5.f, d3, d1));
             const float e5 = __builtin_fmaf(4.f, d2, __builtin_fmaf(-5.f, d4, d6)), o5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+#if RISP_W45R2_ABL == 5
+            const float bv[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
+#else
             const float bv[8] = {__builtin_fmaf(5.25f, d4 - d2, d0 - d6), e1 + o1, e1 - o1, __builtin_fmaf(2.f, o3, e3),
                                  __builtin_fmaf(-2.f, o3, e3), __builtin_fmaf(2.f, e5, o5), __builtin_fmaf(2.f, e5, -o5),
                                  __builtin_fmaf(5.25f, d3 - d5, d7 - d1)};
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (i + 1 < 6) load_row(i + 1);              // the raw row is consumed: the next one lands during the matrix instructions
             __builtin_amdgcn_sched_barrier(0);
@@ -1497,6 +1506,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_r2_kernel(const risp_conv_
             }
         }
     }
+#if RISP_W45R2_ABL == 2
+    if (acc[0][0][0][0] == 123.456f)
+#endif
     w45r2_epilogue<4>(d, acc, n, cb, y0 + 2 * rp, x0 + 4 * (16 * xh + q), kk);
 }
 

@@ -11,11 +11,38 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lptr_t;
 
+#ifndef DMA_MODE
+#define DMA_MODE 0      // what a "piece" is made of (-DDMA_MODE=k): 0 the LDS-DMA of the kernels; 1 a 16-byte-per-lane load into registers
+#endif                  // (no LDS write); 2 the scalar bookkeeping alone (M0 save / set / restore, no memory instruction); 3 the address arithmetic alone
 __device__ __forceinline__ void lds_dma16(const float *src, float *dst_wave_base) {
     const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)dst_wave_base);
     unsigned keep_m0;
+#if DMA_MODE == 0
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep_m0) : "v"(src), "s"(lds_dst) : "memory");
+#elif DMA_MODE == 1
+    // fixed high registers as the sink (declared clobbered, never read): a late-landing load cannot hit a live value
+    asm volatile("global_load_dwordx4 v[160:163], %0, off" :: "v"(src) : "memory", "v160", "v161", "v162", "v163");
+    (void)lds_dst; (void)keep_m0;
+#elif DMA_MODE == 2
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\ts_mov_b32 m0, %0" : "=&s"(keep_m0) : "s"(lds_dst) : "memory");
+    asm volatile("" :: "v"(src));
+#else
+    asm volatile("" :: "v"(src), "s"(lds_dst));
+    (void)keep_m0;
+#endif
+}
+
+// DMA_MODE 4: the same transfer addressed as a wave-uniform 64-bit base in scalar registers + a 32-bit per-lane offset (no
+// 64-bit vector address arithmetic per piece)
+__device__ __forceinline__ void lds_dma16_s(const float *uniform_base, unsigned lane_off_bytes, float *dst_wave_base) {
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)dst_wave_base);
+    const unsigned long long ub = (unsigned long long)uniform_base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub), hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(lane_off_bytes), "s"(sb), "s"(lds_dst) : "memory");
 }
 
 template <bool BAR, bool DMA, int TRF, bool EPI, bool L2SRC = false, int NW = 4, int PIECES = 24, bool SPREAD = false>
@@ -47,7 +74,11 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void stages(const float *__restri
 #pragma unroll
                 for (int j = 0; j < (PIECES + NW - 1) / NW; ++j) {
                     const int id = wave + NW * j;
+#if DMA_MODE == 4
+                    if (id < PIECES) lds_dma16_s(gsrc + (size_t)((ch + 1) & 15) * 6144 + (id % 24) * 256, lane * 16, nxt + id * 256);
+#else
                     if (id < PIECES) lds_dma16(gsrc + (size_t)((ch + 1) & 15) * 6144 + (id % 24) * 256 + lane * 4, nxt + id * 256);
+#endif
                 }
             }
             if (TRF == 2) {
