@@ -52,7 +52,7 @@ with open(os.path.join(root, 'summary.txt'), 'w') as out:
     # ---- grouped convolution layers (tools/bench_layers.py): kernel duration against the matrix / packed-FMA peak and HBM
     LPIX = 32 * 256 * 256
     LAY = [('conv_lin_kernel<9, 3', '9x9 3->64 forward (linear-k MFMA)', 2 * 244 * 64, 4 * (3 / 8 + 64)),
-           ('conv_wino45_r2_kernel', '5x5 64->32 fwd, 32->64 bwd, 3->32 bwd F(4,5) (all three in this row: 64x32 FLOPs)', 2 * 10 * 64 * 32, 4 * 128),
+           ('conv_wino45_r2_kernel', '5x5 F(4,5): 64->32 fwd, 32->64 bwd, 3->32 bwd (mean of the three)', 2 * 10 * (64 * 32 + 32 * 64 + 4 * 32) / 3, 4 * (96 + 160 + 67) / 3),
            ('conv_wino5_glds_kernel', '5x5 64->32 fwd / 32->64 bwd F(2,5)', 2 * 15 * 64 * 32, 4 * 128),
            ('conv_small_kernel<5, 2', '5x5 32->3 forward, packed FMA', 2 * 25 * 32 * 4, 4 * 35.4),
            ('conv_wino5_kernel', '5x5 3->32 backward-data F(2,5)', 2 * 15 * 4 * 32, 4 * 67),
