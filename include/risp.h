@@ -295,6 +295,20 @@ int risp_conv_wino45_layout(void);
 size_t risp_conv_wino45_wpack_floats(int cin, int cout);
 int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
 
+/* The same operator on the f16 matrix pipe at fp32-level accuracy (round 4; the 64 -> 64 3x3 layers of Path-Restore,
+ * path_14l_bgr_arch.py:6-21, 58-86; path_14l_bayer_arch.py:59-88): every fp32 operand is cut into two f16 halves,
+ * hi = rn_f16(v s), lo = rn_f16(v s - hi), and x w is taken as (x_lo w_hi + x_hi w_lo + x_hi w_hi) / (s_x s_w) - three
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation instead of eight fp32 matrix instructions of twice the duration; the
+ * dropped term is 2^-22 of the product.  x, y, add, mask stay fp32 tensors: the activations are scaled (per workgroup tile
+ * and chunk of 16 input channels, by the tile's own largest magnitude - so gradients of magnitude 1e-8 are as exact as
+ * activations of magnitude 1) and split at staging time; the weights are scaled and split once, at pack time.
+ * wpack: risp_conv_f16x2_wpack_bytes() bytes, 16-byte aligned: a 16-byte header whose first float is 1 / s_w (s_w = 2^k with
+ * max|w| s_w in [2^14, 2^15)), then [chunk of 16 cin][tap][part: hi, lo][channel half][cout padded to 32 or 64][8 channels]
+ * _Float16 (reconfigisp_amd/convnets.py::f16x2_weights).  ksize 3, cin % 16 == 0, cout <= 64, W % 4 == 0, 16-byte aligned
+ * tensors, load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS.  A tile's result does not depend on the batch it travels in. */
+size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize);
+int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
+
 /* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */

@@ -111,6 +111,31 @@ def wino45_weights(w, transpose, ck=4, layout=None):
     return p.view(ncb, 2, 16, nch, 4, 5, 2, 4).permute(0, 3, 5, 6, 1, 4, 2, 7).contiguous()
 
 
+def f16x2_weights(w, transpose):
+    """Pre-split pack of ``risp_conv2d_f16x2`` (include/risp.h): a 16-byte header whose first float is 1 / s_w, then
+    [chunk of 16 cin][tap][part: hi, lo][channel half][cout padded to 32 or 64][8 channels] halves of w * s_w, where
+    s_w = 2^k puts max|w| into [2^14, 2^15), hi = rn_f16(w s_w), lo = rn_f16(w s_w - hi).  ``transpose``: the backward-data
+    layer of a forward weight (roles swapped, taps rotated by 180 degrees).  Pure tensor algebra on the device of ``w`` (no
+    host synchronisation); tests/test_pack_algebra_cpu.py pins it on the CPU.  Returns a float16 tensor."""
+    if transpose:
+        w = w.flip(2, 3).transpose(0, 1)
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    nt, nch = (co + 31) // 32, (ci + 15) // 16
+    _, e = torch.frexp(w.detach().abs().max())                # max|w| = m 2^e, m in [0.5, 1)
+    sw = torch.ldexp(torch.ones((), device=w.device), 15 - e)       # max|w| s_w = m 2^15
+    ws = w.detach().float() * sw
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    p = torch.zeros((2, nch * 16, k * k, nt * 32), device=w.device, dtype=torch.float16)
+    p[0, :ci, :, :co] = hi.permute(1, 2, 3, 0).reshape(ci, k * k, co)
+    p[1, :ci, :, :co] = lo.permute(1, 2, 3, 0).reshape(ci, k * k, co)
+    #       (part, chunk, half, 8, tap, cout) -> (chunk, tap, part, half, cout, 8)
+    p = p.view(2, nch, 2, 8, k * k, nt * 32).permute(1, 4, 0, 2, 5, 3).contiguous()
+    hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
+    hdr[0] = 1.0 / sw
+    return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
+
+
 WINO_F45 = os.environ.get('RISP_WINO_F45', '1') != '0'       # 5x5: F(4,5) where cin % 4 == 0 (default), else F(2,5)
 
 

@@ -95,6 +95,18 @@ __device__ __forceinline__ void lds_dma16(const float *src, float *dst_wave_base
                  : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(src), "s"(lds_dst), "s"(mask) : "memory");
 }
 
+// The same with a wave-uniform 64-bit base in scalar registers and one 32-bit byte offset per lane (no 64-bit address pair
+// per piece in vector registers).  `mask` as in lds_dma16 (a wave issues the instruction even when no lane copies, so every
+// wave of a workgroup counts the same number of transfers in vmcnt).
+__device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, void *dst_wave_base, unsigned long long mask = ~0ull) {
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)dst_wave_base);
+    unsigned long long keep_exec;
+    unsigned keep_m0;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %5\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory");
+}
+
 // Workgroups per image of the element-wise BACKWARD kernels (stand-alone risp_*_bwd and the fused slot mixture share it, so
 // both cut an image into the same partial sums and give the same parameter-gradient bits): >= 4 vectors per thread so the
 // block reduction amortises, but enough workgroups for the chip when the batch is small (the per-GPU batch of the 8-GPU

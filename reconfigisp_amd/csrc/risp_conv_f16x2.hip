@@ -1,0 +1,640 @@
+// Split-precision convolution on the f16 matrix pipe (round 4): fp32 in, fp32 out, fp32-level accuracy at 16/3 of the
+// fp32 matrix-instruction rate.  Layers: the 64 -> 64 3x3 layers of Path-Restore (path_14l_bgr_arch.py:6-21, 58-86;
+// path_14l_bayer_arch.py:59-88) and the 5x5 64 -> 32 layer of SRCNNRes with its backward (srcnn_res_arch.py:20).
+//
+// Arithmetic.  Every fp32 operand v is cut into two halves of 11 significant bits each, hi = rn_f16(v s), lo = rn_f16(v s - hi)
+// (s a power of two), so that v s = hi + lo up to 2^-22 |v s|, and a product of two operands is taken as
+//        x w  ~  (x_lo w_hi + x_hi w_lo + x_hi w_hi) / (s_x s_w)
+// - three v_mfma_f32_32x32x16_f16 instructions (products of f16 values are exact in fp32; accumulation in fp32) instead of
+// eight v_mfma_f32_32x32x2_f32 of twice the duration.  The dropped term x_lo w_lo is 2^-22 of the product.  Against float64
+// (tests/test_pack_algebra_cpu.py::test_f16x2_split_numerics: 64-channel 3x3 and 5x5 rows, activations in [0,1) and
+// gradient-like inputs of magnitude 1e-5) the emulated scheme has HALF the rms error of the fp32 FMA chain the fp32 matrix
+// instruction is (5.3e-8 vs 1.1e-7 of max|y|), because its error is per product (random walk) where the chain rounds the
+// running sum at every step; the GPU tests compare the kernel itself with float64.
+//
+// Range.  f16 has 5 exponent bits: hi overflows above 65504 and lo loses bits below 2^-14.  Weights are scaled per LAYER at
+// pack time (s_w = 2^k puts max|w| into [2^14, 2^15)).  Activations / upstream gradients are scaled per WORKGROUP TILE and
+// CHUNK of 16 input channels at staging time: the tile's largest magnitude (wave shuffles + one LDS row, no extra barrier)
+// picks s_x = 2^e with max|x| s_x in [2^14, 2^15); the accumulators carry the running exponent and are rescaled (exact:
+// a power of two) only when a later chunk needs a smaller one.  Everything down to 2^-17 of the tile's maximum keeps its 22
+// bits, below that the absolute error is 2^-39 of the maximum.  No inter-kernel state, deterministic, and a gradient tensor
+// of magnitude 1e-8 is as exact as an activation tensor of magnitude 1.
+//
+// Kernel.  Workgroup = 4 waves = 8 rows x 64 pixels x all (<= 64) couts; a wave owns 2 rows x 64 pixels = 4 matrix tiles of
+// 32 pixels x 2 cout blocks of 32 (128 accumulator registers); MFMA rows (A) are PIXELS and columns (B) couts, so that a lane
+// ends with 16 consecutive pixels of a cout row: 16-byte stores without an LDS transposition.  Per chunk of 16 input
+// channels the halo tile is staged through registers (8 x 16-byte loads per thread = 4 pixels x 8 channels, scaled, split,
+// 8 x ds_write_b128) and the chunk's weights (all taps, hi and lo) arrive by LDS-DMA from the pre-split pack.
+// LDS layout: one 16-byte slot = the hi (or lo) halves of 8 channels of one pixel = exactly one lane's A operand.  Within a
+// tile row the slot of column c is (c & 3) * 17 + (c >> 2): the staging lanes (4 consecutive columns each) write consecutive
+// slots, and a matrix tile takes pixel column 4 Q + r for lanes (Q = lane & 15, r = tile bit, lane bit 4), so that 16 consecutive
+// lanes read 16 consecutive slots for every tap shift: both directions are free of bank conflicts.
+#include "risp_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer addressing (a 128-bit resource in scalar registers + one 32-bit byte offset per lane + a scalar byte offset): a tensor
+// plane costs a scalar add instead of a 64-bit address pair per lane and access.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t h2_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 h2_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float h2_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+#ifndef RISP_H2_EARLY
+#define RISP_H2_EARLY 0      // 1: the next tile's first chunk is fetched in front of the epilogue's stores (needs 42 more live registers there)
+#endif
+#ifndef RISP_H2_STAGGER
+#define RISP_H2_STAGGER 100  // start delay of the second workgroup of a CU, in percent of a tile's matrix-instruction time (0 = off)
+#endif
+#ifndef RISP_H2_PERSIST
+#define RISP_H2_PERSIST 1    // 0: one workgroup per tile
+#endif
+#ifndef RISP_H2_DBG
+#define RISP_H2_DBG 0
+#endif
+#ifndef RISP_H2_ABL
+#define RISP_H2_ABL 0        // diagnostic builds (tools/ab_f16x2.py; outputs wrong, only the time matters): 1 no staging after the first chunk, 2 no epilogue, 3 no matrix instructions, 4 no operand reads after the first tap
+#endif
+
+namespace {
+constexpr int H2_TH = 8, H2_TW = 64, H2_S = 17, H2_RS = 4 * H2_S, H2_CK = 16;
+constexpr int h2_half_grid_min = 256;    // stagger only when every CU holds two workgroups
+
+template <int KS, int NT>
+struct H2 {
+    static constexpr int P = KS / 2, IH = H2_TH + 2 * P;
+    static constexpr int PART = 2 * IH * H2_RS;                  // 16-byte slots of one part (hi or lo): [channel half][row][slot]
+    static constexpr int TILE = 2 * PART;
+    static constexpr int WST = KS * 2 * 2 * NT * 32;             // weight slots of one stage = one filter row: [kx][part][channel half][cout]
+    static constexpr int RING = 3;                               // weight stages in LDS: transfers run two stages ahead
+    static constexpr int PW = (WST / 64 + 3) / 4;                 // LDS-DMA instructions per wave and stage (the same for every wave)
+    static constexpr int LDS_BYTES = (TILE + RING * WST) * 16 + 64 + 256;  // tile, weight ring, the row of maxima, the bias
+    static constexpr int HALO_ROW_TASKS = 2 * P * 32, HALO_COL_TASKS = IH * 2 * P * 2;
+    static_assert(WST % 64 == 0, "weight stage in whole LDS-DMA pieces");
+    static_assert(HALO_ROW_TASKS + HALO_COL_TASKS <= 256, "one extra staging pass");
+};
+
+__device__ __forceinline__ float comp(const float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+// hi / lo halves of 8 scaled values -> two 16-byte slots
+__device__ __forceinline__ void split8(const float (&a)[8], float s, uint4 &hi, uint4 &lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a0 = a[2 * e] * s, a1 = a[2 * e + 1] * s;
+        const h2 hh = {(_Float16)a0, (_Float16)a1};
+        const h2 ll = {(_Float16)(a0 - (float)hh[0]), (_Float16)(a1 - (float)hh[1])};
+        h[e] = __builtin_bit_cast(unsigned, hh);
+        l[e] = __builtin_bit_cast(unsigned, ll);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// largest of a wave's non-negative values, in every lane: butterflies inside the rows of 16 by DPP, then the four rows by
+// readlane (non-negative floats order like their bit patterns) - the shuffle form (six ds_bpermute round trips) sat on every
+// chunk's critical path
+__device__ __forceinline__ float h2_wave_max(float v) {
+    int x = __builtin_bit_cast(int, v);
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true));     // row_half_mirror
+    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true));     // row_mirror
+    const int r = max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)),
+                      max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+    return __builtin_bit_cast(float, r);
+}
+
+__device__ __forceinline__ float amax4(float m, const float4 &v) {
+    return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+}
+
+// HAS_ADD / HAS_MASK: epilogue flags as template parameters - with run-time flags the epilogue is a chain of wave-uniform
+// branches around its loads, hipcc spills what the loads return and waits vmcnt(0) behind every block.  cout == 32 NT.
+template <int KS, int NT, bool HAS_ADD, bool HAS_MASK>
+__global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ntiles) {
+    using C = H2<KS, NT>;
+    constexpr int P = C::P, IH = C::IH, S = H2_S, RS = H2_RS, WST = C::WST;
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 *tile = smem, *wl = smem + C::TILE;
+    float *red = reinterpret_cast<float *>(wl + C::RING * WST);            // 4 floats: per-wave maxima of the chunk being staged
+    float *lbias = red + 16;                                         // 64 floats (LDS reads do not queue behind the stores)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hl = lane >> 5;
+    const int nchunks = d.cin / H2_CK, nstages = nchunks * KS;
+    const size_t hw = (size_t)d.H * d.W;
+    const uint4 *wpack = reinterpret_cast<const uint4 *>(d.wpack) + 1;       // slot 0 = header
+    const float inv_sw = *reinterpret_cast<const float *>(d.wpack);
+
+    // PERSISTENT workgroups: 2 per CU, each walks tiles id, id + gridDim.x, ...  The stores of a tile are never waited for:
+    // they drain while the next tile is staged and multiplied, and the next tile's first chunk is fetched BEFORE them (loads
+    // and stores return in issue order).  One workgroup per tile ran in lockstep rounds - every workgroup of the chip in its
+    // store epilogue at the same time, the matrix pipes idle, then every memory channel idle through the matrix phases.
+    // Consecutive workgroup ids sit on different XCDs (8 L2s): XCD k takes the k-th contiguous eighth of each sweep, so that
+    // tiles sharing halo rows share an L2.
+    const int nwg = gridDim.x;
+    const int wg = (nwg & 7) == 0 ? (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+
+    // ---- staging tasks of this thread.  Pass 1 = the 8 interior rows: (8 channels, row, quad) = 8 x 16-byte loads, 8 slots.
+    // Pass 2 = the 2 P halo rows as (channel pair, row, quad) tasks - 2 x 16-byte loads, P tasks per thread - and the halo columns
+    // as (channel pair, row, column) tasks - 2 scalar loads, NC2 tasks per thread.  (Whole 8-channel slots per thread, as in
+    // pass 1, would keep 32 more registers in flight through the matrix phase.)
+    constexpr int NC2 = (IH * 2 * P * 8 + 255) / 256;
+    const int g1 = tid >> 7, r1 = (tid >> 4) & 7, q1 = tid & 15;
+    const int dst1 = (g1 * IH + r1 + P) * RS;                               // + slot of column 4 q + j + P
+    unsigned off1, offr[P], offc[NC2];                                      // byte offsets of the tasks inside the image
+    bool ok1, okr[P], okc[NC2];
+    int dstr[P], dstc[NC2];                                                 // byte offsets into the hi part
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int id = tid + 256 * k, hr = (id >> 4) % (2 * P), cp = id / (32 * P);
+        dstr[k] = (((cp >> 2) * IH + (hr < P ? hr : H2_TH + hr)) * RS) * 16 + (cp & 3) * 4;        // + 16 * slot of column 4 q + j + P
+    }
+#pragma unroll
+    for (int k = 0; k < NC2; ++k) {
+        const int id = tid + 256 * k;
+        const int cp = id / (IH * 2 * P), rem = id - cp * (IH * 2 * P), ir = rem / (2 * P), cc = rem - ir * (2 * P);
+        const int c = cc < P ? cc : H2_TW + cc;
+        dstc[k] = id < IH * 2 * P * 8 ? (((cp >> 2) * IH + ir) * RS + (c & 3) * S + (c >> 2)) * 16 + (cp & 3) * 4 : -1;
+    }
+    int x0, y0, n;                                                          // the tile being staged
+    __amdgpu_buffer_rsrc_t rx;                                              // its image
+    const unsigned hw4 = (unsigned)hw * 4u;                                 // bytes of a plane (cin * H * W < 2^30: checked by the entry point)
+    auto setup = [&](int t) {
+        n = t / (tiles_x * tiles_y);
+        const int rem = t - n * (tiles_x * tiles_y), ty = rem / tiles_x;
+        x0 = (rem - ty * tiles_x) * H2_TW;
+        y0 = ty * H2_TH;
+        rx = h2_rsrc(d.x + (size_t)n * d.cin * hw);
+        const int gy1 = y0 + r1, gx1 = x0 + 4 * q1;
+        ok1 = gy1 < d.H && gx1 < d.W;
+        off1 = ok1 ? 8u * g1 * hw4 + 4u * (unsigned)(gy1 * d.W + gx1) : 0u;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int id = tid + 256 * k, q = id & 15, hr = (id >> 4) % (2 * P), cp = id / (32 * P);
+            const int gy = y0 - P + (hr < P ? hr : H2_TH + hr), gx = x0 + 4 * q;
+            okr[k] = gy >= 0 && gy < d.H && gx < d.W;
+            offr[k] = okr[k] ? 2u * cp * hw4 + 4u * (unsigned)(gy * d.W + gx) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NC2; ++k) {
+            const int id = tid + 256 * k;
+            const int cp = id / (IH * 2 * P), rem2 = id - cp * (IH * 2 * P), ir = rem2 / (2 * P), cc = rem2 - ir * (2 * P);
+            const int gy = y0 - P + ir, gx = x0 - P + (cc < P ? cc : H2_TW + cc);
+            okc[k] = dstc[k] >= 0 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            offc[k] = okc[k] ? 2u * cp * hw4 + 4u * (unsigned)(gy * d.W + gx) : 0u;
+        }
+    };
+
+    float4 v1[8], vr[P][2];
+    float vc[NC2][2];
+    auto fetch = [&](int ch) {
+        const unsigned off = (unsigned)ch * H2_CK * hw4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v1[j] = h2_load16(rx, off1, off + j * hw4);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            vr[k][0] = h2_load16(rx, offr[k], off);
+            vr[k][1] = h2_load16(rx, offr[k], off + hw4);
+        }
+#pragma unroll
+        for (int k = 0; k < NC2; ++k) {
+            vc[k][0] = h2_load4(rx, offc[k], off);
+            vc[k][1] = h2_load4(rx, offc[k], off + hw4);
+        }
+    };
+    auto slot_of = [&](int c) { return (c & 3) * S + (c >> 2); };
+    auto put_quad = [&](const float4 (&v)[8], bool ok, int dst, int c0, float s) {       // 4 pixels x 8 channels: 8 slots
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = ok ? comp(v[e], j) : 0.f;
+            uint4 hi, lo;
+            split8(a, s, hi, lo);
+            const int sl = dst + slot_of(c0 + j);
+            tile[sl] = hi;
+            tile[C::PART + sl] = lo;
+        }
+    };
+    auto put_pair = [&](float a0, float a1, float s, int byte_off) {     // one pixel, one channel pair: 4 bytes of hi, 4 of lo
+        a0 *= s;
+        a1 *= s;
+        const h2 hh = {(_Float16)a0, (_Float16)a1};
+        const h2 ll = {(_Float16)(a0 - (float)hh[0]), (_Float16)(a1 - (float)hh[1])};
+        char *base = reinterpret_cast<char *>(tile) + byte_off;
+        *reinterpret_cast<unsigned *>(base) = __builtin_bit_cast(unsigned, hh);
+        *reinterpret_cast<unsigned *>(base + C::PART * 16) = __builtin_bit_cast(unsigned, ll);
+    };
+
+    // operand addresses.  B = pixels: lane (n = lane & 31, hl) of pixel tile t holds row 2 wave + (n >> 4), column 4 (n & 15) + t;
+    // at tap (ky, kx) its slot is row + ky, ((t + kx) & 3) * S + (n & 15) + ((t + kx) >> 2): a compile-time offset from bbase.
+    // A = weights: lane (m = lane & 31, hl) holds cout m of a block, channels 8 hl .. 8 hl + 7.
+    const int bbase = (hl * IH + 2 * wave + (l31 >> 4)) * RS + (l31 & 15);
+    const int abase = hl * NT * 32 + l31;
+    // Weight stages (one filter row of one chunk each) go through a ring of three LDS buffers, the LDS-DMA two stages ahead: the
+    // wait in front of a stage's closing barrier is for the pieces issued a whole stage earlier, and it is a COUNTED wait that
+    // leaves the younger pieces and the tile prefetch in flight (loads, stores and LDS-DMA return in issue order: vmcnt(0)
+    // there made every chunk wait for the HBM latency of the next chunk's tile).
+    constexpr int PW = C::PW, LOADS = 8 + 2 * P + 2 * NC2;           // vector-memory instructions of issue_weights / fetch
+    int ring = 0;                                                    // ring slot of the stage being multiplied
+    auto issue_weights = [&](int stage, int slot) {                  // LDS-DMA of stage (chunk, ky) = stage / KS, stage % KS
+        uint4 *dst = wl + slot * WST;
+        const uint4 *src = wpack + (size_t)stage * WST;
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            const int piece = wave + 4 * p;
+            const bool real = piece < WST / 64;                      // every wave issues PW instructions: the same vmcnt arithmetic
+            lds_dma16_s(src + (real ? piece : 0) * 64, lane * 16, dst + (real ? piece : 0) * 64, __builtin_amdgcn_ballot_w64(real));
+        }
+    };
+    auto ring_next = [&](int r, int k) { return r + k >= C::RING ? r + k - C::RING : r + k; };
+#define H2_WAIT_VM(keep) __builtin_amdgcn_s_waitcnt(0x0F70 | ((keep) & 15) | (((keep) >> 4) << 14))      /* s_waitcnt vmcnt(keep) */
+
+#ifdef RISP_H2_STAMPS
+    unsigned long long t_start = __builtin_amdgcn_s_memtime(), t_stage = 0, t_mat = 0, t_wait = 0, t_epi = 0, t_steps = 0, t0, t1;
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#define H2STAMP(v) do { __builtin_amdgcn_s_waitcnt(0xC07F); v = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define H2STAMP(v) do { } while (0)
+#endif
+    int t_cur = wg;
+    if (t_cur >= ntiles) return;
+#if RISP_H2_STAGGER
+    // The two workgroups of a CU (ids b and b + gridDim.x / 2 - checked with HW_ID, tools/ab_f16x2.py) would run in lockstep: both
+    // in their matrix phases (sharing the pipe), then both staging / storing (the pipe idle).  The second one starts late by
+    // about a matrix phase, so that one multiplies while the other moves data.
+    if (2 * (int)blockIdx.x >= nwg && nwg > h2_half_grid_min) {
+        const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(RISP_H2_STAGGER * nstages * 4 * KS * 3 * NT * 32 / 100);
+        while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+    if (tid < 64) lbias[tid] = (d.epilogue & RISP_EPI_NOBIAS) || tid >= d.cout ? 0.f : d.bias[tid];      // visible after the first barrier
+    setup(t_cur);
+    issue_weights(0, 0);
+    if (nstages > 1) issue_weights(1, 1);
+    fetch(0);
+    for (;;) {
+        f32x16 acc[4][NT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][b][e] = 0.f;
+        int se = 0;                                    // running exponent: the accumulators hold sum * 2^se * s_w
+        const int t_next = t_cur + nwg;
+        const bool more = t_next < ntiles;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            H2STAMP(t0);
+            // largest magnitude of the chunk's tile -> red[wave]
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = amax4(m, ok1 ? v1[j] : make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                if (okr[k]) m = amax4(amax4(m, vr[k][0]), vr[k][1]);
+#pragma unroll
+            for (int k = 0; k < NC2; ++k)
+                if (okc[k]) m = fmaxf(m, fmaxf(fabsf(vc[k][0]), fabsf(vc[k][1])));
+#if RISP_H2_DBG & 1
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+#else
+            m = h2_wave_max(m);
+#endif
+            if (lane == 0) red[wave] = m;
+#ifdef RISP_H2_STAMPS
+            H2STAMP(t1); t_wait += t1 - t0; t0 = t1;   // waiting for the prefetched tile (vmcnt) + the reduction
+#endif
+            __syncthreads();                           // A: the maxima are visible; every wave has left the previous chunk's tile
+#if RISP_H2_ABL == 1
+            if (ch == 0 && t_cur == wg) {
+#endif
+            const float4 mx = *reinterpret_cast<const float4 *>(red);
+            const float tmax = fmaxf(fmaxf(mx.x, mx.y), fmaxf(mx.z, mx.w));
+            // exponent that puts tmax into [2^14, 2^15): biased exponent eb of tmax -> 2^(141 - eb)
+            int eb = (int)(__builtin_bit_cast(unsigned, tmax) >> 23);
+            eb = __builtin_amdgcn_readfirstlane(eb);
+            int want = 141 - eb;                        // exponent of s_x (unbiased)
+            want = want > 100 ? 100 : want;             // an all-zero or denormal tile: any scale will do
+            if (ch == 0) {
+                se = want;
+            } else if (want < se) {                     // larger values than before: rescale the running sums (exact)
+                const int fe = 127 + want - se;
+                const float f = fe > 0 ? __builtin_bit_cast(float, (unsigned)fe << 23) : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[t][b][e] *= f;
+                se = want;
+            }
+            const float s = __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+            put_quad(v1, ok1, dst1, 4 * q1 + P, s);
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int q = (tid + 256 * k) & 15;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    put_pair(okr[k] ? comp(vr[k][0], j) : 0.f, okr[k] ? comp(vr[k][1], j) : 0.f, s, dstr[k] + 16 * slot_of(4 * q + j + P));
+            }
+#pragma unroll
+            for (int k = 0; k < NC2; ++k)
+                if (dstc[k] >= 0) put_pair(okc[k] ? vc[k][0] : 0.f, okc[k] ? vc[k][1] : 0.f, s, dstc[k]);
+#if RISP_H2_ABL == 1
+            }
+#endif
+            // the weight pieces of stage (ch, 0) were issued a stage ago; at ch == 0 of a later tile the previous tile's stores
+            // are younger than them and stay in flight
+            // (the weight pieces of this chunk's first stage were waited for in front of the previous stage's last barrier, or - first
+            // tile - are older than the tile just consumed)
+            __syncthreads();                           // B: tile and weights complete
+#ifdef RISP_H2_STAMPS
+            H2STAMP(t1); t_stage += t1 - t0; t0 = t1;
+#endif
+
+            // ---- matrix phase: KS stages (filter rows) x KS taps x 4 pixel tiles x NT cout blocks x 3 products
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int stage = ch * KS + ky;
+                const bool dma = stage + 2 < nstages || more;
+                auto feed = [&]() {                     // two stages ahead, into the slot of the stage before this one (every wave has left it)
+#if RISP_H2_ABL != 1
+                    if (stage + 2 < nstages) issue_weights(stage + 2, ring_next(ring, 2));
+                    else if (more) issue_weights(stage + 2 - nstages, ring_next(ring, 2));
+                    if (ky == 0 && ch + 1 < nchunks) fetch(ch + 1);   // behind the pieces: in flight during the whole matrix phase
+#endif
+                };
+#if RISP_H2_ABL == 3
+                feed();
+#else
+                const uint4 *ws = wl + ring * WST + abase;
+                const uint4 *ts = tile + bbase + ky * RS;
+                h8 a[2][NT][2], bv[2][2];
+                auto load_a = [&](int kx, int buf) {
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+#pragma unroll
+                        for (int part = 0; part < 2; ++part)
+                            a[buf][b][part] = __builtin_bit_cast(h8, ws[((kx * 2 + part) * 2) * NT * 32 + b * 32]);
+                };
+                auto load_b = [&](int u, int buf) {
+#if RISP_H2_ABL == 4
+                    u = 0;
+#endif
+                    const int sl = (u & 3) * S + (u >> 2);
+                    bv[buf][0] = __builtin_bit_cast(h8, ts[sl]);
+                    bv[buf][1] = __builtin_bit_cast(h8, ts[C::PART + sl]);
+                };
+#if RISP_H2_DBG & 2
+                feed();
+#endif
+                load_a(0, 0);
+                load_b(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#if !(RISP_H2_DBG & 2)
+                feed();                                 // behind the first operand reads: issued while those are in flight
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef RISP_H2_STAMPS
+                unsigned long long ts0, ts1;
+                H2STAMP(ts0);
+#endif
+#pragma unroll
+                for (int step = 0; step < 4 * KS; ++step) {
+                    const int kx = step >> 2, t = step & 3;
+                    if (step + 1 < 4 * KS) {
+                        load_b(((step + 1) & 3) + ((step + 1) >> 2), (step + 1) & 1);
+                        if (((step + 1) & 3) == 0) load_a((step + 1) >> 2, ((step + 1) >> 2) & 1);
+                    }
+                    // keep the reads of step + 1 in front of the products of this step (hipcc sinks them to their first use and
+                    // waits lgkmcnt(0) in front of every group otherwise) and apart from later reads of the same slots
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ab = kx & 1, bb = step & 1;
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][0], bv[bb][1], acc[t][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][1], bv[bb][0], acc[t][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][0], bv[bb][0], acc[t][b], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#ifdef RISP_H2_STAMPS
+                ts1 = __builtin_amdgcn_s_memtime();
+                t_steps += ts1 - ts0;
+#endif
+#endif
+                ring = ring_next(ring, 1);
+                // the NEXT stage's pieces - issued one stage ago - must have landed; younger: this stage's pieces and, until the
+                // chunk's last stage, the tile prefetch issued behind the pieces of stage 0.  (ABL builds: plain vmcnt(0).)
+#if RISP_H2_ABL == 1
+                H2_WAIT_VM(0);
+#else
+                if (!dma) H2_WAIT_VM(0);
+                else if (ky + 1 < KS && ch + 1 < nchunks) H2_WAIT_VM(PW + LOADS);
+                else H2_WAIT_VM(PW);
+#endif
+                if (ky + 1 < KS) __syncthreads();
+            }
+#ifdef RISP_H2_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            H2STAMP(t1); t_mat += t1 - t0;
+#endif
+        }
+        // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias).  Lane (n, hl): couts 32 b + 8 (e >> 2) + 4 hl + (e & 3), the
+        // four pixels 4 (n & 15) .. + 3 of row 2 wave + (n >> 4) sit in the four pixel tiles: one 16-byte store per cout, 16 lanes
+        // = 256 contiguous bytes of a cout row.  The NEXT tile's first chunk is fetched first.
+#ifdef RISP_H2_STAMPS
+        const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+        const int en = n, oy = y0 + 2 * wave + (l31 >> 4), ox = x0 + 4 * (l31 & 15);
+#if RISP_H2_EARLY
+        if (more) {
+            setup(t_next);
+#if RISP_H2_ABL != 1
+            fetch(0);
+#endif
+        }
+#endif
+#if RISP_H2_ABL == 2
+        if (acc[0][0][0] == 123.456f) {
+#endif
+        const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+        const int epi = d.epilogue;
+        constexpr bool has_add = HAS_ADD, has_mask = HAS_MASK;
+        const float floor_ = (epi & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
+        const bool pixok = oy < d.H && ox < d.W;
+        // addresses = wave-uniform base (image, cout group: scalar registers) + one 32-bit lane offset (pixel, + 4 couts for the
+        // upper half-wave); cout % 8 == 0, so a group of 8 couts is valid or not as a whole (wave-uniform)
+        unsigned hw4e = hw4;                            // opaque copy: the 3 x 64 plane offsets below are tile-invariant, and hipcc
+        asm volatile("" : "+s"(hw4e));                  // would keep them all in scalar registers across the persistent loop (spilling them)
+        const unsigned loff = pixok ? 4u * (unsigned)(oy * d.W + ox) + 4u * hl * hw4 : 0u;
+        const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)en * d.cout * hw);
+        const __amdgpu_buffer_rsrc_t ra = h2_rsrc(has_add ? d.add + (size_t)en * d.add_c * hw : d.x);
+        const __amdgpu_buffer_rsrc_t rm = h2_rsrc(has_mask ? d.mask + (size_t)en * d.cout * hw : d.x);
+        // gfx9 counts loads and stores in one in-order counter: a load issued after a store returns only when that store has
+        // completed.  So the residual / mask rows are loaded in few, large batches (64 registers: 16 couts, 8 with both tensors),
+        // each batch in front of its own stores - one store round trip per batch instead of one per cout pair.  (Forming all
+        // results first and storing at the end would need none, but hipcc cannot reuse the accumulator registers element by
+        // element and spills the results.)
+        constexpr int EB = (HAS_ADD && HAS_MASK) ? 8 : 16, NB = 16 * NT / EB;
+        float4 av[HAS_ADD ? EB : 1], mv[HAS_MASK ? EB : 1];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            // batch g = couts [g * EB, g * EB + EB) in units of (b, j, i): cout = 32 b + 8 j + 4 hl + i
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const int c = g * EB + k, cu = (c >> 4) * 32 + 8 * ((c >> 2) & 3) + (c & 3);
+                if (has_add) av[k] = h2_load16(ra, loff, (unsigned)cu * hw4e);
+                if (has_mask) mv[k] = h2_load16(rm, loff, (unsigned)cu * hw4e);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const int c = g * EB + k, b = c >> 4, j = (c >> 2) & 3, i = c & 3, e = 4 * j + i, cu = b * 32 + 8 * j + i;
+                const float bb = lbias[cu + 4 * hl];
+                float4 o = make_float4(acc[0][b][e] * fin + bb, acc[1][b][e] * fin + bb, acc[2][b][e] * fin + bb, acc[3][b][e] * fin + bb);
+                if (has_add) {
+                    const float4 a4 = av[k];
+                    o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+                }
+                o.x = o.x > floor_ ? o.x : floor_;            // ReLU, or nothing (floor = -inf); NaN -> floor as the other kernels' ReLU
+                o.y = o.y > floor_ ? o.y : floor_;
+                o.z = o.z > floor_ ? o.z : floor_;
+                o.w = o.w > floor_ ? o.w : floor_;
+                if (has_mask) {
+                    const float4 mk = mv[k];
+                    o.x = mk.x > 0.f ? o.x : 0.f;
+                    o.y = mk.y > 0.f ? o.y : 0.f;
+                    o.z = mk.z > 0.f ? o.z : 0.f;
+                    o.w = mk.w > 0.f ? o.w : 0.f;
+                }
+                if (pixok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, loff, (unsigned)cu * hw4e, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if RISP_H2_ABL == 2
+        }
+#endif
+#ifdef RISP_H2_STAMPS
+        t_epi += __builtin_amdgcn_s_memtime() - t_loop_end;
+#endif
+        if (!more) break;
+#if !RISP_H2_EARLY
+        setup(t_next);
+#if RISP_H2_ABL != 1
+        fetch(0);
+#endif
+#endif
+        t_cur = t_next;
+    }
+#ifdef RISP_H2_STAMPS
+    if (lane == 0 && d.cvals) {                        // diagnostic build: cycle shares of a wave's life (tools/ab_f16x2.py)
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(d.cvals)) + 8 * ((size_t)blockIdx.x * 4 + wave);
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        o[0] = t_wait; o[1] = t_stage; o[2] = t_mat; o[3] = t_epi; o[4] = t_end - t_start;
+        o[5] = rt_start; o[6] = __builtin_amdgcn_s_memrealtime() | (t_steps << 40);
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[7] = hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
+}
+
+inline int h2_cu_count() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+
+template <int KS, int NT, bool HAS_ADD, bool HAS_MASK>
+int launch_f16x2(const risp_conv_desc &d, void *stream) {
+    using C = H2<KS, NT>;
+    auto kern = &conv_f16x2_kernel<KS, NT, HAS_ADD, HAS_MASK>;
+    if (C::LDS_BYTES > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+        risp_set_error("risp_conv2d_f16x2: cannot raise the dynamic LDS limit to %d bytes", C::LDS_BYTES);
+        return 2;
+    }
+    const int tx = (d.W + H2_TW - 1) / H2_TW, ty = (d.H + H2_TH - 1) / H2_TH;
+    const long long ntiles = (long long)tx * ty * d.N;
+    if (ntiles > 0x7fffffff) {
+        risp_set_error("risp_conv2d_f16x2: too many tiles");
+        return 1;
+    }
+#ifndef RISP_H2_WGS
+#define RISP_H2_WGS 2
+#endif
+    const int slots = RISP_H2_PERSIST ? RISP_H2_WGS * h2_cu_count() : 0x7fffffff;
+    const int grid = ntiles < slots ? (int)ntiles : slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, (hipStream_t)stream, d, tx, ty, (int)ntiles);
+    RISP_LAUNCH_CHECK("risp_conv2d_f16x2");
+    return 0;
+}
+
+template <int KS, int NT>
+int launch_f16x2_epi(const risp_conv_desc &d, void *stream) {
+    const bool a = (d.epilogue & RISP_EPI_ADD) != 0, m = (d.epilogue & RISP_EPI_MASK) != 0;
+    return a ? (m ? launch_f16x2<KS, NT, true, true>(d, stream) : launch_f16x2<KS, NT, true, false>(d, stream))
+             : (m ? launch_f16x2<KS, NT, false, true>(d, stream) : launch_f16x2<KS, NT, false, false>(d, stream));
+}
+}  // namespace
+
+extern "C" {
+
+#ifdef RISP_H2_STAMPS
+int risp_conv_f16x2_occupancy(void) {                 // diagnostic builds only: resident workgroups per CU
+    int nb = -1;
+    using C = H2<3, 2>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_f16x2_kernel<3, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_f16x2_kernel<3, 2, false, false>, 256, C::LDS_BYTES);
+    return nb;
+}
+#endif
+
+size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize) {
+    const int nt = (cout + 31) / 32, nch = (cin + H2_CK - 1) / H2_CK;
+    return 16 + (size_t)nch * ksize * ksize * 2 * 2 * nt * 32 * 16;
+}
+
+int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
+    RISP_CHECK_ARG(dp, "risp_conv2d_f16x2: null descriptor");
+    const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_f16x2: null tensor");
+    RISP_CHECK_ARG(d.group_n == 0, "risp_conv2d_f16x2: grouped launches are not supported");
+    RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cin % H2_CK == 0 && d.cout > 0 &&
+                       (d.cout == 32 || d.cout == 64) && d.ksize == 3 && (unsigned long long)(d.cout > d.cin ? d.cout : d.cin) * d.H * d.W < (1ull << 30) &&
+                       (!(d.epilogue & RISP_EPI_ADD) || d.add_c == d.cout),
+                   "risp_conv2d_f16x2: needs a 3x3 layer, cin %% 16 == 0, cout 32 or 64 (= add_c), W %% 4 == 0, fewer than 2^30 "
+                   "elements per image (N=%d H=%d W=%d cin=%d cout=%d k=%d)",
+                   d.N, d.H, d.W, d.cin, d.cout, d.ksize);
+    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_f16x2: only plain loads");
+    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
+                   "risp_conv2d_f16x2: epilogue %d not supported", d.epilogue);
+    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_f16x2: bias missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_f16x2: add tensor missing");
+    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_f16x2: mask tensor missing");
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
+                     reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
+                   "risp_conv2d_f16x2: tensors must be 16-byte aligned");
+    return d.cout == 64 ? launch_f16x2_epi<3, 2>(d, stream) : launch_f16x2_epi<3, 1>(d, stream);
+}
+
+}  // extern "C"
