@@ -460,6 +460,15 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
         const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
         const int en = n, oy = y0 + 2 * wave + (l31 >> 4), ox = x0 + 4 * (l31 & 15);
+#if RISP_H2_DBG & 4                                     // epilogue mapping check: every accumulator element = its own code
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][b][e] = (float)(((t * 2 + b) * 16 + e) * 64 + lane);
+        se = 0;
+#endif
 #if RISP_H2_EARLY
         if (more) {
             setup(t_next);
@@ -521,7 +530,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
                     o.z = mk.z > 0.f ? o.z : 0.f;
                     o.w = mk.w > 0.f ? o.w : 0.f;
                 }
-                if (pixok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, loff, (unsigned)cu * hw4e, 0);
+                // (plane offset in the VECTOR offset, scalar offset 0: a 16-byte buffer store reads its data registers late, and
+                // hipcc pads the following overwrite of them with wait states only for this form - with the plane in the scalar
+                // offset the last four lanes of every 16 stored the NEXT cout's values on gfx950)
+                if (pixok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, loff + (unsigned)cu * hw4e, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
