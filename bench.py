@@ -41,6 +41,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+MFMA_F16_PEAK_TFLOPS = 2516.6   # dense f16 / bf16 MFMA: 1024 FLOP / clk / SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF)
 
 ARCH_HBM = 'Bayer_02_Demosaic_01_sRGB_11_01_14'           # element-wise only: one fused launch
 ARCH_DENOISE = 'Demosaic_01_sRGB_07_11_01_14'             # nearest demosaic, bilateral, WbManual, Gamma, GtmManual
@@ -498,21 +499,41 @@ def main():
         cnn = build_pipeline(ARCH_CNN, device)
         steps_c = max(3, args.steps // 20)
         cstep = GraphedForward(cnn, bay) if graph else (lambda: cnn(bay))
-        with torch.no_grad():
-            wall_c, dev_ms_c = timed(lambda: cstep(), steps_c, 2, device, world)
-            CN.MFMA_ISSUED = [0.0]            # one more forward, counting the FLOPs its launches issue on the matrix cores
-            cnn(bay)
-            issued, CN.MFMA_ISSUED = CN.MFMA_ISSUED[0], None
+        def cnn_leg(arith):
+            # the wide 3x3 layers in split precision on the f16 matrix pipe (the product's default) or on the fp32 matrix cores
+            keep, CN.CONV_ARITH = CN.CONV_ARITH, arith
+            try:
+                with torch.no_grad():
+                    cstep()                           # (a graphed forward was captured with the default arithmetic)
+                    wall, dev_ms = timed(lambda: cstep(), steps_c, 2, device, world)
+                    CN.MFMA_ISSUED, CN.MFMA_ISSUED_F16 = [0.0], [0.0]      # one more forward, counting the FLOPs its launches issue
+                    cnn(bay)
+                    f32, f16 = CN.MFMA_ISSUED[0], CN.MFMA_ISSUED_F16[0]
+            finally:
+                CN.MFMA_ISSUED = CN.MFMA_ISSUED_F16 = None
+                CN.CONV_ARITH = keep
+            return wall, dev_ms, f32, f16
+        wall_c, dev_ms_c, issued, issued16 = cnn_leg(CN.CONV_ARITH)
+        tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12
         extra.update(cnn_arch=ARCH_CNN, cnn_MPix_s=round(world * pix_per_step * steps_c / wall_c / 1e6, 1),
                      cnn_ms_per_step=round(dev_ms_c, 3),
-                     cnn_effective_TFLOPs=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12, 2),
-                     cnn_effective_frac=round(FLOP_PER_PIX_CNN * pix_per_step / (dev_ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     cnn_mfma_issued_TFLOPs=round(issued / (dev_ms_c * 1e-3) / 1e12, 2),
-                     cnn_mfma_issued_frac=round(issued / (dev_ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                     cnn_note='effective = direct-convolution FLOPs (SURVEY 8d) / time; issued = FLOPs of the MFMA '
-                              'instructions the launches actually execute (Winograd F(4,3) halves the 3x3 layers, cout '
-                              'padded to 32; the small-cout layers run on vector FMAs and count 0) / time: the matrix-pipe '
-                              'utilisation is the ISSUED fraction')
+                     cnn_arith=('2 x f16 split (3 products, f32 accumulate) for the 3x3 64->64 layers, f32 elsewhere'
+                                if CN.CONV_ARITH == 'f16x2' else 'f32'),
+                     cnn_effective_TFLOPs=round(tf(FLOP_PER_PIX_CNN * pix_per_step, dev_ms_c), 2),
+                     cnn_effective_frac=round(tf(FLOP_PER_PIX_CNN * pix_per_step, dev_ms_c) / MFMA_F32_PEAK_TFLOPS, 4),
+                     cnn_mfma_issued_TFLOPs=round(tf(issued, dev_ms_c), 2),
+                     cnn_mfma_f16_issued_TFLOPs=round(tf(issued16, dev_ms_c), 2),
+                     cnn_mfma_issued_frac=round(tf(issued, dev_ms_c) / MFMA_F32_PEAK_TFLOPS + tf(issued16, dev_ms_c) / MFMA_F16_PEAK_TFLOPS, 4),
+                     cnn_note='effective = direct-convolution FLOPs (SURVEY 8d) / time, priced against the F32 matrix peak (it '
+                              'exceeds 1 where Winograd or the f16 pipe do the work: not a utilisation); issued = FLOPs of the MFMA '
+                              'instructions the launches execute (Winograd halves the fp32 3x3 layers, cout padded to 32; the '
+                              'split-precision layers issue 3 f16 products per tap; the small-cout layers run on vector FMAs '
+                              'and count 0); cnn_mfma_issued_frac = f32 issued / %.1f + f16 issued / %.1f TFLOP/s: the share of the '
+                              'time the matrix pipes are busy at their nameplate rates' % (MFMA_F32_PEAK_TFLOPS, MFMA_F16_PEAK_TFLOPS))
+        if CN.CONV_ARITH != 'f32' and not graph:
+            wall_f, dev_ms_f, issued_f, _ = cnn_leg('f32')
+            extra.update(cnn_f32_MPix_s=round(world * pix_per_step * steps_c / wall_f / 1e6, 1), cnn_f32_ms_per_step=round(dev_ms_f, 3),
+                         cnn_f32_mfma_issued_frac=round(tf(issued_f, dev_ms_f) / MFMA_F32_PEAK_TFLOPS, 4))
     if not args.no_search:
         # a secondary leg must never cost the headline line, at any N: on a failure it reports the error instead.  (Every
         # rank runs the same code on the same shapes, so a failure - out of memory, a bad shape - is raised on all of

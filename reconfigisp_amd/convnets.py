@@ -137,6 +137,12 @@ def f16x2_weights(w, transpose):
 
 
 WINO_F45 = os.environ.get('RISP_WINO_F45', '1') != '0'       # 5x5: F(4,5) where cin % 4 == 0 (default), else F(2,5)
+# Arithmetic of the wide hidden layers (3x3, cin % 16 == 0, cout 32 / 64): 'f16x2' (default) = split precision on the f16 matrix
+# pipe - each fp32 operand as two f16 halves, three products, fp32 accumulation (risp_conv2d_f16x2: fp32 tensors in and out,
+# error against float64 no larger than the fp32 kernels'); 'f32' = the fp32 matrix-core kernels (Winograd F(4,3) / F(2,3)).
+CONV_ARITH = os.environ.get('RISP_CONV_ARITH', 'f16x2')
+if CONV_ARITH not in ('f16x2', 'f32'):
+    raise ValueError("RISP_CONV_ARITH must be 'f16x2' or 'f32', got %r" % CONV_ARITH)
 
 
 def _wino5_pack(w, transpose):
@@ -210,6 +216,11 @@ class PackedConv:
         self.wino_fwd = self.wino_bwd = None
         self.wino_entry = self.wino43_fwd = self.wino43_bwd = None
         self.wino45_fwd = self.wino45_bwd = None
+        self.f16x2_fwd = self.f16x2_bwd = None
+        if self.k == 3:                                 # split-precision packs (see CONV_ARITH); either direction on its own
+            ok = lambda ci, co: ci % 16 == 0 and co in (32, 64)
+            self.f16x2_fwd = f16x2_weights(w, False) if ok(self.cin, self.cout) else None
+            self.f16x2_bwd = f16x2_weights(w, True) if ok(self.cout, self.cin) else None
         # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
         self.k3 = k3_weights(w) if (self.k in (3, 9) and self.cin in (3, 4) and self.cout <= 64) else None
         if self.k == 3 and WINOGRAD:
@@ -278,6 +289,9 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
 # bench.py sets this to [0.0] to count the FLOPs the launches ISSUE on the matrix cores (diagnostic; None = off)
 MFMA_ISSUED = None
 _TAPS = {'risp_conv2d_wino3': (12, 2), 'risp_conv2d_wino43': (18, 4), 'risp_conv2d_wino5': (30, 2), 'risp_conv2d_wino45': (40, 4)}
+# ... and, separately, the FLOPs the split-precision launches issue on the f16 matrix pipe (3 products per tap) and the time-free
+# count of such launches: bench.py prices the two pipes against their own peaks
+MFMA_ISSUED_F16 = None
 
 
 def _issued_flops(entry, cin, cout, k, pixels):
@@ -326,10 +340,16 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     w45 = getattr(pc, 'wino45_bwd' if transpose else 'wino45_fwd', None)
     if w45 is not None and WINO_F45:                  # 5x5 layers whose launch has cin % 4 == 0: F(4,5), 2/3 of F(2,5)'s matrix work
         wino, entry = w45, 'risp_conv2d_wino45'
-    use_wino = (wino is not None and load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
-                (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
-                 (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
+    plain16 = (load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
+               (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
+                (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
+    use_wino = wino is not None and plain16
     wpack = wino if use_wino else (pc.bwd if transpose else pc.fwd)
+    h2 = getattr(pc, 'f16x2_bwd' if transpose else 'f16x2_fwd', None)
+    if (CONV_ARITH == 'f16x2' and h2 is not None and plain16 and group is None and (add is None or add_c == cout)
+            and max(cin, cout) * h * w < (1 << 30)):
+        # wide 3x3 layer: split precision on the f16 matrix pipe (same tensors, same epilogue flags, its own pack)
+        wpack, entry, use_wino = h2, 'risp_conv2d_f16x2', True
     if (K3 and getattr(pc, 'k3', None) is not None and not transpose and w % 4 == 0 and h >= pc.k - 1 and w >= pc.k - 1
             and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
             and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS)) and (x.data_ptr() | out.data_ptr()) % 16 == 0):
@@ -339,7 +359,10 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
     _group_fields(d, n, group, wpack, None if transpose else pc.bias)
     L.call(entry if use_wino else 'risp_conv2d', C.byref(d), _stream())
-    if MFMA_ISSUED is not None:
+    if entry == 'risp_conv2d_f16x2':
+        if MFMA_ISSUED_F16 is not None:
+            MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * pc.k * cin * cout * nn_ * h * w
+    elif MFMA_ISSUED is not None:
         MFMA_ISSUED[0] += _issued_flops(entry if use_wino else 'risp_conv2d', cin, cout, pc.k, nn_ * h * w)
     return out
 
@@ -688,7 +711,9 @@ class _Stacked:
 
 
 def stack_packed(pcs):
-    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd'), ('cin', 'cout', 'k', 'wino_entry'))
+    st = _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd'), ('cin', 'cout', 'k', 'wino_entry'))
+    st.f16x2_fwd = st.f16x2_bwd = None              # grouped launches stay on the fp32 kernels
+    return st
 
 
 def stack_small(scs):

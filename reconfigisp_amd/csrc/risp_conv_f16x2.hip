@@ -252,9 +252,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
         const uint4 *src = wpack + (size_t)stage * WST;
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
-            const int piece = wave + 4 * p;
-            const bool real = piece < WST / 64;                      // every wave issues PW instructions: the same vmcnt arithmetic
-            lds_dma16_s(src + (real ? piece : 0) * 64, lane * 16, dst + (real ? piece : 0) * 64, __builtin_amdgcn_ballot_w64(real));
+            // every wave issues PW instructions, so that the counted vmcnt waits are the same arithmetic for all of them: a wave
+            // without a piece of its own repeats an earlier one (same bytes to the same place).  A transfer with EXEC = 0 is not
+            // a substitute - it does not count in vmcnt, and the waves issuing it then waited for one transfer too few.
+            const int piece = (wave + 4 * p) % (WST / 64);
+            lds_dma16_s(src + piece * 64, lane * 16, dst + piece * 64);
         }
     };
     auto ring_next = [&](int r, int k) { return r + k >= C::RING ? r + k - C::RING : r + k; };
@@ -519,10 +521,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
                     const float4 a4 = av[k];
                     o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
                 }
-                o.x = o.x > floor_ ? o.x : floor_;            // ReLU, or nothing (floor = -inf); NaN -> floor as the other kernels' ReLU
-                o.y = o.y > floor_ ? o.y : floor_;
-                o.z = o.z > floor_ ? o.z : floor_;
-                o.w = o.w > floor_ ? o.w : floor_;
+                o.x = o.x < floor_ ? floor_ : o.x;            // ReLU, or nothing (floor = -inf); a NaN stays a NaN (torch.relu)
+                o.y = o.y < floor_ ? floor_ : o.y;
+                o.z = o.z < floor_ ? floor_ : o.z;
+                o.w = o.w < floor_ ? floor_ : o.w;
                 if (has_mask) {
                     const float4 mk = mv[k];
                     o.x = mk.x > 0.f ? o.x : 0.f;

@@ -364,12 +364,13 @@ def test_inference_dispatch_f43(cin, cout, hw, monkeypatch):
 
 @pytest.mark.parametrize('cout', [64, 33])
 @pytest.mark.parametrize('hw', [(8, 8), (20, 36), (33, 32), (64, 256), (6, 260)])
-def test_f43_both_cout_blocks_in_one_wave_equals_per_block_launches(cout, hw):
+def test_f43_both_cout_blocks_in_one_wave_equals_per_block_launches(cout, hw, monkeypatch):
     """conv_wino43_b2_kernel keeps both 32-cout blocks of a 33..64-cout layer in one wave (one input transform feeds twelve
     matrix instructions); per output it performs the one-block kernel's arithmetic in the same order, so the layer launched
     as two separate 32-cout layers (the one-block kernel) must give the same bits - forward and backward-data packs, every
-    epilogue."""
+    epilogue.  (The fp32 route: RISP_CONV_ARITH=f32.)"""
     from reconfigisp_amd import convnets as CN
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
     h, w = hw
     n, cin = 3, 64
     wt, b = rnd(cout, cin, 3, 3, seed=81) * 0.05, rnd(cout, seed=82) * 0.1

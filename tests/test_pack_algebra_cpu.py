@@ -239,3 +239,91 @@ def test_winograd45_pack_forward_and_backward_data(cin, cout):
             gref, = torch.autograd.grad(ref, x, gy, retain_graph=True)
             got = wino45_emulate(gy, CN.wino45_weights(wt, True, 4, layout), 4, cin, layout)
             assert torch.allclose(got, gref, rtol=1e-9, atol=1e-9)
+
+
+# --------------------------------------------------------------------------- split precision (risp_conv2d_f16x2)
+def _split16(v, s):
+    vs = v * s
+    hi = vs.half()
+    return hi, (vs - hi.float()).half()
+
+
+def _pow2_scale(t):
+    """s = 2^k with max|t| s in [2^14, 2^15) - the rule of convnets.f16x2_weights and of the kernel's per-tile scale"""
+    _, e = torch.frexp(t.abs().max())
+    return torch.ldexp(torch.ones(()), 15 - e)
+
+
+def _emulate_f16x2(x, w, k):
+    """x w ~ (x_lo w_hi + x_hi w_lo + x_hi w_hi) / (s_x s_w) with f16 halves; per tap and 16-channel block the products are
+    summed exactly (they are exact in fp32; float64 here) and added to an fp32 accumulator - one rounding per matrix instruction,
+    in the kernel's order (lo-hi, hi-lo, hi-hi)"""
+    sx, sw = _pow2_scale(x), _pow2_scale(w)
+    (xh, xl), (wh, wl) = _split16(x, sx), _split16(w, sw)
+    n, c, h, ww = x.shape
+    p = k // 2
+    xp = [torch.nn.functional.pad(t.double(), (p, p, p, p)) for t in (xh, xl)]
+    wp = [wh.double(), wl.double()]
+    acc = torch.zeros((n, w.shape[0], h, ww), dtype=torch.float32)
+    for c0 in range(0, c, 16):
+        for ky in range(k):
+            for kx in range(k):
+                for i, j in ((1, 0), (0, 1), (0, 0)):
+                    part = torch.einsum('nchw,oc->nohw', xp[i][:, c0:c0 + 16, ky:ky + h, kx:kx + ww], wp[j][:, c0:c0 + 16, ky, kx])
+                    acc = (acc.double() + part).float()
+    return acc / (sx * sw)
+
+
+def _fma_chain(x, w, k):
+    """what v_mfma_f32_32x32x2_f32 is: one fp32 rounding of the running sum per product"""
+    n, c, h, ww = x.shape
+    p = k // 2
+    xp = torch.nn.functional.pad(x, (p, p, p, p))
+    acc = torch.zeros((n, w.shape[0], h, ww), dtype=torch.float32)
+    for c0 in range(c):
+        for ky in range(k):
+            for kx in range(k):
+                acc = (acc.double() + xp[:, c0, ky:ky + h, kx:kx + ww].double()[:, None] * w[:, c0, ky, kx].double()[None, :, None, None]).float()
+    return acc
+
+
+@pytest.mark.parametrize('case', ['3x3 activations', '5x5 activations', '3x3 gradients'])
+def test_f16x2_split_numerics(case):
+    """The scheme of risp_conv_f16x2.hip against float64, beside the fp32 FMA chain the fp32 matrix instruction is: its rms error
+    must not be larger (measured: about half - its error is per product, a random walk, where the chain rounds the running sum
+    at every step), for activations in [0,1) and for sparse upstream gradients of magnitude 1e-5."""
+    torch.manual_seed(0)
+    k, cout = (5, 32) if case.startswith('5x5') else (3, 64)
+    x = torch.rand(1, 64, 20, 20)
+    if case.endswith('gradients'):
+        x = torch.randn(1, 64, 20, 20) * 1e-5 * (torch.rand(1, 64, 20, 20) > 0.5)
+    w = (torch.rand(cout, 64, k, k) - 0.5) * 2 / (64 * k * k) ** 0.5
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=k // 2)
+    m = ref.abs().max()
+    rms = lambda y: ((y.double() - ref).pow(2).mean().sqrt() / m).item()
+    e_split, e_chain = rms(_emulate_f16x2(x, w, k)), rms(_fma_chain(x, w, k))
+    assert e_split <= e_chain, (e_split, e_chain)
+    assert e_split < 1.2e-7
+
+
+def test_f16x2_weight_pack_layout_and_scale():
+    """convnets.f16x2_weights: header = 1 / s_w, body [chunk][tap][hi, lo][channel half][cout][8]; hi + lo reproduces w s_w to 2^-22;
+    the transposed pack is the backward-data layer"""
+    from reconfigisp_amd import convnets as CN
+    torch.manual_seed(1)
+    for co, ci in ((64, 64), (32, 64), (40, 32)):
+        w = torch.randn(co, ci, 3, 3) * 0.05
+        for tr in (False, True):
+            p = CN.f16x2_weights(w, tr)
+            wt = w.flip(2, 3).transpose(0, 1) if tr else w
+            o, i = wt.shape[0], wt.shape[1]
+            nt, nch = (o + 31) // 32, (i + 15) // 16
+            assert p.dtype == torch.float16 and p.numel() == 8 + nch * 9 * 2 * 2 * nt * 32 * 8
+            inv = p[:2].view(torch.float32).item()
+            sw = 1.0 / inv
+            assert 2.0 ** 14 <= wt.abs().max().item() * sw < 2.0 ** 15 and sw == 2.0 ** round(np.log2(sw))
+            body = p[8:].view(nch, 9, 2, 2, nt * 32, 8).float()
+            rec = ((body[:, :, 0] + body[:, :, 1]) * inv).permute(3, 0, 2, 4, 1).reshape(nt * 32, nch * 16, 3, 3)
+            assert (rec[:o, :i] - wt).abs().max().item() <= 2.0 ** -22 * wt.abs().max().item()
+            assert rec[o:].abs().max().item() == 0 if o < nt * 32 else True
+            assert body[:, :, 0].abs().max().item() < 2.0 ** 15
