@@ -296,7 +296,8 @@ size_t risp_conv_wino45_wpack_floats(int cin, int cout);
 int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
 
 /* The same operator on the f16 matrix pipe at fp32-level accuracy (round 4; the 64 -> 64 3x3 layers of Path-Restore,
- * path_14l_bgr_arch.py:6-21, 58-86; path_14l_bayer_arch.py:59-88): every fp32 operand is cut into two f16 halves,
+ * path_14l_bgr_arch.py:6-21, 58-86; path_14l_bayer_arch.py:59-88; the 5x5 64 -> 32 layer of SRCNNRes and its backward,
+ * srcnn_res_arch.py:20): every fp32 operand is cut into two f16 halves,
  * hi = rn_f16(v s), lo = rn_f16(v s - hi), and x w is taken as (x_lo w_hi + x_hi w_lo + x_hi w_hi) / (s_x s_w) - three
  * v_mfma_f32_32x32x16_f16 with fp32 accumulation instead of eight fp32 matrix instructions of twice the duration; the
  * dropped term is 2^-22 of the product.  x, y, add, mask stay fp32 tensors: the activations are scaled (per workgroup tile
@@ -304,8 +305,9 @@ int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
  * activations of magnitude 1) and split at staging time; the weights are scaled and split once, at pack time.
  * wpack: risp_conv_f16x2_wpack_bytes() bytes, 16-byte aligned: a 16-byte header whose first float is 1 / s_w (s_w = 2^k with
  * max|w| s_w in [2^14, 2^15)), then [chunk of 16 cin][tap][part: hi, lo][channel half][cout padded to 32 or 64][8 channels]
- * _Float16 (reconfigisp_amd/convnets.py::f16x2_weights).  ksize 3, cin % 16 == 0, cout <= 64, W % 4 == 0, 16-byte aligned
- * tensors, load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS.  A tile's result does not depend on the batch it travels in. */
+ * _Float16 (reconfigisp_amd/convnets.py::f16x2_weights).  ksize 3 or 5, cin % 16 == 0, cout 32 or 64, add_c == cout, W % 4 == 0,
+ * fewer than 2^30 elements per image, 16-byte aligned tensors, load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS; grouped
+ * launches (group_n, strides in floats).  A tile's result does not depend on the batch it travels in. */
 size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
 

@@ -217,7 +217,7 @@ class PackedConv:
         self.wino_entry = self.wino43_fwd = self.wino43_bwd = None
         self.wino45_fwd = self.wino45_bwd = None
         self.f16x2_fwd = self.f16x2_bwd = None
-        if self.k == 3:                                 # split-precision packs (see CONV_ARITH); either direction on its own
+        if self.k in (3, 5):                            # split-precision packs (see CONV_ARITH); either direction on its own
             ok = lambda ci, co: ci % 16 == 0 and co in (32, 64)
             self.f16x2_fwd = f16x2_weights(w, False) if ok(self.cin, self.cout) else None
             self.f16x2_bwd = f16x2_weights(w, True) if ok(self.cout, self.cin) else None
@@ -256,7 +256,7 @@ def _group_fields(d, n, group, wpack, bias):
     if wpack.shape[0] != g or (bias is not None and bias.shape[0] != g):
         raise ValueError('grouped launch: %d members but the stacked packs hold %d' % (g, wpack.shape[0]))
     d.group_n, d.group_flags = n, flags
-    d.wpack_gs = wpack.stride(0)
+    d.wpack_gs = wpack.stride(0) * wpack.element_size() // 4        # in floats, whatever the pack's dtype
     d.bias_gs = bias.stride(0) if bias is not None else 0
     d.N = g * n
     return g * n
@@ -346,9 +346,9 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     use_wino = wino is not None and plain16
     wpack = wino if use_wino else (pc.bwd if transpose else pc.fwd)
     h2 = getattr(pc, 'f16x2_bwd' if transpose else 'f16x2_fwd', None)
-    if (CONV_ARITH == 'f16x2' and h2 is not None and plain16 and group is None and (add is None or add_c == cout)
+    if (CONV_ARITH == 'f16x2' and h2 is not None and plain16 and (add is None or add_c == cout)
             and max(cin, cout) * h * w < (1 << 30)):
-        # wide 3x3 layer: split precision on the f16 matrix pipe (same tensors, same epilogue flags, its own pack)
+        # wide 3x3 / 5x5 layer: split precision on the f16 matrix pipe (same tensors, same epilogue flags, its own pack)
         wpack, entry, use_wino = h2, 'risp_conv2d_f16x2', True
     if (K3 and getattr(pc, 'k3', None) is not None and not transpose and w % 4 == 0 and h >= pc.k - 1 and w >= pc.k - 1
             and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
@@ -711,9 +711,8 @@ class _Stacked:
 
 
 def stack_packed(pcs):
-    st = _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd'), ('cin', 'cout', 'k', 'wino_entry'))
-    st.f16x2_fwd = st.f16x2_bwd = None              # grouped launches stay on the fp32 kernels
-    return st
+    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd'),
+                    ('cin', 'cout', 'k', 'wino_entry'))
 
 
 def stack_small(scs):

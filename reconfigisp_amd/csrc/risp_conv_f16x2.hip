@@ -10,25 +10,29 @@
 // (tests/test_pack_algebra_cpu.py::test_f16x2_split_numerics: 64-channel 3x3 and 5x5 rows, activations in [0,1) and
 // gradient-like inputs of magnitude 1e-5) the emulated scheme has HALF the rms error of the fp32 FMA chain the fp32 matrix
 // instruction is (5.3e-8 vs 1.1e-7 of max|y|), because its error is per product (random walk) where the chain rounds the
-// running sum at every step; the GPU tests compare the kernel itself with float64.
+// running sum at every step; tests/test_gpu_f16x2.py compares the kernel itself with float64, beside the fp32 kernels.
 //
 // Range.  f16 has 5 exponent bits: hi overflows above 65504 and lo loses bits below 2^-14.  Weights are scaled per LAYER at
 // pack time (s_w = 2^k puts max|w| into [2^14, 2^15)).  Activations / upstream gradients are scaled per WORKGROUP TILE and
-// CHUNK of 16 input channels at staging time: the tile's largest magnitude (wave shuffles + one LDS row, no extra barrier)
+// CHUNK of 16 input channels at staging time: the tile's largest magnitude (DPP butterflies + one LDS row, no extra barrier)
 // picks s_x = 2^e with max|x| s_x in [2^14, 2^15); the accumulators carry the running exponent and are rescaled (exact:
 // a power of two) only when a later chunk needs a smaller one.  Everything down to 2^-17 of the tile's maximum keeps its 22
 // bits, below that the absolute error is 2^-39 of the maximum.  No inter-kernel state, deterministic, and a gradient tensor
 // of magnitude 1e-8 is as exact as an activation tensor of magnitude 1.
 //
-// Kernel.  Workgroup = 4 waves = 8 rows x 64 pixels x all (<= 64) couts; a wave owns 2 rows x 64 pixels = 4 matrix tiles of
-// 32 pixels x 2 cout blocks of 32 (128 accumulator registers); MFMA rows (A) are PIXELS and columns (B) couts, so that a lane
-// ends with 16 consecutive pixels of a cout row: 16-byte stores without an LDS transposition.  Per chunk of 16 input
-// channels the halo tile is staged through registers (8 x 16-byte loads per thread = 4 pixels x 8 channels, scaled, split,
-// 8 x ds_write_b128) and the chunk's weights (all taps, hi and lo) arrive by LDS-DMA from the pre-split pack.
-// LDS layout: one 16-byte slot = the hi (or lo) halves of 8 channels of one pixel = exactly one lane's A operand.  Within a
+// Kernel.  Workgroup = 4 waves = 8 rows x 64 pixels x NT cout blocks of 32; a wave owns 2 rows x 64 pixels = 4 pixel tiles of
+// 32 (B operand) x NT cout blocks (A operand): lane (n, half) of pixel tile t holds row (n >> 4), column 4 (n & 15) + t, so that
+// the four tiles give a lane four CONSECUTIVE pixels of a cout row - 16-byte stores, 16 lanes = 256 contiguous bytes, no LDS
+// transposition.  Per chunk of 16 input channels the halo tile is staged through registers (8 x 16-byte loads per thread = 4
+// pixels x 8 channels, scaled, split, 8 x ds_write_b128); the weights arrive pre-split by LDS-DMA, one STAGE = one filter row
+// of one chunk at a time, through a ring of LDS buffers that runs ahead of the matrix instructions.
+// LDS layout: one 16-byte slot = the hi (or lo) halves of 8 channels of one pixel = exactly one lane's B operand.  Within a
 // tile row the slot of column c is (c & 3) * 17 + (c >> 2): the staging lanes (4 consecutive columns each) write consecutive
-// slots, and a matrix tile takes pixel column 4 Q + r for lanes (Q = lane & 15, r = tile bit, lane bit 4), so that 16 consecutive
-// lanes read 16 consecutive slots for every tap shift: both directions are free of bank conflicts.
+// slots, and the 16 lanes of a pixel tile read 16 consecutive slots for every tap shift: both directions are free of bank
+// conflicts.
+// PERSISTENT workgroups, 2 per CU, each walks tiles id, id + gridDim.x, ...: a tile's stores are never waited for (they drain
+// while the next tile is staged), and nothing runs in chip-wide lockstep rounds.  Consecutive workgroup ids sit on different
+// XCDs (8 L2s): XCD k takes the k-th contiguous eighth of each sweep, so that tiles sharing halo rows share an L2.
 #include "risp_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,25 +52,8 @@ __device__ __forceinline__ float h2_load4(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-#ifndef RISP_H2_EARLY
-#define RISP_H2_EARLY 0      // 1: the next tile's first chunk is fetched in front of the epilogue's stores (needs 42 more live registers there)
-#endif
-#ifndef RISP_H2_STAGGER
-#define RISP_H2_STAGGER 100  // start delay of the second workgroup of a CU, in percent of a tile's matrix-instruction time (0 = off)
-#endif
-#ifndef RISP_H2_PERSIST
-#define RISP_H2_PERSIST 1    // 0: one workgroup per tile
-#endif
-#ifndef RISP_H2_DBG
-#define RISP_H2_DBG 0
-#endif
-#ifndef RISP_H2_ABL
-#define RISP_H2_ABL 0        // diagnostic builds (tools/ab_f16x2.py; outputs wrong, only the time matters): 1 no staging after the first chunk, 2 no epilogue, 3 no matrix instructions, 4 no operand reads after the first tap
-#endif
-
 namespace {
 constexpr int H2_TH = 8, H2_TW = 64, H2_S = 17, H2_RS = 4 * H2_S, H2_CK = 16;
-constexpr int h2_half_grid_min = 256;    // stagger only when every CU holds two workgroups
 
 template <int KS, int NT>
 struct H2 {
@@ -74,12 +61,13 @@ struct H2 {
     static constexpr int PART = 2 * IH * H2_RS;                  // 16-byte slots of one part (hi or lo): [channel half][row][slot]
     static constexpr int TILE = 2 * PART;
     static constexpr int WST = KS * 2 * 2 * NT * 32;             // weight slots of one stage = one filter row: [kx][part][channel half][cout]
-    static constexpr int RING = 3;                               // weight stages in LDS: transfers run two stages ahead
+    // weight stages in LDS; the transfers run RING - 1 stages ahead.  3x3: three (80 KB per workgroup, two workgroups per CU);
+    // 5x5 (12 tile rows): two.
+    static constexpr int RING = KS == 3 ? 3 : 2;
     static constexpr int PW = (WST / 64 + 3) / 4;                 // LDS-DMA instructions per wave and stage (the same for every wave)
-    static constexpr int LDS_BYTES = (TILE + RING * WST) * 16 + 64 + 256;  // tile, weight ring, the row of maxima, the bias
-    static constexpr int HALO_ROW_TASKS = 2 * P * 32, HALO_COL_TASKS = IH * 2 * P * 2;
+    static constexpr int LDS_BYTES = (TILE + RING * WST) * 16 + 64 + 2 * 256;    // tile, weight ring, the row of maxima, the bias (x 2)
     static_assert(WST % 64 == 0, "weight stage in whole LDS-DMA pieces");
-    static_assert(HALO_ROW_TASKS + HALO_COL_TASKS <= 256, "one extra staging pass");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
 __device__ __forceinline__ float comp(const float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
@@ -117,30 +105,29 @@ __device__ __forceinline__ float amax4(float m, const float4 &v) {
     return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
 }
 
+#define H2_WAIT_VM(keep) __builtin_amdgcn_s_waitcnt(0x0F70 | ((keep) & 15) | (((keep) >> 4) << 14))      /* s_waitcnt vmcnt(keep) */
+#ifdef RISP_H2_STAMPS
+#define H2STAMP(v) do { __builtin_amdgcn_s_waitcnt(0xC07F); v = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define H2STAMP(v) do { } while (0)
+#endif
+
 // HAS_ADD / HAS_MASK: epilogue flags as template parameters - with run-time flags the epilogue is a chain of wave-uniform
-// branches around its loads, hipcc spills what the loads return and waits vmcnt(0) behind every block.  cout == 32 NT.
+// branches around its loads, hipcc spills what the loads return and waits vmcnt(0) behind every block.
+// ncb: cout blocks of 32 NT in the tile index (a 64-cout layer on the NT = 1 kernel is two tiles per pixel tile).
 template <int KS, int NT, bool HAS_ADD, bool HAS_MASK>
-__global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ncb, int ntiles) {
     using C = H2<KS, NT>;
-    constexpr int P = C::P, IH = C::IH, S = H2_S, RS = H2_RS, WST = C::WST;
+    constexpr int P = C::P, IH = C::IH, S = H2_S, RS = H2_RS, WST = C::WST, RING = C::RING, AHEAD = RING - 1;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *tile = smem, *wl = smem + C::TILE;
-    float *red = reinterpret_cast<float *>(wl + C::RING * WST);            // 4 floats: per-wave maxima of the chunk being staged
-    float *lbias = red + 16;                                         // 64 floats (LDS reads do not queue behind the stores)
+    float *red = reinterpret_cast<float *>(wl + RING * WST);         // 4 floats: per-wave maxima of the chunk being staged
+    float *lbias = red + 16;                                         // 2 x 64 floats, by tile parity (LDS reads do not queue behind the stores)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hl = lane >> 5;
     const int nchunks = d.cin / H2_CK, nstages = nchunks * KS;
     const size_t hw = (size_t)d.H * d.W;
-    const uint4 *wpack = reinterpret_cast<const uint4 *>(d.wpack) + 1;       // slot 0 = header
-    const float inv_sw = *reinterpret_cast<const float *>(d.wpack);
-
-    // PERSISTENT workgroups: 2 per CU, each walks tiles id, id + gridDim.x, ...  The stores of a tile are never waited for:
-    // they drain while the next tile is staged and multiplied, and the next tile's first chunk is fetched BEFORE them (loads
-    // and stores return in issue order).  One workgroup per tile ran in lockstep rounds - every workgroup of the chip in its
-    // store epilogue at the same time, the matrix pipes idle, then every memory channel idle through the matrix phases.
-    // Consecutive workgroup ids sit on different XCDs (8 L2s): XCD k takes the k-th contiguous eighth of each sweep, so that
-    // tiles sharing halo rows share an L2.
     const int nwg = gridDim.x;
     const int wg = (nwg & 7) == 0 ? (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
 
@@ -166,15 +153,30 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
         const int c = cc < P ? cc : H2_TW + cc;
         dstc[k] = id < IH * 2 * P * 8 ? (((cp >> 2) * IH + ir) * RS + (c & 3) * S + (c >> 2)) * 16 + (cp & 3) * 4 : -1;
     }
-    int x0, y0, n;                                                          // the tile being staged
-    __amdgpu_buffer_rsrc_t rx;                                              // its image
-    const unsigned hw4 = (unsigned)hw * 4u;                                 // bytes of a plane (cin * H * W < 2^30: checked by the entry point)
-    auto setup = [&](int t) {
-        n = t / (tiles_x * tiles_y);
-        const int rem = t - n * (tiles_x * tiles_y), ty = rem / tiles_x;
-        x0 = (rem - ty * tiles_x) * H2_TW;
-        y0 = ty * H2_TH;
-        rx = h2_rsrc(d.x + (size_t)n * d.cin * hw);
+    const unsigned hw4 = (unsigned)hw * 4u;                                 // bytes of a plane (max(cin, cout) * H * W < 2^30: checked by the entry point)
+    // the tile being staged: image / member, cout block, corner; its tensors as the launch's group layout has them
+    struct TileRef {
+        int n, cb, x0, y0;
+        const uint4 *w;                                                     // the member's pack
+    };
+    TileRef cur;
+    __amdgpu_buffer_rsrc_t rx;
+    int parity = 0;
+    auto locate = [&](int t, TileRef &r) {
+        r.cb = t % ncb;
+        const int q = t / ncb;
+        r.n = q / (tiles_x * tiles_y);
+        const int rem = q - r.n * (tiles_x * tiles_y), ty = rem / tiles_x;
+        r.x0 = (rem - ty * tiles_x) * H2_TW;
+        r.y0 = ty * H2_TH;
+        const int g = d.group_n > 0 ? r.n / d.group_n : 0;
+        r.w = reinterpret_cast<const uint4 *>(d.wpack + (size_t)g * d.wpack_gs);
+    };
+    auto setup = [&](const TileRef &r) {                                    // staging addresses + the bias row of tile r
+        const int g = d.group_n > 0 ? r.n / d.group_n : 0;
+        const int nx = (d.group_flags & RISP_GROUP_SHARED_X) ? r.n - g * d.group_n : r.n;
+        rx = h2_rsrc(d.x + (size_t)nx * d.cin * hw);
+        const int x0 = r.x0, y0 = r.y0;
         const int gy1 = y0 + r1, gx1 = x0 + 4 * q1;
         ok1 = gy1 < d.H && gx1 < d.W;
         off1 = ok1 ? 8u * g1 * hw4 + 4u * (unsigned)(gy1 * d.W + gx1) : 0u;
@@ -192,6 +194,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
             const int gy = y0 - P + ir, gx = x0 - P + (cc < P ? cc : H2_TW + cc);
             okc[k] = dstc[k] >= 0 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
             offc[k] = okc[k] ? 2u * cp * hw4 + 4u * (unsigned)(gy * d.W + gx) : 0u;
+        }
+        parity ^= 1;                                    // visible after the tile's first barrier; the previous tile's epilogue reads the other row
+        if (tid < 32 * NT) {
+            const int co = r.cb * 32 * NT + tid;
+            lbias[parity * 64 + tid] = (d.epilogue & RISP_EPI_NOBIAS) || co >= d.cout ? 0.f : d.bias[(size_t)g * d.bias_gs + co];
         }
     };
 
@@ -241,49 +248,43 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
     // A = weights: lane (m = lane & 31, hl) holds cout m of a block, channels 8 hl .. 8 hl + 7.
     const int bbase = (hl * IH + 2 * wave + (l31 >> 4)) * RS + (l31 & 15);
     const int abase = hl * NT * 32 + l31;
-    // Weight stages (one filter row of one chunk each) go through a ring of three LDS buffers, the LDS-DMA two stages ahead: the
-    // wait in front of a stage's closing barrier is for the pieces issued a whole stage earlier, and it is a COUNTED wait that
-    // leaves the younger pieces and the tile prefetch in flight (loads, stores and LDS-DMA return in issue order: vmcnt(0)
-    // there made every chunk wait for the HBM latency of the next chunk's tile).
+    // Weight stages (one filter row of one chunk each) go through a ring of LDS buffers, the LDS-DMA AHEAD stages in front of the
+    // matrix instructions.  The wait in front of a stage's closing barrier is a COUNTED wait for the pieces of the NEXT stage that
+    // leaves what is younger in flight (loads, stores and LDS-DMA return in issue order).
+    // A piece = 64 consecutive LDS slots of the stage image [kx][part][channel half][32 NT couts]; in the pack a row holds all
+    // 32 NT ncb couts of the layer: the lane offsets below pick this tile's cout block.
     constexpr int PW = C::PW, LOADS = 8 + 2 * P + 2 * NC2;           // vector-memory instructions of issue_weights / fetch
-    int ring = 0;                                                    // ring slot of the stage being multiplied
-    auto issue_weights = [&](int stage, int slot) {                  // LDS-DMA of stage (chunk, ky) = stage / KS, stage % KS
-        uint4 *dst = wl + slot * WST;
-        const uint4 *src = wpack + (size_t)stage * WST;
+    const int row_slots = ncb * NT * 32;                             // pack slots per (kx, part, channel half) row
+    unsigned wvoff[PW];
+    int wpiece[PW];
 #pragma unroll
-        for (int p = 0; p < PW; ++p) {
-            // every wave issues PW instructions, so that the counted vmcnt waits are the same arithmetic for all of them: a wave
-            // without a piece of its own repeats an earlier one (same bytes to the same place).  A transfer with EXEC = 0 is not
-            // a substitute - it does not count in vmcnt, and the waves issuing it then waited for one transfer too few.
-            const int piece = (wave + 4 * p) % (WST / 64);
-            lds_dma16_s(src + piece * 64, lane * 16, dst + piece * 64);
-        }
+    for (int p = 0; p < PW; ++p) {
+        // every wave issues PW instructions, so that the counted vmcnt waits are the same arithmetic for all of them: a wave
+        // without a piece of its own repeats an earlier one (same bytes to the same place).  A transfer with EXEC = 0 is not
+        // a substitute - it does not count in vmcnt, and the waves issuing it then waited for one transfer too few.
+        wpiece[p] = (wave + 4 * p) % (WST / 64);
+        const int L = wpiece[p] * 64 + lane, row = L / (NT * 32), col = L - row * (NT * 32);
+        wvoff[p] = 16u * (unsigned)(row * row_slots + col);
+    }
+    int ring = 0;                                                    // ring slot of the stage being multiplied
+    auto issue_weights = [&](int stage, int slot, const TileRef &r) {       // LDS-DMA of stage (chunk, ky) = stage / KS, stage % KS
+        uint4 *dst = wl + slot * WST;
+        const uint4 *src = r.w + 1 + (size_t)stage * (KS * 4) * row_slots + r.cb * NT * 32;          // slot 0 of the pack = header
+#pragma unroll
+        for (int p = 0; p < PW; ++p) lds_dma16_s(src, wvoff[p], dst + wpiece[p] * 64);
     };
-    auto ring_next = [&](int r, int k) { return r + k >= C::RING ? r + k - C::RING : r + k; };
-#define H2_WAIT_VM(keep) __builtin_amdgcn_s_waitcnt(0x0F70 | ((keep) & 15) | (((keep) >> 4) << 14))      /* s_waitcnt vmcnt(keep) */
+    auto ring_next = [&](int r, int k) { return r + k >= RING ? r + k - RING : r + k; };
 
 #ifdef RISP_H2_STAMPS
     unsigned long long t_start = __builtin_amdgcn_s_memtime(), t_stage = 0, t_mat = 0, t_wait = 0, t_epi = 0, t_steps = 0, t0, t1;
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
-#define H2STAMP(v) do { __builtin_amdgcn_s_waitcnt(0xC07F); v = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define H2STAMP(v) do { } while (0)
 #endif
     int t_cur = wg;
     if (t_cur >= ntiles) return;
-#if RISP_H2_STAGGER
-    // The two workgroups of a CU (ids b and b + gridDim.x / 2 - checked with HW_ID, tools/ab_f16x2.py) would run in lockstep: both
-    // in their matrix phases (sharing the pipe), then both staging / storing (the pipe idle).  The second one starts late by
-    // about a matrix phase, so that one multiplies while the other moves data.
-    if (2 * (int)blockIdx.x >= nwg && nwg > h2_half_grid_min) {
-        const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(RISP_H2_STAGGER * nstages * 4 * KS * 3 * NT * 32 / 100);
-        while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
-    if (tid < 64) lbias[tid] = (d.epilogue & RISP_EPI_NOBIAS) || tid >= d.cout ? 0.f : d.bias[tid];      // visible after the first barrier
-    setup(t_cur);
-    issue_weights(0, 0);
-    if (nstages > 1) issue_weights(1, 1);
+    locate(t_cur, cur);
+    setup(cur);
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) issue_weights(s, s, cur);
     fetch(0);
     for (;;) {
         f32x16 acc[4][NT];
@@ -296,6 +297,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
         int se = 0;                                    // running exponent: the accumulators hold sum * 2^se * s_w
         const int t_next = t_cur + nwg;
         const bool more = t_next < ntiles;
+        TileRef nxt = cur;
+        if (more) locate(t_next, nxt);
         for (int ch = 0; ch < nchunks; ++ch) {
             H2STAMP(t0);
             // largest magnitude of the chunk's tile -> red[wave]
@@ -308,20 +311,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
 #pragma unroll
             for (int k = 0; k < NC2; ++k)
                 if (okc[k]) m = fmaxf(m, fmaxf(fabsf(vc[k][0]), fabsf(vc[k][1])));
-#if RISP_H2_DBG & 1
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-#else
             m = h2_wave_max(m);
-#endif
             if (lane == 0) red[wave] = m;
 #ifdef RISP_H2_STAMPS
             H2STAMP(t1); t_wait += t1 - t0; t0 = t1;   // waiting for the prefetched tile (vmcnt) + the reduction
 #endif
             __syncthreads();                           // A: the maxima are visible; every wave has left the previous chunk's tile
-#if RISP_H2_ABL == 1
-            if (ch == 0 && t_cur == wg) {
-#endif
             const float4 mx = *reinterpret_cast<const float4 *>(red);
             const float tmax = fmaxf(fmaxf(mx.x, mx.y), fmaxf(mx.z, mx.w));
             // exponent that puts tmax into [2^14, 2^15): biased exponent eb of tmax -> 2^(141 - eb)
@@ -354,11 +349,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
 #pragma unroll
             for (int k = 0; k < NC2; ++k)
                 if (dstc[k] >= 0) put_pair(okc[k] ? vc[k][0] : 0.f, okc[k] ? vc[k][1] : 0.f, s, dstc[k]);
-#if RISP_H2_ABL == 1
-            }
-#endif
-            // the weight pieces of stage (ch, 0) were issued a stage ago; at ch == 0 of a later tile the previous tile's stores
-            // are younger than them and stay in flight
             // (the weight pieces of this chunk's first stage were waited for in front of the previous stage's last barrier, or - first
             // tile - are older than the tile just consumed)
             __syncthreads();                           // B: tile and weights complete
@@ -370,84 +360,114 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int stage = ch * KS + ky;
-                const bool dma = stage + 2 < nstages || more;
-                auto feed = [&]() {                     // two stages ahead, into the slot of the stage before this one (every wave has left it)
-#if RISP_H2_ABL != 1
-                    if (stage + 2 < nstages) issue_weights(stage + 2, ring_next(ring, 2));
-                    else if (more) issue_weights(stage + 2 - nstages, ring_next(ring, 2));
-                    if (ky == 0 && ch + 1 < nchunks) fetch(ch + 1);   // behind the pieces: in flight during the whole matrix phase
-#endif
+                const bool dma = stage + AHEAD < nstages || more;
+                const bool fetched = ky == 0 && ch + 1 < nchunks;
+                auto feed = [&]() {                     // AHEAD stages ahead, into the slot every wave has left; then the tile prefetch
+                    if (stage + AHEAD < nstages) issue_weights(stage + AHEAD, ring_next(ring, AHEAD), cur);
+                    else if (more) issue_weights(stage + AHEAD - nstages, ring_next(ring, AHEAD), nxt);
+                    if (fetched) fetch(ch + 1);         // behind the pieces: in flight during the whole matrix phase
                 };
-#if RISP_H2_ABL == 3
-                feed();
-#else
                 const uint4 *ws = wl + ring * WST + abase;
                 const uint4 *ts = tile + bbase + ky * RS;
-                h8 a[2][NT][2], bv[2][2];
-                auto load_a = [&](int kx, int buf) {
-#pragma unroll
-                    for (int b = 0; b < NT; ++b)
-#pragma unroll
-                        for (int part = 0; part < 2; ++part)
-                            a[buf][b][part] = __builtin_bit_cast(h8, ws[((kx * 2 + part) * 2) * NT * 32 + b * 32]);
-                };
-                auto load_b = [&](int u, int buf) {
-#if RISP_H2_ABL == 4
-                    u = 0;
-#endif
-                    const int sl = (u & 3) * S + (u >> 2);
-                    bv[buf][0] = __builtin_bit_cast(h8, ts[sl]);
-                    bv[buf][1] = __builtin_bit_cast(h8, ts[C::PART + sl]);
-                };
-#if RISP_H2_DBG & 2
-                feed();
-#endif
-                load_a(0, 0);
-                load_b(0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#if !(RISP_H2_DBG & 2)
-                feed();                                 // behind the first operand reads: issued while those are in flight
-#endif
-                __builtin_amdgcn_sched_barrier(0);
 #ifdef RISP_H2_STAMPS
                 unsigned long long ts0, ts1;
-                H2STAMP(ts0);
 #endif
+                if constexpr (KS == 3) {
+                    // 12 steps (kx, t): the B operand of step + 1 (and the A operands of the next tap) are read while the six
+                    // products of this step run
+                    h8 a[2][NT][2], bv[2][2];
+                    auto load_a = [&](int kx, int buf) {
 #pragma unroll
-                for (int step = 0; step < 4 * KS; ++step) {
-                    const int kx = step >> 2, t = step & 3;
-                    if (step + 1 < 4 * KS) {
-                        load_b(((step + 1) & 3) + ((step + 1) >> 2), (step + 1) & 1);
-                        if (((step + 1) & 3) == 0) load_a((step + 1) >> 2, ((step + 1) >> 2) & 1);
+                        for (int b = 0; b < NT; ++b)
+#pragma unroll
+                            for (int part = 0; part < 2; ++part)
+                                a[buf][b][part] = __builtin_bit_cast(h8, ws[((kx * 2 + part) * 2) * NT * 32 + b * 32]);
+                    };
+                    auto load_b = [&](int u, int buf) {
+                        const int sl = (u & 3) * S + (u >> 2);
+                        bv[buf][0] = __builtin_bit_cast(h8, ts[sl]);
+                        bv[buf][1] = __builtin_bit_cast(h8, ts[C::PART + sl]);
+                    };
+                    load_a(0, 0);
+                    load_b(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    feed();                             // behind the first operand reads: issued while those are in flight
+                    __builtin_amdgcn_sched_barrier(0);
+                    H2STAMP(ts0);
+#pragma unroll
+                    for (int step = 0; step < 4 * KS; ++step) {
+                        const int kx = step >> 2, t = step & 3;
+                        if (step + 1 < 4 * KS) {
+                            load_b(((step + 1) & 3) + ((step + 1) >> 2), (step + 1) & 1);
+                            if (((step + 1) & 3) == 0) load_a((step + 1) >> 2, ((step + 1) >> 2) & 1);
+                        }
+                        // keep the reads of step + 1 in front of the products of this step (hipcc sinks them to their first use and
+                        // waits lgkmcnt(0) in front of every group otherwise) and apart from later reads of the same slots
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int ab = kx & 1, bb = step & 1;
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][0], bv[bb][1], acc[t][b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][1], bv[bb][0], acc[t][b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][0], bv[bb][0], acc[t][b], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    // keep the reads of step + 1 in front of the products of this step (hipcc sinks them to their first use and
-                    // waits lgkmcnt(0) in front of every group otherwise) and apart from later reads of the same slots
-                    asm volatile("" ::: "memory");
+                } else {
+                    // 5 taps: pixel tile t at tap kx reads the slots of column shift u = t + kx - 8 distinct B operands serve the
+                    // 20 (t, kx) pairs of the row (one cout block per wave: read pair by pair the LDS would be the limit).  The A
+                    // operands of all taps stay in registers; B runs two shifts ahead.
+                    static_assert(KS == 3 || NT == 1, "the 5x5 form holds one cout block per wave");
+                    h8 a[KS][2], bv[3][2];
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) a[kx][part] = __builtin_bit_cast(h8, ws[((kx * 2 + part) * 2) * NT * 32]);
+                    auto load_b = [&](int u, int buf) {
+                        const int sl = (u & 3) * S + (u >> 2);
+                        bv[buf][0] = __builtin_bit_cast(h8, ts[sl]);
+                        bv[buf][1] = __builtin_bit_cast(h8, ts[C::PART + sl]);
+                    };
+                    load_b(0, 0);
+                    load_b(1, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int ab = kx & 1, bb = step & 1;
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][0], bv[bb][1], acc[t][b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][1], bv[bb][0], acc[t][b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ab][b][0], bv[bb][0], acc[t][b], 0, 0, 0);
+                    feed();
                     __builtin_amdgcn_sched_barrier(0);
+                    H2STAMP(ts0);
+#pragma unroll
+                    for (int u = 0; u < KS + 3; ++u) {
+                        if (u + 2 < KS + 3) load_b(u + 2, (u + 2) % 3);
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int kx = u - t;
+                            if (kx >= 0 && kx < KS) {
+                                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][0], bv[u % 3][1], acc[t][0], 0, 0, 0);
+                                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][1], bv[u % 3][0], acc[t][0], 0, 0, 0);
+                                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][0], bv[u % 3][0], acc[t][0], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
 #ifdef RISP_H2_STAMPS
                 ts1 = __builtin_amdgcn_s_memtime();
                 t_steps += ts1 - ts0;
 #endif
-#endif
                 ring = ring_next(ring, 1);
-                // the NEXT stage's pieces - issued one stage ago - must have landed; younger: this stage's pieces and, until the
-                // chunk's last stage, the tile prefetch issued behind the pieces of stage 0.  (ABL builds: plain vmcnt(0).)
-#if RISP_H2_ABL == 1
-                H2_WAIT_VM(0);
-#else
-                if (!dma) H2_WAIT_VM(0);
-                else if (ky + 1 < KS && ch + 1 < nchunks) H2_WAIT_VM(PW + LOADS);
-                else H2_WAIT_VM(PW);
-#endif
+                // the NEXT stage's pieces must have landed: issued AHEAD - 1 stages ago (in front of this stage's feed when AHEAD is 1).
+                // Younger than them: the pieces of the feeds since, and the tile prefetch of this chunk's stage 0 where it came later.
+                if (!dma) {
+                    H2_WAIT_VM(0);
+                } else if (AHEAD == 2) {
+                    if (ky + 1 < KS && ch + 1 < nchunks) H2_WAIT_VM(PW + LOADS);
+                    else H2_WAIT_VM(PW);
+                } else {
+                    if (fetched) H2_WAIT_VM(LOADS);
+                    else H2_WAIT_VM(0);
+                }
                 if (ky + 1 < KS) __syncthreads();
             }
 #ifdef RISP_H2_STAMPS
@@ -455,103 +475,83 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
             H2STAMP(t1); t_mat += t1 - t0;
 #endif
         }
-        // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias).  Lane (n, hl): couts 32 b + 8 (e >> 2) + 4 hl + (e & 3), the
-        // four pixels 4 (n & 15) .. + 3 of row 2 wave + (n >> 4) sit in the four pixel tiles: one 16-byte store per cout, 16 lanes
-        // = 256 contiguous bytes of a cout row.  The NEXT tile's first chunk is fetched first.
+        // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias).  Lane (n, hl): couts 32 b + 8 (e >> 2) + 4 hl + (e & 3) of the
+        // tile's cout block(s), the four pixels 4 (n & 15) .. + 3 of row 2 wave + (n >> 4) sit in the four pixel tiles: one 16-byte
+        // store per cout, 16 lanes = 256 contiguous bytes of a cout row.
 #ifdef RISP_H2_STAMPS
         const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
-        const int en = n, oy = y0 + 2 * wave + (l31 >> 4), ox = x0 + 4 * (l31 & 15);
-#if RISP_H2_DBG & 4                                     // epilogue mapping check: every accumulator element = its own code
+        {
+            const int oy = cur.y0 + 2 * wave + (l31 >> 4), ox = cur.x0 + 4 * (l31 & 15);
+            const int g = d.group_n > 0 ? cur.n / d.group_n : 0;
+            const int na = (d.group_flags & RISP_GROUP_SHARED_ADD) ? cur.n - g * d.group_n : cur.n;
+            const float inv_sw = *reinterpret_cast<const float *>(cur.w);
+            const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+            const int epi = d.epilogue;
+            constexpr bool has_add = HAS_ADD, has_mask = HAS_MASK;
+            const float floor_ = (epi & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
+            const bool pixok = oy < d.H && ox < d.W;
+            // addresses = wave-uniform base (image: scalar registers) + one 32-bit lane offset (pixel, + 4 couts for the upper
+            // half-wave) + the cout plane
+            unsigned hw4e = hw4;                        // opaque copy: the plane offsets below are tile-invariant, and hipcc would keep
+            asm volatile("" : "+s"(hw4e));              // them all in scalar registers across the persistent loop (spilling them)
+            const unsigned loff = (pixok ? 4u * (unsigned)(oy * d.W + ox) : 0u) + (unsigned)(cur.cb * 32 * NT + 4 * hl) * hw4;
+            const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)cur.n * d.cout * hw);
+            const __amdgpu_buffer_rsrc_t ra = h2_rsrc(has_add ? d.add + (size_t)na * d.add_c * hw : d.x);
+            const __amdgpu_buffer_rsrc_t rm = h2_rsrc(has_mask ? d.mask + (size_t)cur.n * d.cout * hw : d.x);
+            const float *bias_row = lbias + parity * 64 + 4 * hl;
+            // gfx9 counts loads and stores in one in-order counter: a load issued after a store returns only when that store has
+            // completed.  So the residual / mask rows are loaded in few, large batches (64 registers: 16 couts, 8 with both
+            // tensors), each batch in front of its own stores - one store round trip per batch instead of one per cout pair.
+            // (Forming all results first and storing at the end would need none, but hipcc cannot reuse the accumulator registers
+            // element by element and spills the results.)
+            constexpr int EB = (HAS_ADD && HAS_MASK) ? 8 : 16, NB = 16 * NT / EB;
+            float4 av[HAS_ADD ? EB : 1], mv[HAS_MASK ? EB : 1];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int g2 = 0; g2 < NB; ++g2) {
+                // batch = couts [g2 * EB, g2 * EB + EB) in units of (b, j, i): cout = 32 b + 8 j + 4 hl + i
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[t][b][e] = (float)(((t * 2 + b) * 16 + e) * 64 + lane);
-        se = 0;
-#endif
-#if RISP_H2_EARLY
-        if (more) {
-            setup(t_next);
-#if RISP_H2_ABL != 1
-            fetch(0);
-#endif
-        }
-#endif
-#if RISP_H2_ABL == 2
-        if (acc[0][0][0] == 123.456f) {
-#endif
-        const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
-        const int epi = d.epilogue;
-        constexpr bool has_add = HAS_ADD, has_mask = HAS_MASK;
-        const float floor_ = (epi & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
-        const bool pixok = oy < d.H && ox < d.W;
-        // addresses = wave-uniform base (image, cout group: scalar registers) + one 32-bit lane offset (pixel, + 4 couts for the
-        // upper half-wave); cout % 8 == 0, so a group of 8 couts is valid or not as a whole (wave-uniform)
-        unsigned hw4e = hw4;                            // opaque copy: the 3 x 64 plane offsets below are tile-invariant, and hipcc
-        asm volatile("" : "+s"(hw4e));                  // would keep them all in scalar registers across the persistent loop (spilling them)
-        const unsigned loff = pixok ? 4u * (unsigned)(oy * d.W + ox) + 4u * hl * hw4 : 0u;
-        const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)en * d.cout * hw);
-        const __amdgpu_buffer_rsrc_t ra = h2_rsrc(has_add ? d.add + (size_t)en * d.add_c * hw : d.x);
-        const __amdgpu_buffer_rsrc_t rm = h2_rsrc(has_mask ? d.mask + (size_t)en * d.cout * hw : d.x);
-        // gfx9 counts loads and stores in one in-order counter: a load issued after a store returns only when that store has
-        // completed.  So the residual / mask rows are loaded in few, large batches (64 registers: 16 couts, 8 with both tensors),
-        // each batch in front of its own stores - one store round trip per batch instead of one per cout pair.  (Forming all
-        // results first and storing at the end would need none, but hipcc cannot reuse the accumulator registers element by
-        // element and spills the results.)
-        constexpr int EB = (HAS_ADD && HAS_MASK) ? 8 : 16, NB = 16 * NT / EB;
-        float4 av[HAS_ADD ? EB : 1], mv[HAS_MASK ? EB : 1];
-#pragma unroll
-        for (int g = 0; g < NB; ++g) {
-            // batch g = couts [g * EB, g * EB + EB) in units of (b, j, i): cout = 32 b + 8 j + 4 hl + i
-#pragma unroll
-            for (int k = 0; k < EB; ++k) {
-                const int c = g * EB + k, cu = (c >> 4) * 32 + 8 * ((c >> 2) & 3) + (c & 3);
-                if (has_add) av[k] = h2_load16(ra, loff, (unsigned)cu * hw4e);
-                if (has_mask) mv[k] = h2_load16(rm, loff, (unsigned)cu * hw4e);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < EB; ++k) {
-                const int c = g * EB + k, b = c >> 4, j = (c >> 2) & 3, i = c & 3, e = 4 * j + i, cu = b * 32 + 8 * j + i;
-                const float bb = lbias[cu + 4 * hl];
-                float4 o = make_float4(acc[0][b][e] * fin + bb, acc[1][b][e] * fin + bb, acc[2][b][e] * fin + bb, acc[3][b][e] * fin + bb);
-                if (has_add) {
-                    const float4 a4 = av[k];
-                    o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+                for (int k = 0; k < EB; ++k) {
+                    const int c = g2 * EB + k, cu = (c >> 4) * 32 + 8 * ((c >> 2) & 3) + (c & 3);
+                    if (has_add) av[k] = h2_load16(ra, loff, (unsigned)cu * hw4e);
+                    if (has_mask) mv[k] = h2_load16(rm, loff, (unsigned)cu * hw4e);
                 }
-                o.x = o.x < floor_ ? floor_ : o.x;            // ReLU, or nothing (floor = -inf); a NaN stays a NaN (torch.relu)
-                o.y = o.y < floor_ ? floor_ : o.y;
-                o.z = o.z < floor_ ? floor_ : o.z;
-                o.w = o.w < floor_ ? floor_ : o.w;
-                if (has_mask) {
-                    const float4 mk = mv[k];
-                    o.x = mk.x > 0.f ? o.x : 0.f;
-                    o.y = mk.y > 0.f ? o.y : 0.f;
-                    o.z = mk.z > 0.f ? o.z : 0.f;
-                    o.w = mk.w > 0.f ? o.w : 0.f;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < EB; ++k) {
+                    const int c = g2 * EB + k, b = c >> 4, j = (c >> 2) & 3, i = c & 3, e = 4 * j + i, cu = b * 32 + 8 * j + i;
+                    const float bb = bias_row[cu];
+                    float4 o = make_float4(acc[0][b][e] * fin + bb, acc[1][b][e] * fin + bb, acc[2][b][e] * fin + bb, acc[3][b][e] * fin + bb);
+                    if (has_add) {
+                        const float4 a4 = av[k];
+                        o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+                    }
+                    o.x = o.x < floor_ ? floor_ : o.x;            // ReLU, or nothing (floor = -inf); a NaN stays a NaN (torch.relu)
+                    o.y = o.y < floor_ ? floor_ : o.y;
+                    o.z = o.z < floor_ ? floor_ : o.z;
+                    o.w = o.w < floor_ ? floor_ : o.w;
+                    if (has_mask) {
+                        const float4 mk = mv[k];
+                        o.x = mk.x > 0.f ? o.x : 0.f;
+                        o.y = mk.y > 0.f ? o.y : 0.f;
+                        o.z = mk.z > 0.f ? o.z : 0.f;
+                        o.w = mk.w > 0.f ? o.w : 0.f;
+                    }
+                    // (plane offset in the VECTOR offset, scalar offset 0: a 16-byte buffer store reads its data registers late, and
+                    // hipcc pads the following overwrite of them with wait states only for this form - with the plane in the scalar
+                    // offset the last four lanes of every 16 stored the NEXT cout's values on gfx950)
+                    if (pixok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, loff + (unsigned)cu * hw4e, 0, 0);
                 }
-                // (plane offset in the VECTOR offset, scalar offset 0: a 16-byte buffer store reads its data registers late, and
-                // hipcc pads the following overwrite of them with wait states only for this form - with the plane in the scalar
-                // offset the last four lanes of every 16 stored the NEXT cout's values on gfx950)
-                if (pixok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, loff + (unsigned)cu * hw4e, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-#if RISP_H2_ABL == 2
-        }
-#endif
 #ifdef RISP_H2_STAMPS
         t_epi += __builtin_amdgcn_s_memtime() - t_loop_end;
 #endif
         if (!more) break;
-#if !RISP_H2_EARLY
-        setup(t_next);
-#if RISP_H2_ABL != 1
+        cur = nxt;
+        setup(cur);
         fetch(0);
-#endif
-#endif
         t_cur = t_next;
     }
 #ifdef RISP_H2_STAMPS
@@ -578,6 +578,10 @@ inline int h2_cu_count() {
     return cus;
 }
 
+#ifndef RISP_H2_WGS
+#define RISP_H2_WGS 2        // persistent workgroups per CU (1: diagnostic builds, tools/ab_f16x2.py)
+#endif
+
 template <int KS, int NT, bool HAS_ADD, bool HAS_MASK>
 int launch_f16x2(const risp_conv_desc &d, void *stream) {
     using C = H2<KS, NT>;
@@ -587,18 +591,15 @@ int launch_f16x2(const risp_conv_desc &d, void *stream) {
         risp_set_error("risp_conv2d_f16x2: cannot raise the dynamic LDS limit to %d bytes", C::LDS_BYTES);
         return 2;
     }
-    const int tx = (d.W + H2_TW - 1) / H2_TW, ty = (d.H + H2_TH - 1) / H2_TH;
-    const long long ntiles = (long long)tx * ty * d.N;
+    const int tx = (d.W + H2_TW - 1) / H2_TW, ty = (d.H + H2_TH - 1) / H2_TH, ncb = d.cout / (32 * NT);
+    const long long ntiles = (long long)tx * ty * d.N * ncb;
     if (ntiles > 0x7fffffff) {
         risp_set_error("risp_conv2d_f16x2: too many tiles");
         return 1;
     }
-#ifndef RISP_H2_WGS
-#define RISP_H2_WGS 2
-#endif
-    const int slots = RISP_H2_PERSIST ? RISP_H2_WGS * h2_cu_count() : 0x7fffffff;
+    const int slots = RISP_H2_WGS * h2_cu_count();
     const int grid = ntiles < slots ? (int)ntiles : slots;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, (hipStream_t)stream, d, tx, ty, (int)ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, (hipStream_t)stream, d, tx, ty, ncb, (int)ntiles);
     RISP_LAUNCH_CHECK("risp_conv2d_f16x2");
     return 0;
 }
@@ -632,11 +633,11 @@ int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_f16x2: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_f16x2: null tensor");
-    RISP_CHECK_ARG(d.group_n == 0, "risp_conv2d_f16x2: grouped launches are not supported");
-    RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cin % H2_CK == 0 && d.cout > 0 &&
-                       (d.cout == 32 || d.cout == 64) && d.ksize == 3 && (unsigned long long)(d.cout > d.cin ? d.cout : d.cin) * d.H * d.W < (1ull << 30) &&
+    RISP_CHECK_GROUP(d, "risp_conv2d_f16x2");
+    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cin % H2_CK == 0 && (d.cout == 32 || d.cout == 64) &&
+                       (d.ksize == 3 || d.ksize == 5) && (unsigned long long)(d.cout > d.cin ? d.cout : d.cin) * d.H * d.W < (1ull << 30) &&
                        (!(d.epilogue & RISP_EPI_ADD) || d.add_c == d.cout),
-                   "risp_conv2d_f16x2: needs a 3x3 layer, cin %% 16 == 0, cout 32 or 64 (= add_c), W %% 4 == 0, fewer than 2^30 "
+                   "risp_conv2d_f16x2: needs a 3x3 or 5x5 layer, cin %% 16 == 0, cout 32 or 64 (= add_c), W %% 4 == 0, fewer than 2^30 "
                    "elements per image (N=%d H=%d W=%d cin=%d cout=%d k=%d)",
                    d.N, d.H, d.W, d.cin, d.cout, d.ksize);
     RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_f16x2: only plain loads");
@@ -648,6 +649,7 @@ int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
                      reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_f16x2: tensors must be 16-byte aligned");
+    if (d.ksize == 5) return launch_f16x2_epi<5, 1>(d, stream);         // one cout block per tile: 64 couts = two tiles per pixel tile
     return d.cout == 64 ? launch_f16x2_epi<3, 2>(d, stream) : launch_f16x2_epi<3, 1>(d, stream);
 }
 

@@ -84,7 +84,9 @@ class ErrorBudget:
     def __init__(self, factor=2.0, atol=4e-6, bar=1e-4, outliers=1):
         self.factor, self.atol, self.bar, self.outliers, self.rows = factor, atol, bar, outliers, []
 
-    def __call__(self, got, ref32, ref64, what='', family=None):
+    def __call__(self, got, ref32, ref64, what='', family=None, event=None):
+        """``event``: members that one cause perturbs together count as ONE outlier (a ReLU mask flipped in one operator of a
+        DARTS iteration moves the architecture gradient of every slot upstream of it)."""
         import torch
         tonp = lambda v: np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, np.float64)
         got, ref32, ref64 = tonp(got), tonp(ref32), tonp(ref64)
@@ -92,20 +94,20 @@ class ErrorBudget:
         if not got.size:
             return
         scale = np.abs(ref64).max() or 1.0
-        self.rows.append((what, np.abs(got - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale, family or what))
+        self.rows.append((what, np.abs(got - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale, family or what, event or what))
 
     def finish(self):
         fam, over = {}, {}
-        for _, _, e_ref, family in self.rows:
+        for _, _, e_ref, family, _ in self.rows:
             fam[family] = max(fam.get(family, 0.0), e_ref)
         bad = []
-        for what, e_got, e_ref, family in self.rows:
+        for what, e_got, e_ref, family, event in self.rows:
             # capped at the bar - unless the reference's own fp32 result is beyond it on this very tensor (then 1.25 x that)
             bound = max(min(self.factor * fam[family], self.bar), 1.25 * e_ref if e_ref > self.bar else 0.0) + self.atol
             ok = e_got <= bound
             own = e_got <= self.factor * e_ref + self.atol
             if not own:
-                over.setdefault(family, []).append(what)
+                over.setdefault(family, {}).setdefault(event, []).append(what)
             if os.environ.get('RISP_BUDGET_REPORT') == '1':
                 print('BUDGET %-40s hip %.2e  ref32 %.2e  ratio %6.2f  family %-12s %.2e %s%s' % (
                     what, e_got, e_ref, e_got / max(e_ref, 1e-30), family, fam[family], '' if ok else '  <-- OVER',
@@ -113,9 +115,9 @@ class ErrorBudget:
             if not ok:
                 bad.append('%s: |hip - fp64| = %.3e of the tensor\'s magnitude; reference fp32: %.3e (family %s: %.3e)' % (
                     what, e_got, e_ref, family, fam[family]))
-        for family, members in over.items():
-            if len(members) > self.outliers:
-                bad.append('family %s: %d members cost more than %.1f x their own reference error (at most %d may): %s' % (
-                    family, len(members), self.factor, self.outliers, ', '.join(members)))
+        for family, events in over.items():
+            if len(events) > self.outliers:
+                bad.append('family %s: %d events cost more than %.1f x their own reference error (at most %d may): %s' % (
+                    family, len(events), self.factor, self.outliers, '; '.join(', '.join(m) for m in events.values())))
         assert not bad, 'over the fp32 error budget (min(%.1f x reference, %.0e) + %.1e):\n  ' % (
             self.factor, self.bar, self.atol) + '\n  '.join(bad)

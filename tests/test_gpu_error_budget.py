@@ -55,7 +55,7 @@ def test_darts_iterations_within_budget():
                             'it%d val loss' % it, 'losses')
         for k, a in enumerate(model.netG.alphas):
             key = 'it%d_alpha_grad%d' % (it, k)
-            budget(a.grad, g[key], f[key], key, 'alpha grads')
+            budget(a.grad, g[key], f[key], key, 'alpha grads', event='iteration %d' % it)
         model.optimize_parameters()
         for k, v in model.netG.state_dict().items():
             key = 'it%d_%s' % (it, k)

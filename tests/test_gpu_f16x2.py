@@ -188,3 +188,72 @@ def test_dispatch_switch_through_conv(arith, monkeypatch):
     assert calls == (['risp_conv2d_f16x2'] * 2 if arith == 'f16x2' else ['risp_conv2d_wino43'] * 2)
     assert err(y, torch.relu(TF.conv2d(x.double(), wt.double(), b.double(), padding=1)))[1] < 5e-6
     assert err(g, TF.conv_transpose2d(x.double(), wt.double(), padding=1) * (mask > 0))[1] < 5e-6
+
+
+def launch_k(entry, x, pack, bias, n, h, w, cin, cout, k, epi=0, add=None, mask=None, group=None):
+    from reconfigisp_amd import lib as L
+    nn = n * (group[0] if group else 1)
+    y = torch.full((nn, cout, h, w), float('nan'), device='cuda')
+    d = L.ConvDesc(N=nn, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=0, cin_img=0, epilogue=epi | (0 if bias is not None else 16),
+                   add_c=cout if add is not None else 0, x=x.data_ptr(), wpack=pack.data_ptr(),
+                   bias=bias.data_ptr() if bias is not None else None, cvals=None, add=add.data_ptr() if add is not None else None,
+                   mask=mask.data_ptr() if mask is not None else None, y=y.data_ptr())
+    if group:
+        d.group_n, d.group_flags = n, group[1]
+        d.wpack_gs = pack.stride(0) * pack.element_size() // 4
+        d.bias_gs = bias.stride(0) if bias is not None else 0
+    L.call(entry, C.byref(d), None)
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 32), (32, 64), (64, 64), (16, 32)])
+@pytest.mark.parametrize('nhw', [(1, 8, 64), (3, 13, 68), (2, 40, 100), (1, 7, 4), (2, 33, 128)])
+def test_5x5_forward_and_backward_pack_against_float64(cin, cout, nhw):
+    """the 5x5 form (SRCNNRes' 64 -> 32 layer and its 32 -> 64 backward, srcnn_res_arch.py:20): one cout block per tile, a
+    64-cout layer as two tiles per pixel tile"""
+    from reconfigisp_amd import convnets as CN
+    n, h, w = nhw
+    wt, b = rnd(cout, cin, 5, 5, seed=71) * 0.02, rnd(cout, seed=72) * 0.1
+    x, mask = rnd(n, cin, h, w, seed=73), rnd(n, cout, h, w, seed=74)
+    ref = TF.conv2d(x.double(), wt.double(), b.double(), padding=2)
+    y = launch_k('risp_conv2d_f16x2', x, CN.f16x2_weights(wt, False), b, n, h, w, cin, cout, 5, CN.EPI_RELU)
+    assert err(y, torch.relu(ref))[1] < 3e-6
+    wb = rnd(cin, cout, 5, 5, seed=75) * 0.02            # a forward layer cout_f = cin here: its backward-data maps cin -> cout
+    refb = TF.conv_transpose2d(x.double(), wb.double(), padding=2) * (mask > 0)
+    yb = launch_k('risp_conv2d_f16x2', x, CN.f16x2_weights(wb, True), None, n, h, w, cin, cout, 5, CN.EPI_MASK, None, mask)
+    rms, mx = err(yb, refb)
+    assert mx < 3e-6 and rms < 2e-7, (rms, mx)
+
+
+def test_5x5_accuracy_next_to_the_fp32_winograd_kernel():
+    from reconfigisp_amd import convnets as CN
+    n, h, w, cin, cout = 2, 64, 128, 64, 32
+    wt, b = rnd(cout, cin, 5, 5, seed=81) * 0.02, rnd(cout, seed=82) * 0.1
+    x = torch.rand(n, cin, h, w, device='cuda', generator=torch.Generator('cuda').manual_seed(83))
+    ref = TF.conv2d(x.double(), wt.double(), b.double(), padding=2)
+    y = launch_k('risp_conv2d_f16x2', x, CN.f16x2_weights(wt, False), b, n, h, w, cin, cout, 5)
+    y32 = launch_k('risp_conv2d_wino45', x, CN.wino45_weights(wt, False), b, n, h, w, cin, cout, 5)
+    (rms, mx), (rms32, mx32) = err(y, ref), err(y32, ref)
+    assert rms <= rms32 and mx <= 1.5 * mx32, (rms, rms32, mx, mx32)
+
+
+@pytest.mark.parametrize('k,cin,cout', [(5, 64, 32), (5, 32, 64), (3, 64, 64)])
+def test_grouped_launch_equals_member_launches(k, cin, cout):
+    """risp_conv_desc.group_n: G members' images stacked along N, weights / bias by member - the bits of the member launches"""
+    from reconfigisp_amd import convnets as CN, lib as L
+    G, n, h, w = 3, 2, 21, 68
+    wts = [rnd(cout, cin, k, k, seed=90 + g) * (0.02 * (g + 1)) for g in range(G)]
+    bs = torch.stack([rnd(cout, seed=95 + g) * 0.1 for g in range(G)])
+    packs = torch.stack([CN.f16x2_weights(wt, False) for wt in wts])
+    x, mask = rnd(G * n, cin, h, w, seed=99), rnd(G * n, cout, h, w, seed=100)
+    yg = launch_k('risp_conv2d_f16x2', x, packs, bs, n, h, w, cin, cout, k, CN.EPI_MASK, None, mask, group=(G, 0))
+    for g in range(G):
+        s = slice(g * n, (g + 1) * n)
+        ym = launch_k('risp_conv2d_f16x2', x[s].contiguous(), packs[g], bs[g], n, h, w, cin, cout, k, CN.EPI_MASK, None, mask[s].contiguous())
+        assert torch.equal(yg[s], ym), g
+    # one input shared by all members (the slot input as x of a first layer)
+    ys = launch_k('risp_conv2d_f16x2', x[:n].contiguous(), packs, bs, n, h, w, cin, cout, k, 0, None, None, group=(G, L.GROUP_SHARED_X))
+    for g in range(G):
+        ym = launch_k('risp_conv2d_f16x2', x[:n].contiguous(), packs[g], bs[g], n, h, w, cin, cout, k)
+        assert torch.equal(ys[g * n:(g + 1) * n], ym), g

@@ -59,6 +59,10 @@ if K == 3 and hasattr(prod, 'risp_conv2d_wino43'):
     p43 = CN.wino43_weights(wt, False, prod.risp_conv_wino43_chunk())
     d43 = desc(p43)
     runs['product F(4,3) fp32'] = (lambda: prod.risp_conv2d_wino43(C.byref(d43), None))
+if K == 5:
+    p45 = CN.wino45_weights(wt, False)
+    d45 = desc(p45)
+    runs['product F(4,5) fp32'] = (lambda: prod.risp_conv2d_wino45(C.byref(d45), None))
 pd = torch.empty(prod.risp_conv_wpack_floats(cin, cout, K), device='cuda')
 prod.risp_conv_pack_weights(C.c_void_p(wt.data_ptr()), cin, cout, K, 0, C.c_void_p(pd.data_ptr()), None)
 dd = desc(pd)
@@ -95,7 +99,7 @@ for name, l in libs.items():                       # diagnostic builds (-DRISP_H
     if '-DRISP_H2_STAMPS' not in name:
         continue
     l.risp_conv_f16x2_occupancy.restype = C.c_int
-    nwg = min(((w + 63) // 64) * ((h + 7) // 8) * n, (1 if 'RISP_H2_WGS=1' in name else 2) * torch.cuda.get_device_properties(0).multi_processor_count)
+    nwg = min(((w + 63) // 64) * ((h + 7) // 8) * n * (cout // 32 if K == 5 else 1), (1 if 'RISP_H2_WGS=1' in name else 2) * torch.cuda.get_device_properties(0).multi_processor_count)
     buf = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device='cuda')
     ds = desc(ph)
     ds.cvals = buf.data_ptr()
