@@ -82,7 +82,8 @@ def timed(fn, steps, warmup, device, world):
     ev_b.record()
     ev_b.synchronize()
     est_ms = max(ev_a.elapsed_time(ev_b) / 3, 1e-3)
-    for _ in range(min(4000, int(50.0 / est_ms) + 1)):
+    timed.spin_up_launches = 3 + min(4000, int(50.0 / est_ms) + 1)
+    for _ in range(timed.spin_up_launches - 3):
         fn()
     for _ in range(warmup):
         fn()
@@ -279,8 +280,14 @@ def launch_ranks(n, argv):
         env.setdefault('RISP_BENCH_BACKEND', 'gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    out, _ = child.communicate()
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = child.communicate(timeout=float(env.get('RISP_BENCH_TIMEOUT', '1500')))
+    except subprocess.TimeoutExpired:           # a rank stuck in a collective: end the whole child tree, keep what was printed
+        import signal
+        os.killpg(child.pid, signal.SIGKILL)
+        out, _ = child.communicate()
+        sys.stderr.write('bench.py: the ranks did not finish within the time limit (RISP_BENCH_TIMEOUT); killed\n')
     lines = [ln for ln in out.splitlines() if ln.startswith('{') and '"metric"' in ln]
     for ln in out.splitlines():
         if ln not in lines:
@@ -461,6 +468,7 @@ def main():
         else:
             wall, dev_ms = timed(rotating(net), args.steps, args.warmup, device, world)
         host_us = timed.host_us / (queue if graph else 1)
+        spin_up = timed.spin_up_launches * (queue if graph else 1)
         b2b_ms = kernel_time_ms(net, batches[:queue], max(args.steps, 100), device, True)
         b2b_ms_cached = kernel_time_ms(net, batches[:1], max(args.steps, 100), device, True)
     value = world * pix_per_step * args.steps / wall / 1e6
@@ -486,6 +494,7 @@ def main():
              'hbm_frac_back_to_back_c_abi': round(hbm(BYTES_PER_PIX_ISP, b2b_ms) / HBM_PEAK_GBS, 4),
              'kernel_ms_one_batch_cache_assisted': round(b2b_ms_cached, 5),
              'hbm_frac_one_batch_cache_assisted': round(hbm(BYTES_PER_PIX_ISP, b2b_ms_cached) / HBM_PEAK_GBS, 4),
+             'spin_up_launches': spin_up,       # untimed, before the W warm-up steps: ~50 ms of the same launches (see timed())
              'launch': ('hipGraph replay, %d resident batches (steps) per replay' % queue) if graph else
                        ('one Python forward() per step on the stream, rotating over %d resident batches' % queue),
              'pointwise_arch': ARCH_HBM,
@@ -535,16 +544,40 @@ def main():
             extra.update(cnn_f32_MPix_s=round(world * pix_per_step * steps_c / wall_f / 1e6, 1), cnn_f32_ms_per_step=round(dev_ms_f, 3),
                          cnn_f32_mfma_issued_frac=round(tf(issued_f, dev_ms_f) / MFMA_F32_PEAK_TFLOPS, 4))
     if not args.no_search:
-        # a secondary leg must never cost the headline line, at any N: on a failure it reports the error instead.  (Every
-        # rank runs the same code on the same shapes, so a failure - out of memory, a bad shape - is raised on all of
-        # them and all of them skip to the end together.)
+        # a secondary leg must never cost the headline line: at N = 1 a failure is reported instead of raised.  At N > 1 a
+        # failure can be rank-local (out of memory on one GPU, an RCCL error) while the peers sit in a collective: the ranks
+        # cannot agree on anything any more, so the exception goes up and the launcher ends the job (launch_ranks also
+        # carries a time limit that kills the child tree).
         try:
             leg = search_step_leg(device, rank, world, global_batch=args.search_batch, size=args.size)
         except Exception as e:                                  # noqa: BLE001
+            if world > 1:
+                raise
             leg = {'error': '%s: %s' % (type(e).__name__, e)}
         if rank == 0:
             extra['search_step'] = leg
 
+    proof = None
+    if world > 1:
+        # Proof of ranks: what each rank ran on, gathered over the process group itself - and, measured in the SAME run, what one
+        # rank alone delivers while the others wait in a barrier (the N = 1 figure beside the N-rank one; the scaling efficiency
+        # is the reader's to compute).
+        props = torch.cuda.get_device_properties(device)
+        me = {'rank': rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device_index': local,
+              'device_name': props.name, 'pci_bus_id': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0),
+                                                                         getattr(props, 'pci_device_id', 0)),
+              'uuid': str(getattr(props, 'uuid', '')), 'value_MPix_s': round(pix_per_step * args.steps / wall / 1e6, 1)}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        solo = None
+        if rank == 0:
+            with torch.no_grad():
+                wall_1, _ = timed(rotating(net), args.steps, args.warmup, device, 1)
+            solo = round(pix_per_step * args.steps / wall_1 / 1e6, 1)
+        dist.barrier()
+        proof = {'ranks': ranks, 'backend': dist.get_backend(), 'world_as_seen_by_pg': dist.get_world_size(),
+                 'distinct_devices': len({r['pci_bus_id'] + r['uuid'] for r in ranks}),
+                 'one_rank_alone_same_run_MPix_s': solo}
     if rank == 0:
         line = {
             'metric': 'MPix/s end-to-end 5-stage ISP forward, 256x256 Bayer', 'value': round(value, 1),
@@ -561,6 +594,8 @@ def main():
                                    '%d B/pix algorithmic' % BYTES_PER_PIX_ISP},
             'extra': extra,
         }
+        if proof is not None:
+            line['proof_of_ranks'] = proof
         if one_device and world > 1:
             line['dry_run_all_ranks_on_one_device'] = True
         if not args.no_cpu and world == 1:

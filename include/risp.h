@@ -155,9 +155,11 @@ int risp_mix_bwd(const float *const *outs, const float *w, int K, const float *g
  * operand of each kind) evaluated in registers from the slot input x: x is read once and the operators' outputs never
  * touch HBM.  pmul[k] multiplies a WB_MANUAL block on the way in (the wrapper's params * 5, tools_origin.py:214) and its
  * gradient on the way out.  y is bit-identical to running the operators one by one and risp_mix_fwd.
- * Backward: gw (K) = <gy, o_k>; go[k] (tensor operands, may be NULL) = w[k] gy; gx = sum over the element-wise operands
- * (operand order) of their input gradients at upstream w[k] gy (NULL allowed only when there is none); gp[k] = (N,P)
- * parameter-gradient block of operand k (GTM_MANUAL: whole batch in row 0), fully written, may be NULL.  Deterministic. */
+ * Backward: gw (K) = <gy, o_k>; go[k] (tensor operands, may be NULL) = w[k] gy; gx = sum over the element-wise operands of
+ * their input gradients at upstream w[k] gy, added in KIND order (skip, manual white balance, gamma, tone curve, quadratic
+ * white balance, gain - whatever the operand order; NULL allowed only when there is none); gp[k] = (N,P) parameter-gradient
+ * block of operand k (GTM_MANUAL: whole batch in row 0), fully written, may be NULL.  Deterministic.  Identical bits to the
+ * unfused slot: y, gp (and go); gw and gx differ from it by summation order (~1e-7). */
 #define RISP_SLOT_TENSOR (-1)
 #define RISP_SLOT_ROW (RISP_MAX_MIX + 40)
 typedef struct risp_slot_mix_desc {

@@ -151,26 +151,36 @@ class DartsModel(BaseModel):
         return loss, out, None, None
 
     def _allreduce_mean(self, tensors):
-        """Average a list of small gradient tensors over the ranks with ONE flat all-reduce (RCCL)."""
+        """Average a list of small gradient tensors over the ranks with ONE flat all-reduce (RCCL): a persistent flat buffer per
+        gradient set, one list-wide copy in, the collective (averaging on RCCL: no division launch), one list-wide copy out -
+        three launches whatever the number of tensors (was torch.cat of ~45 tensors + ~45 copy_ launches, four times per
+        iteration)."""
         if not self.distributed:
             return tensors                          # (a world of one still goes through the collective: same code path)
         live = [t for t in tensors if t is not None and t.numel()]
         if not live:
             return tensors
-        flat = torch.cat([t.reshape(-1) for t in live])
+        sizes = tuple(t.numel() for t in live)
+        key = (sizes, live[0].device, live[0].dtype)
+        cache = self.__dict__.setdefault('_flat_grads', {})
+        if key not in cache:                        # the views are kept with the buffer: nothing is re-sliced per call
+            flat = torch.empty(sum(sizes), device=live[0].device, dtype=live[0].dtype)
+            cache[key] = (flat, [v.view_as(t) for v, t in zip(flat.split(sizes), live)])
+        flat, views = cache[key]
+        torch._foreach_copy_(views, live)
         probe = self.comm_seconds is not None       # bench.py: seconds inside the collectives (synchronising)
         if probe:
             torch.cuda.synchronize(flat.device) if flat.is_cuda else None
             t0 = time.perf_counter()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == 'nccl':
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:                                       # gloo (CPU tests, dry runs) has no averaging reduction
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= self.world
         if probe:
             torch.cuda.synchronize(flat.device) if flat.is_cuda else None
             self.comm_seconds += time.perf_counter() - t0
-        flat /= self.world
-        at = 0
-        for t in live:
-            t.copy_(flat[at: at + t.numel()].view_as(t))
-            at += t.numel()
+        torch._foreach_copy_(live, views)
         return tensors
 
     # ------------------------------------------------------------------ weight step
@@ -190,7 +200,7 @@ class DartsModel(BaseModel):
             params = [p for p in self.netG_attr.trainable_parameters if p.numel()]
             only = getattr(self.netG_attr, 'params_only_backward', None)
             if only:
-                only(True)
+                only(True, params)
             try:
                 grads = torch.autograd.grad(l_pix, params, allow_unused=True)
             finally:
@@ -212,7 +222,7 @@ class DartsModel(BaseModel):
         params = self.netG_attr.trainable_parameters
         only = getattr(self.netG_attr, 'params_only_backward', None) if self.step_reuse else None
         if only:
-            only(True)            # nobody consumes the input gradient of the first parametrised slot in this pass
+            only(True, params)    # nobody consumes the input gradient of the first parametrised slot in this pass
         try:
             grads = list(torch.autograd.grad(loss, params, allow_unused=True))
         finally:

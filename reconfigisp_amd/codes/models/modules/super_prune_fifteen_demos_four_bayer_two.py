@@ -131,14 +131,24 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             for m in mods:
                 m.__dict__.pop('_risp_reuse', None)
 
-    def params_only_backward(self, on):
+    def params_only_backward(self, on, params=None):
         """While on: the next backward pass is asked for the PARAMETER gradients only (DartsModel.virtual_step,
         darts_model.py:204 `autograd.grad(loss, trainable_parameters)`).  The slots below the first parametrised one hold no
         parameters, so the input gradient of that slot's operators feeds nothing: the grouped SRCNNRes backward skips its
-        9x9 64->3 backward-data convolution and the member sum (autograd already skips the nodes that lead only to alphas)."""
+        9x9 64->3 backward-data convolution and the member sum (autograd already skips the nodes that lead only to alphas).
+        ``params``: the tensors the pass will ask for - the switch stays OFF unless every one of them is an operator parameter of
+        the first parametrised slot or a later one, and nothing below that slot requires a gradient (proxy weights being
+        fine-tuned in the graph, say): an undefined input gradient would otherwise reach a consumer silently."""
         first = next((s for s, pars in enumerate(self.all_params) if any(p.numel() for p in pars)), None)
-        if first is not None:
-            self.__dict__.setdefault('_group_cache', {}).setdefault(first, {})['skip_gx'] = bool(on)
+        if first is None:
+            return False
+        if on:
+            later = {id(p) for pars in self.all_params[first:] for p in pars}
+            below = [p for mods in self.all_modules[:first] for m in mods for p in m.parameters() if p.requires_grad]
+            if below or (params is not None and any(id(p) not in later for p in params)):
+                on = False
+        self.__dict__.setdefault('_group_cache', {}).setdefault(first, {})['skip_gx'] = bool(on)
+        return bool(on)
 
     def _record(self, slot, k, token, mod):
         """the reuse record of op k of `slot` for this input token (None outside a scope / for ops with parameters)"""
@@ -289,6 +299,11 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             outs = self._run_jobs(jobs, len(index), x, args)
             sel = self._select(post, index, len(weights))
             stacks = [pos for pos, _ in jobs if len(pos) > 1]
+            if fused and not F.can_fuse_slot(x, list(fused.values()), [outs[i] for i in range(len(index)) if i not in fused]):
+                # an operand view that is not 16-byte aligned: the element-wise operators as their own launches, plain mixture
+                for i, nm in fused.items():
+                    outs[i] = mods[index[i]](x, args[i])
+                fused = {}
             if fused:
                 entries = [('op', fused[i], args[i]) if i in fused else ('tensor', outs[i]) for i in range(len(index))]
                 y = F.slot_mix(sel, x, entries, w_host=[weights[k] for k in index], stacks=stacks)

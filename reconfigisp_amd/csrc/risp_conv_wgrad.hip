@@ -95,6 +95,7 @@ size_t risp_conv_wgrad_scratch_floats(int ksize) { return (size_t)ksize * ksize 
 int risp_conv2d_wgrad(const risp_conv_desc *dp, const float *gy, float *dw, float *scratch, void *stream) {
     RISP_CHECK_ARG(dp && gy && dw && scratch, "risp_conv2d_wgrad: null argument");
     const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(d.group_n == 0, "risp_conv2d_wgrad: grouped descriptors are not supported (one weight gradient per launch)");
     RISP_CHECK_ARG(d.x && d.N > 0 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cin <= 64 && d.cout > 0 && d.cout <= 64 &&
                        (d.ksize == 1 || d.ksize == 3 || d.ksize == 5 || d.ksize == 9),
                    "risp_conv2d_wgrad: unsupported layer cin=%d cout=%d k=%d", d.cin, d.cout, d.ksize);

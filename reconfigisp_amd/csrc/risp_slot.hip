@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void slot_mix_fwd_kernel(const risp_slot_mix_d
 }
 
 // Backward of the same: per operand the architecture term <gy, o_k>; tensors receive go_k = w_k gy; the element-wise
-// operators' input gradients ctx.bwd(x, w_k gy) are added in operand order into ONE gx; their parameter gradients are
+// operators' input gradients ctx.bwd(x, w_k gy) are added in KIND order (below) into ONE gx; their parameter gradients are
 // reduced registers -> lanes -> waves -> one row of RISP_SLOT_ROW floats per workgroup, which slot_mix_finish_kernel adds
 // in index order (bit-repeatable; the block partition is that of the stand-alone backward kernels, so the parameter
 // gradients are the bits they produce).  Row layout: [K architecture terms | wb 3 | gamma 1 | gtm 3 | wbq 30 | gain 3].

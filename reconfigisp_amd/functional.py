@@ -309,16 +309,21 @@ class _SlotMix(torch.autograd.Function):
                     go[i] = buf[j]
         gp = [None] * k
         pointwise = False
+        # only what the graph consumes is allocated and written (risp_slot_mix_bwd takes NULL for go[k] / gp[k]): 12 B/pixel per
+        # tensor operand whose producer needs no gradient.  forward inputs: (w, w_host, x, kinds, stacks, *flat)
+        need_flat, need_x = iter(ctx.needs_input_grad[5:]), ctx.needs_input_grad[2]
         for i, kind in enumerate(kinds):
             d.kind[i], d.w[i], d.pmul[i] = kind, ctx.w_host[i], 5.0 if kind == OP_WB_MANUAL else 1.0
             d.ptr[i] = keep[i].data_ptr() if keep[i] is not None else None
             if kind == L.SLOT_TENSOR:
-                if go[i] is None:
+                need = next(need_flat)
+                if go[i] is None and need:
                     go[i] = torch.empty_like(x)
-                d.go[i] = go[i].data_ptr()
+                d.go[i] = go[i].data_ptr() if go[i] is not None else None
             else:
                 pointwise = True
-                if kind != OP_SKIP:
+                need = next(need_flat) if kind not in (OP_SKIP, OP_GAIN3) else need_x       # gray world: its gains lead back to x
+                if kind != OP_SKIP and need:
                     gp[i] = torch.empty_like(keep[i])
                     d.gp[i] = gp[i].data_ptr()
         gx = torch.empty_like(x) if pointwise else None
@@ -326,7 +331,7 @@ class _SlotMix(torch.autograd.Function):
         scratch = torch.empty(L.load().risp_slot_mix_scratch_floats(n, hw), **dev)
         L.call('risp_slot_mix_bwd', C.byref(d), _p(gy), _p(gx), _p(gw), _p(scratch), _stream())
         for i, kind in enumerate(kinds):
-            if kind == OP_GAIN3:                     # gray world: the gains' gradient flows back through the channel means
+            if kind == OP_GAIN3 and gp[i] is not None:        # gray world: the gains' gradient flows back through the channel means
                 gm = torch.empty((n, 3), **dev)
                 L.call('risp_grayworld_gains_bwd', _p(stats), _p(gp[i]), _p(gm), n, hw, _stream())
                 L.call('risp_stats_bwd', _p(gx), None, _p(gm), None, None, n * 3, hw, _stream())
@@ -546,10 +551,12 @@ class _HipImpl:
         return _SlotMix.apply(w, w_host, x, tuple(kinds), stacks, *flat)
 
     @staticmethod
-    def can_fuse_slot(x, names):
-        """element-wise operands can be evaluated inside the mixture kernel: BGR input, 16-byte planes, one of each kind"""
+    def can_fuse_slot(x, names, tensors=()):
+        """element-wise operands can be evaluated inside the mixture kernel: BGR input, 16-byte planes (the slot input and every
+        materialised operand in ``tensors``), one of each kind"""
         return (x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and (x.shape[2] * x.shape[3]) % 4 == 0 and
-                x.data_ptr() % 16 == 0 and len(set(names)) == len(names) and all(nm in SLOT_KINDS for nm in names))
+                x.data_ptr() % 16 == 0 and len(set(names)) == len(names) and all(nm in SLOT_KINDS for nm in names) and
+                all(t.data_ptr() % 16 == 0 and t.is_contiguous() for t in tensors))
 
     @staticmethod
     def prune_softmax(alpha, threshold, unavailable=None):
@@ -693,8 +700,8 @@ def slot_mix(w, x, entries, w_host=None, stacks=None):
     return _IMPL.slot_mix(w, x, entries, w_host, stacks)
 
 
-def can_fuse_slot(x, names):
-    return _IMPL.can_fuse_slot(x, names)
+def can_fuse_slot(x, names, tensors=()):
+    return _IMPL.can_fuse_slot(x, names, tensors)
 
 
 def prune_softmax(alpha, threshold, unavailable=None):

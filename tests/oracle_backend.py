@@ -26,7 +26,7 @@ class OracleImpl:
     srcnn_res_group = staticmethod(lambda x, pvs, ms, cache: [OracleImpl.srcnn_res(x, pv, m) for pv, m in zip(pvs, ms)])
     srcnn_demosaic_group = staticmethod(lambda x, ms, cache, record=None: [OracleImpl.srcnn_demosaic(x, m) for m in ms])
 
-    can_fuse_slot = staticmethod(lambda x, names: x.dim() == 4 and x.shape[1] == 3 and len(set(names)) == len(names))
+    can_fuse_slot = staticmethod(lambda x, names, tensors=(): x.dim() == 4 and x.shape[1] == 3 and len(set(names)) == len(names))
 
     @staticmethod
     def slot_mix(w, x, entries, w_host=None, stacks=None):

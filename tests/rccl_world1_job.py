@@ -24,8 +24,29 @@ def darts_job(distributed):
     torch.manual_seed(0)
     model = create_model(opt)
     seed_darts(model)
+    ops_per_call = []
     if distributed:
         model.comm_seconds = 0.0                   # bracket the collectives: proves they ran
+        # the framework operations one _allreduce_mean issues (one list-wide copy in, the collective, one list-wide copy out)
+        from torch.utils._python_dispatch import TorchDispatchMode
+
+        class Count(TorchDispatchMode):
+            def __init__(self):
+                super().__init__()
+                self.names = []
+
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                self.names.append(str(func))
+                return func(*args, **(kwargs or {}))
+
+        inner = model._allreduce_mean
+
+        def counted(tensors):
+            with Count() as c:
+                r = inner(tensors)
+            ops_per_call.append(c.names)
+            return r
+        model._allreduce_mean = counted
     data = tuple(torch.from_numpy(np.asarray(g[k])) for k in ('img', 'gt', 'val_img', 'val_gt'))
     model.feed_data(data)
     model.update_learning_rate(0, warmup_iter=-1)
@@ -35,6 +56,8 @@ def darts_job(distributed):
     model.optimize_parameters()
     out.update({k: v.detach().cpu() for k, v in model.netG.state_dict().items()})
     out['comm_seconds'] = torch.tensor(model.comm_seconds or 0.0)
+    if distributed:
+        out['allreduce_ops'] = ops_per_call
     return out
 
 

@@ -33,6 +33,9 @@ def test_one_rank_process_group_on_rccl_changes_no_bit(tmp_path):
     plain, ranked = res['plain'], res['ranked']
     assert ranked['darts'].pop('comm_seconds').item() > 0          # the four all-reduces of the iteration really ran
     plain['darts'].pop('comm_seconds')
+    calls = ranked['darts'].pop('allreduce_ops')                    # four gradient sets per iteration, each: copy in, collective, copy out
+    assert len(calls) == 4 and all(len(ops) <= 3 for ops in calls), calls
+    assert all(sum('allreduce' in o for o in ops) == 1 and sum('_foreach_copy_' in o for o in ops) == 2 for ops in calls), calls
     assert set(plain['darts']) == set(ranked['darts'])
     for k in plain['darts']:
         assert torch.equal(plain['darts'][k], ranked['darts'][k]), k

@@ -10,3 +10,6 @@ for r in $(seq $ROUNDS); do
     echo -n "[$v]  "; (cd /tmp && python3 "$REPO/tools/bench_darts.py" $BATCH 256 $NSTEP $ITERS 2>&1 | tail -1 | cut -c1-80)
   done
 done
+# leave the box's library in its default configuration (the last variant would otherwise stay installed for whatever runs next)
+touch "$REPO"/reconfigisp_amd/csrc/*.hip
+make -s -C "$REPO/reconfigisp_amd/csrc" -j8 > /tmp/ab_build.log 2>&1 || { tail -5 /tmp/ab_build.log; exit 1; }
