@@ -35,23 +35,29 @@ if xscale != 1:
     x = torch.randn(n, cin, h, w, device='cuda') * xscale * (torch.rand(n, cin, h, w, device='cuda') > 0.5)
 res_in = torch.rand(n, cout, h, w, device='cuda') * xscale
 y = torch.empty(n, cout, h, w, device='cuda')
-full_epi = os.environ.get('RISP_AB_EPI') == '1'
+EPI_MODE = int(os.environ.get('RISP_AB_EPI', '0'))          # 1 residual + ReLU, 2 mask, 3 residual + mask
+full_epi = EPI_MODE in (1, 3)
+use_mask = EPI_MODE in (2, 3)
+mask_t = torch.randn(n, cout, h, w, device='cuda')
 relu = os.environ.get('RISP_AB_RELU', '1') == '1'
 def ref64(sl):
     r = torch.nn.functional.conv2d(x[sl].double(), wt.double(), b.double(), padding=K // 2)
     if full_epi:
         r = r + res_in[sl].double()
+    if use_mask:
+        return r * (mask_t[sl] > 0)
     return torch.relu(r) if relu else r
 refs = {0: ref64(slice(0, 1)), n - 1: ref64(slice(n - 1, n))}
 scale = max(r.abs().max().item() for r in refs.values())
 def err(yy):
     e = torch.cat([(yy[i:i + 1].double() - r).flatten() for i, r in refs.items()])
     return e.pow(2).mean().sqrt().item() / scale, e.abs().max().item() / scale
-epi = (CN.EPI_RELU if relu else 0) | (CN.EPI_ADD if full_epi else 0)
+relu = relu and not use_mask
+epi = (CN.EPI_RELU if relu else 0) | (CN.EPI_ADD if full_epi else 0) | (CN.EPI_MASK if use_mask else 0)
 def desc(pack):
     return L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=K, load_mode=0, cin_img=0, epilogue=epi, add_c=cout if full_epi else 0,
                       x=x.data_ptr(), wpack=pack.data_ptr(), bias=b.data_ptr(), cvals=None,
-                      add=res_in.data_ptr() if full_epi else None, mask=None, y=y.data_ptr())
+                      add=res_in.data_ptr() if full_epi else None, mask=mask_t.data_ptr() if use_mask else None, y=y.data_ptr())
 # the product library's fp32 kernels on the same data
 prod = L.load()
 runs = {}
@@ -75,6 +81,7 @@ for name, l in libs.items():
     runs['f16x2 ' + name] = (lambda l=l: l.risp_conv2d_f16x2(C.byref(dh), None))
 yt = torch.nn.functional.conv2d(x[:1], wt, b, padding=K // 2)
 if full_epi: yt = yt + res_in[:1]
+if use_mask: yt = yt * (mask_t[:1] > 0)
 print('torch fp32 conv (image 0)               rms %.2e max %.2e of max|y|' % (
     ((torch.relu(yt) if relu else yt).double() - refs[0]).pow(2).mean().sqrt().item() / scale,
     ((torch.relu(yt) if relu else yt).double() - refs[0]).abs().max().item() / scale))
@@ -124,7 +131,7 @@ for name, l in libs.items():                       # diagnostic builds (-DRISP_H
     start = buf.view(nwg * 4, 8)[:, 5]
     print('   start spread (100 MHz ticks): %d; distinct (se, cu) ids seen %d' % ((start.max() - start.min()).item(), len(set(cu.tolist()))))
 flop = 2.0 * cin * cout * K * K * n * h * w
-byts = 4.0 * n * h * w * (cin + cout * (2 if full_epi else 1))
+byts = 4.0 * n * h * w * (cin + cout * (1 + full_epi + use_mask))
 for k, v in res.items():
     m = sorted(v)[len(v) // 2]
     print('%-40s median %.1f us  min %.1f   (%.1f direct-convolution TFLOP/s, %.2f TB/s of tensors)' % (k, m, min(v), flop / m / 1e6, byts / m / 1e6))

@@ -17,11 +17,11 @@ for sub in ('a', 'b'):
     for f in glob.glob(os.path.join(root, sub, '**', '*counter_collection.csv'), recursive=True):
         acc, cnt = defaultdict(float), defaultdict(int)
         for r in csv.DictReader(open(f)):
-            if "conv_mfma" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ("conv_mfma", "conv_wino", "conv_f16x2")):
                 acc[r['Counter_Name']] += float(r['Counter_Value']); cnt[r['Counter_Name']] += 1
         for k in acc: print('%-28s avg/launch %16.0f' % (k, acc[k] / cnt[k]))
 for f in glob.glob(os.path.join(root, 't', '**', '*kernel_stats.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv_mfma" in r["Name"] or "conv_wino" in r["Name"]: print('kernel avg us %.1f calls %s' % (float(r['AverageNs']) / 1e3, r['Calls']))
+        if any(k in r["Name"] for k in ("conv_mfma", "conv_wino", "conv_f16x2")): print('kernel avg us %.1f calls %s' % (float(r['AverageNs']) / 1e3, r['Calls']))
 PY
 tail -1 "$OUT/t.log"
