@@ -399,6 +399,39 @@ int risp_param_blocks_fwd(const risp_param_blocks_desc *d, void *stream);
 int risp_param_blocks_bwd(const risp_param_blocks_desc *d, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * The glue of a DARTS iteration as own launches (risp_step.hip).
+ * ------------------------------------------------------------------------- */
+/* loss[0] = mean((y - gt)^2) (kind 0: nn.MSELoss, models/darts_model.py:58-63, isp_model.py:29-34) or mean(|y - gt|) (kind 1:
+ * nn.L1Loss) over numel values, numel % 4 == 0, 16-byte aligned; g != NULL: also the gradient of that mean with respect to y
+ * at upstream 1 (2 (y - gt) / numel, sign(y - gt) / numel) - the backward pass is then a scaling.  Two launches (partial sums
+ * per workgroup into scratch = risp_loss_scratch_floats() floats, added in index order): deterministic. */
+size_t risp_loss_scratch_floats(void);
+int risp_pixel_loss(const float *y, const float *gt, float *g, float *loss, float *scratch, size_t numel, int kind, void *stream);
+
+/* The reference's per-parameter Python loops over the <= 216 floats of a super-net as ONE launch over a table of tensors. */
+#define RISP_MAX_LIST 64
+typedef struct risp_list_desc {
+    int n;                                        /* tensors, <= RISP_MAX_LIST */
+    int numel[RISP_MAX_LIST];
+    float *a[RISP_MAX_LIST];                      /* written */
+    const float *b[RISP_MAX_LIST];
+    const float *c[RISP_MAX_LIST];
+    const float *e[RISP_MAX_LIST];
+} risp_list_desc;
+/* virtual step, darts_model.py:204-222: a = b - lr_meta * (momentum * e + c); e NULL: no momentum buffer yet; c NULL: a = b
+ * (no gradient arrived, or an alpha copied to the twin network).  Operation by operation the reference's arithmetic. */
+int risp_darts_virtual_step(const risp_list_desc *d, float momentum, float lr_meta, void *stream);
+/* out[0] = 2-norm of the concatenation of the c[t] (NULL entries skipped), out[1] = eps = out[0] < 1e-6 ? 0 : 0.01 / out[0]
+ * (:274-277); fixed summation order. */
+int risp_list_norm_eps(const risp_list_desc *d, float *out, void *stream);
+/* a[t] += (factor * scalar[0]) * c[t] (c NULL: untouched): the +eps, -2 eps, +eps shifts of the parameters (:299-312) with
+ * eps on the device. */
+int risp_list_axpy_scalar(const risp_list_desc *d, const float *scalar, float factor, void *stream);
+/* architecture gradient, :254-265 with :313-323: a = b - lr_meta * ((c - e) / 2 * eps[0]); zeros where b, c or e is NULL or
+ * the finite-difference term holds a NaN (nan_flags[t] = 1 there; may be NULL).  numel <= 256. */
+int risp_darts_alpha_grad(const risp_list_desc *d, const float *eps, float lr_meta, int *nan_flags, void *stream);
+
+/* ---------------------------------------------------------------------------
  * One training step of an element-wise fixed pipeline in two launches - replaces the body of
  * IspModel.optimize_parameters (models/isp_model.py:128-142: output = netG(img); l_pix = cri_pix(output, gt);
  * zero_grad(); l_pix.backward(); optimizer_G.step()) when netG is [nearest demosaic ->] a chain of WbManual / Gamma /

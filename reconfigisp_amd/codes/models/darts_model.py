@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from ... import functional as F
 from ..utils.util_loss import latency_loss, local_global_loss
 from . import networks
 from .base_model import BaseModel
@@ -30,10 +31,25 @@ from .isp_model import make_schedulers
 logger = logging.getLogger('base')
 
 
+class PixelLoss(nn.Module):
+    """nn.MSELoss ('l2') / nn.L1Loss ('l1') of the reference (:58-63) - loss and gradient in one pass on the device
+    (functional.pixel_loss); tensors the kernel does not take (numel % 4 != 0, unaligned views, other dtypes) go to torch."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self.kind = kind
+
+    def forward(self, out, gt):
+        if (out.dtype == torch.float32 and gt.dtype == torch.float32 and out.shape == gt.shape and out.numel() % 4 == 0
+                and out.is_contiguous() and gt.is_contiguous() and (out.data_ptr() | gt.data_ptr()) % 16 == 0):
+            return F.pixel_loss(out, gt, self.kind)
+        return nn.functional.mse_loss(out, gt) if self.kind == 'l2' else nn.functional.l1_loss(out, gt)
+
+
 def _criterion(kind, train_opt, device):
     if kind == 'l1':
-        return nn.L1Loss().to(device)
-    mse = nn.MSELoss().to(device)
+        return PixelLoss('l1').to(device)
+    mse = PixelLoss('l2').to(device)
     if kind == 'l2':
         return mse
     if kind == 'local_global_l2':
@@ -211,6 +227,10 @@ class DartsModel(BaseModel):
         self._allreduce_mean([p.grad for p in self.netG_attr.trainable_parameters])
         self.optimizer_G.step()
         self.log_dict['loss'] = l_pix.item()
+        flags, self._nan_flags = getattr(self, '_nan_flags', None), None
+        if flags is not None:                       # (the queue is drained by the read-out above anyway)
+            for idx in flags.nonzero().flatten().tolist():
+                print('Warning: NaN in hessian, for the {}-th alpha'.format(idx + 1))
         if self.is_latency:
             self.log_dict['latency'] = self.latency.item()
             self.log_dict['latency_term'] = self.latency_term.item()
@@ -230,33 +250,17 @@ class DartsModel(BaseModel):
                 only(False)
         if self.sync_arch_grads:
             self._allreduce_mean(grads)
-        # the reference's per-parameter loop (darts_model.py:208-218) as list-wide launches: same operations in the
-        # same order on every element, a handful of launches instead of five per parameter
+        # the reference's per-parameter loop (darts_model.py:208-218) as ONE launch over a table of the tensors (functional.
+        # darts_virtual_step -> risp_darts_virtual_step: the same operations in the same order on every element); the alphas are
+        # rows without a gradient (plain copies)
         with torch.no_grad():
-            plain, stepped = [], []
+            rows = []
             for p, vp, g in zip(params, self.netV.trainable_parameters, grads):
-                if len(p) == 0:
-                    continue
-                if g is None:
-                    plain.append((vp, p))
-                else:
-                    stepped.append((vp, p, g, self.optimizer_G.state[p].get('momentum_buffer')))
-            with_buf = [t for t in stepped if t[3] is not None]
-            no_buf = [t for t in stepped if t[3] is None]
-            if with_buf:
-                upd = list(torch._foreach_mul([t[3] for t in with_buf], self.momentum_G))
-                torch._foreach_add_(upd, [t[2] for t in with_buf])
-            else:
-                upd = []
-            upd += [0. * self.momentum_G + t[2] for t in no_buf]
-            order = with_buf + no_buf
-            if order:
-                torch._foreach_mul_(upd, self.lr_meta)
-                torch._foreach_copy_([t[0] for t in order], torch._foreach_sub([t[1] for t in order], upd))
-            dst = [vp for vp, _ in plain] + list(self.netV.alphas)
-            src = [p for _, p in plain] + list(self.netG_attr.alphas)
-            if dst:
-                torch._foreach_copy_(dst, src)
+                if len(p):
+                    rows.append((vp, p, g, self.optimizer_G.state[p].get('momentum_buffer') if g is not None else None))
+            rows += [(va, a, None, None) for va, a in zip(self.netV.alphas, self.netG_attr.alphas)]
+            if rows:
+                F.darts_virtual_step(rows, self.momentum_G, self.lr_meta)
 
     def optimize_alphas(self):
         # forwards #1 (virtual step), #3 and #4 (Hessian) evaluate netG on the same train batch with the same alphas: the
@@ -280,55 +284,49 @@ class DartsModel(BaseModel):
         if self.sync_arch_grads:
             self._allreduce_mean(grads)
         dalpha, dp = grads[:len(v_alphas)], grads[len(v_alphas):]
-        hessian = self.compute_hessian(dp)
+        pos, neg, eps = self.compute_hessian(dp)
         with torch.no_grad():
-            # the reference's per-alpha `torch.isnan(h).any()` (:260-263) is a device synchronisation each: one transfer
-            # for all of them (every synchronisation drains the launch queue)
-            live = [h for h in hessian if h is not None]
-            bad = torch.stack([torch.isnan(h).any() for h in live]).tolist() if live else []
-            nan_flag = iter(bad)
-            for idx, (alpha, da, h) in enumerate(zip(self.netG_attr.alphas, dalpha, hessian), start=1):
-                has_nan = next(nan_flag) if h is not None else False
-                if da is None or h is None:
-                    alpha.grad = torch.zeros_like(alpha)
-                elif has_nan:
-                    print('Warning: NaN in hessian, for the {}-th alpha'.format(idx))
-                    alpha.grad = torch.zeros_like(alpha)
-                else:
-                    alpha.grad = da - self.lr_meta * h
+            # alpha.grad = dalpha - lr_meta * (pos - neg) / 2 * eps, zeros where a term is missing or the finite difference holds a
+            # NaN (:254-265 with :313-323), for all alphas in ONE launch.  The reference's per-alpha `torch.isnan(h).any()` is a
+            # device synchronisation each; the flags stay on the device and are looked at where the iteration synchronises anyway
+            # (the loss read-out of optimize_parameters).
+            alphas = list(self.netG_attr.alphas)
+            for a in alphas:
+                if a.grad is None:
+                    a.grad = torch.empty_like(a)
+            self._nan_flags = F.darts_alpha_grad([(a.grad, da, p, n) for a, da, p, n in zip(alphas, dalpha, pos, neg)], eps, self.lr_meta)
         self.optimizer_alpha.step()
 
     def compute_hessian(self, dp):
-        """(dalpha L_trn(p + eps dp) - dalpha L_trn(p - eps dp)) / 2. * eps, eps = 0.01/||dp||."""
-        norm = torch.cat([w.view(-1) for w in dp if w is not None]).norm()
+        """The two shifted architecture gradients and eps of (dalpha L_trn(p + eps dp) - dalpha L_trn(p - eps dp)) / 2. * eps,
+        eps = 0.01/||dp|| (:270-324); the difference itself is formed with the architecture gradient (one launch)."""
         # eps = 0 if norm < 1e-6 else 0.01 / norm (:276-277) without reading norm back: the comparison on the host is a
         # device synchronisation in the middle of the iteration
-        eps = torch.where(norm < 1e-6, torch.zeros_like(norm), 0.01 / norm)
+        live_dp = [w for w in dp if w is not None]
+        if live_dp:
+            eps = F.list_norm_eps(live_dp)[1:2]
+        else:
+            eps = torch.zeros(1, device=self.device)
         params = self.netG_attr.trainable_params
-
         live = [(p, d) for p, d in zip(params, dp) if len(p) > 0 and d is not None]
 
-        def shift(scale):
-            with torch.no_grad():
-                if not live:
-                    return
-                if torch.is_tensor(scale):                  # eps is a 0-dim device tensor: scale * d, then p += (two launches)
-                    torch._foreach_add_([p for p, _ in live], torch._foreach_mul([d for _, d in live], scale))
-                else:
-                    torch._foreach_add_([p for p, _ in live], [scale * d for _, d in live])
+        def shift(factor):                                  # p += factor * eps * dp for every parameter: one launch
+            if live:
+                with torch.no_grad():
+                    F.list_axpy_scalar(live, eps, factor)
 
         def dalpha_at():
             loss = self._loss(self.netG, self.img, self.gt, self.glb_flag, self.cri_pix)[0]
-            return list(torch.autograd.grad(loss, self.netG_attr.alphas))
+            return list(torch.autograd.grad(loss, self.netG_attr.alphas, allow_unused=True))
 
-        shift(eps)
+        shift(1.)
         pos = dalpha_at()
-        shift(-2. * eps)
+        shift(-2.)
         neg = dalpha_at()
-        shift(eps)
+        shift(1.)
         if self.sync_arch_grads:
             self._allreduce_mean(pos + neg)
-        return [(p - n) / 2. * eps if p is not None and n is not None else None for p, n in zip(pos, neg)]
+        return pos, neg, eps
 
     def test(self):
         with torch.no_grad():

@@ -556,11 +556,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
     }
 #ifdef RISP_H2_STAMPS
     if (lane == 0 && d.cvals) {                        // diagnostic build: cycle shares of a wave's life (tools/ab_f16x2.py)
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(d.cvals)) + 8 * ((size_t)blockIdx.x * 4 + wave);
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(d.cvals)) + 10 * ((size_t)blockIdx.x * 4 + wave);
         __builtin_amdgcn_s_waitcnt(0x0070);
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         o[0] = t_wait; o[1] = t_stage; o[2] = t_mat; o[3] = t_epi; o[4] = t_end - t_start;
-        o[5] = rt_start; o[6] = __builtin_amdgcn_s_memrealtime() | (t_steps << 40);
+        o[5] = rt_start; o[6] = __builtin_amdgcn_s_memrealtime(); o[8] = t_steps; o[9] = 0;
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -618,8 +618,8 @@ extern "C" {
 int risp_conv_f16x2_occupancy(void) {                 // diagnostic builds only: resident workgroups per CU
     int nb = -1;
     using C = H2<3, 2>;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_f16x2_kernel<3, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_f16x2_kernel<3, 2, false, false>, 256, C::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_f16x2_kernel<3, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_f16x2_kernel<3, 2, false, false>, 256, C::LDS_BYTES);
     return nb;
 }
 #endif

@@ -1,0 +1,182 @@
+// The glue of a DARTS iteration as own launches (round 4): the pixel loss with its gradient, and the reference's per-parameter
+// Python loops - virtual step, finite-difference shifts, architecture gradient (models/darts_model.py:159-180, 204-222, 254-265,
+// 299-323) - as ONE launch each over a table of <= RISP_MAX_LIST tiny tensors.  Every sum is taken in a fixed order: results
+// repeat bit for bit.
+#include "risp_common.h"
+
+namespace {
+
+constexpr int LOSS_BLOCKS = 256;
+
+// pass 1: per-workgroup partial sums of (y - gt)^2 or |y - gt| over a grid-stride walk of 16-byte vectors, and - g != NULL -
+// the gradient of the MEAN loss at upstream 1: 2 (y - gt) / numel or sign(y - gt) / numel
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float4 *__restrict__ y, const float4 *__restrict__ gt, float4 *__restrict__ g,
+                                                           float *__restrict__ partial, size_t n4, float inv_n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float gs = (KIND == 0 ? 2.f : 1.f) * inv_n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 a = y[i], b = gt[i];
+        const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        if (KIND == 0) {
+            s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            if (g) g[i] = make_float4(d0 * gs, d1 * gs, d2 * gs, d3 * gs);
+        } else {
+            s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+            auto sg = [&](float d) { return d > 0.f ? gs : (d < 0.f ? -gs : 0.f); };
+            if (g) g[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// pass 2: one wave adds the partial sums in index order (lane l: l, l + 64, ...), a fixed shuffle tree adds the lanes
+__global__ __launch_bounds__(64) void loss_finish_kernel(const float *__restrict__ partial, int n, float inv_n, float *__restrict__ loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+
+// ---------------------------------------------------------------------------------- tables of tiny tensors
+// one wave per tensor (parameters of 1 .. 64 values, alphas of 2 .. 15)
+__global__ __launch_bounds__(64) void virtual_step_kernel(const risp_list_desc d, float momentum, float lr_meta) {
+    const int t = blockIdx.x;
+    float *vp = d.a[t];
+    const float *p = d.b[t], *g = d.c[t], *buf = d.e[t];
+    for (int i = threadIdx.x; i < d.numel[t]; i += 64) {
+        if (!g) {
+            vp[i] = p[i];                                   // no gradient arrived (or an alpha): plain copy
+        } else {
+            float upd = buf ? buf[i] * momentum : 0.f;      // darts_model.py:208-218, operation by operation
+            upd = upd + g[i];
+            upd = upd * lr_meta;
+            vp[i] = p[i] - upd;
+        }
+    }
+}
+
+// norm = || concatenation of c[t] ||_2 (one workgroup, index order), eps = norm < 1e-6 ? 0 : 0.01 / norm  (:276-277)
+__global__ __launch_bounds__(256) void norm_eps_kernel(const risp_list_desc d, float *__restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int t = 0; t < d.n; ++t) {
+        const float *c = d.c[t];
+        if (!c) continue;
+        for (int i = threadIdx.x; i < d.numel[t]; i += 256) s += c[i] * c[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        out[0] = norm;
+        out[1] = norm < 1e-6f ? 0.f : 0.01f / norm;
+    }
+}
+
+// a[t] += (factor * scalar[0]) * c[t]      (the +eps / -2 eps / +eps shifts of the parameters, :299-312)
+__global__ __launch_bounds__(64) void axpy_scalar_kernel(const risp_list_desc d, const float *__restrict__ scalar, float factor) {
+    const int t = blockIdx.x;
+    float *a = d.a[t];
+    const float *c = d.c[t];
+    if (!c) return;
+    const float s = factor * scalar[0];
+    for (int i = threadIdx.x; i < d.numel[t]; i += 64) a[i] = a[i] + c[i] * s;
+}
+
+// a[t] = b[t] - lr_meta * ((c[t] - e[t]) / 2 * eps), zeros where b / c / e is missing or the Hessian term holds a NaN
+// (:254-265, 313-323); flags[t] = 1 where a NaN was found
+__global__ __launch_bounds__(64) void alpha_grad_kernel(const risp_list_desc d, const float *__restrict__ eps, float lr_meta,
+                                                        int *__restrict__ flags) {
+    const int t = blockIdx.x;
+    float *out = d.a[t];
+    const float *da = d.b[t], *pos = d.c[t], *neg = d.e[t];
+    const int n = d.numel[t];
+    const float e = eps[0];
+    bool bad = false;
+    float h[4];                                             // numel <= 256: up to 4 values per lane
+    for (int k = 0, i = threadIdx.x; k < 4; ++k, i += 64) {
+        h[k] = 0.f;
+        if (i < n && da && pos && neg) {
+            h[k] = (pos[i] - neg[i]) / 2.f * e;
+            bad |= h[k] != h[k];
+        }
+    }
+    const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    for (int k = 0, i = threadIdx.x; k < 4; ++k, i += 64)
+        if (i < n) out[i] = (da && pos && neg && !any_bad) ? da[i] - lr_meta * h[k] : 0.f;
+    if (threadIdx.x == 0 && flags) flags[t] = any_bad ? 1 : 0;
+}
+
+int check_list(const risp_list_desc *d, const char *name, int max_numel) {
+    RISP_CHECK_ARG(d && d->n >= 0 && d->n <= RISP_MAX_LIST, "%s: 0..%d tensors", name, RISP_MAX_LIST);
+    for (int t = 0; t < d->n; ++t)
+        RISP_CHECK_ARG(d->numel[t] > 0 && d->numel[t] <= max_numel && d->a[t], "%s: tensor %d: numel %d (1..%d) or null output", name, t,
+                       d->numel[t], max_numel);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+size_t risp_loss_scratch_floats(void) { return LOSS_BLOCKS; }
+
+int risp_pixel_loss(const float *y, const float *gt, float *g, float *loss, float *scratch, size_t numel, int kind, void *stream) {
+    RISP_CHECK_ARG(y && gt && loss && scratch && numel > 0 && numel % 4 == 0 && (kind == 0 || kind == 1),
+                   "risp_pixel_loss: null tensor, numel %% 4 != 0 or kind not in {0 (mean squared), 1 (mean absolute)}");
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(g)) & 15) == 0,
+                   "risp_pixel_loss: tensors must be 16-byte aligned");
+    const size_t n4 = numel / 4;
+    const int blocks = (int)((n4 + 255) / 256 < (size_t)LOSS_BLOCKS ? (n4 + 255) / 256 : LOSS_BLOCKS);
+    const float inv_n = 1.f / (float)numel;
+    auto y4 = reinterpret_cast<const float4 *>(y), g4 = reinterpret_cast<const float4 *>(gt);
+    if (kind == 0)
+        hipLaunchKernelGGL(loss_partial_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y4, g4, reinterpret_cast<float4 *>(g), scratch, n4, inv_n);
+    else
+        hipLaunchKernelGGL(loss_partial_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y4, g4, reinterpret_cast<float4 *>(g), scratch, n4, inv_n);
+    RISP_LAUNCH_CHECK("risp_pixel_loss");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, blocks, inv_n, loss);
+    RISP_LAUNCH_CHECK("risp_pixel_loss");
+    return 0;
+}
+
+int risp_darts_virtual_step(const risp_list_desc *d, float momentum, float lr_meta, void *stream) {
+    if (int st = check_list(d, "risp_darts_virtual_step", 1 << 20)) return st;
+    for (int t = 0; t < d->n; ++t) RISP_CHECK_ARG(d->b[t], "risp_darts_virtual_step: tensor %d has no source", t);
+    if (d->n == 0) return 0;
+    hipLaunchKernelGGL(virtual_step_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, momentum, lr_meta);
+    RISP_LAUNCH_CHECK("risp_darts_virtual_step");
+    return 0;
+}
+
+int risp_list_norm_eps(const risp_list_desc *d, float *out, void *stream) {
+    RISP_CHECK_ARG(d && out && d->n >= 0 && d->n <= RISP_MAX_LIST, "risp_list_norm_eps: 0..%d tensors, an output of 2 floats", RISP_MAX_LIST);
+    hipLaunchKernelGGL(norm_eps_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d, out);
+    RISP_LAUNCH_CHECK("risp_list_norm_eps");
+    return 0;
+}
+
+int risp_list_axpy_scalar(const risp_list_desc *d, const float *scalar, float factor, void *stream) {
+    if (int st = check_list(d, "risp_list_axpy_scalar", 1 << 20)) return st;
+    RISP_CHECK_ARG(scalar, "risp_list_axpy_scalar: null scalar");
+    if (d->n == 0) return 0;
+    hipLaunchKernelGGL(axpy_scalar_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, scalar, factor);
+    RISP_LAUNCH_CHECK("risp_list_axpy_scalar");
+    return 0;
+}
+
+int risp_darts_alpha_grad(const risp_list_desc *d, const float *eps, float lr_meta, int *nan_flags, void *stream) {
+    if (int st = check_list(d, "risp_darts_alpha_grad", 256)) return st;
+    RISP_CHECK_ARG(eps, "risp_darts_alpha_grad: null eps");
+    if (d->n == 0) return 0;
+    hipLaunchKernelGGL(alpha_grad_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, eps, lr_meta, nan_flags);
+    RISP_LAUNCH_CHECK("risp_darts_alpha_grad");
+    return 0;
+}
+
+}  // extern "C"

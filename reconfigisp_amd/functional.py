@@ -502,12 +502,98 @@ class BilateralChainPlan:
         return self.outs
 
 
+class _PixelLoss(torch.autograd.Function):
+    """mean((y - gt)^2) / mean(|y - gt|) with the gradient formed in the same pass (risp_pixel_loss): two launches forward, a
+    scaling backward - nn.MSELoss / nn.L1Loss are an element-wise launch + a reduction forward and two launches backward."""
+
+    @staticmethod
+    def forward(ctx, y, gt, kind):
+        y, gt = _dev(y, 'output'), _dev(gt, 'target')
+        if y.shape != gt.shape or y.numel() % 4 or (y.data_ptr() | gt.data_ptr()) % 16:
+            raise ValueError('pixel_loss: shapes %s / %s must agree, numel %% 4 == 0, 16-byte aligned' % (tuple(y.shape), tuple(gt.shape)))
+        lib = L.load()
+        g = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        loss = torch.empty((), device=y.device, dtype=torch.float32)
+        scratch = torch.empty(lib.risp_loss_scratch_floats(), device=y.device, dtype=torch.float32)
+        L.call('risp_pixel_loss', _p(y), _p(gt), _p(g), _p(loss), _p(scratch), y.numel(), kind, _stream())
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        g, = ctx.saved_tensors
+        return (g * gl if g is not None else None), None, None
+
+
+def _written(tensors):
+    """The C ABI wrote these tensors in place: bump their version counters as a torch in-place op would - the mixture-weight
+    cache and the step-level reuse of the super-net key on them (a shifted parameter must miss)."""
+    torch.autograd.graph.increment_version(list(tensors))
+
+
+def _tensor_table(rows, with_numel_of=0):
+    """risp_list_desc from rows of (a, b, c, e) tensors (None = NULL); numel of column ``with_numel_of``"""
+    if len(rows) > L.LIST_MAX:
+        raise ValueError('at most %d tensors per table, got %d' % (L.LIST_MAX, len(rows)))
+    d = L.ListDesc()
+    d.n = len(rows)
+    keep = []
+    for t, row in enumerate(rows):
+        d.numel[t] = row[with_numel_of].numel()
+        for name, v in zip('abce', row):
+            if v is not None:
+                if not (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()):
+                    raise RuntimeError('reconfigisp_amd: table entries must be contiguous fp32 CUDA/HIP tensors (no CPU fallback)')
+                getattr(d, name)[t] = v.data_ptr()
+                keep.append(v)
+    return d, keep
+
+
 class _HipImpl:
     """The product implementation: every op runs in libreconfigisp_hip.so."""
 
     @staticmethod
     def skip(x, p=None):
         return x
+
+    @staticmethod
+    def pixel_loss(y, gt, kind):
+        return _PixelLoss.apply(y, gt, {'l2': 0, 'l1': 1}[kind])
+
+    @staticmethod
+    def darts_virtual_step(rows, momentum, lr_meta):
+        """rows of (twin parameter, parameter, gradient or None, momentum buffer or None): one launch (risp_darts_virtual_step)"""
+        for at in range(0, len(rows), L.LIST_MAX):
+            d, _keep = _tensor_table(rows[at: at + L.LIST_MAX], 1)
+            L.call('risp_darts_virtual_step', C.byref(d), float(momentum), float(lr_meta), _stream())
+        _written([r[0] for r in rows])
+
+    @staticmethod
+    def list_norm_eps(tensors):
+        """(2,) device tensor: the 2-norm of the concatenated tensors (None skipped) and eps = 0 if norm < 1e-6 else 0.01 / norm"""
+        live = [t for t in tensors if t is not None]
+        out = torch.empty(2, device=live[0].device, dtype=torch.float32)
+        d, _keep = _tensor_table([(t, None, t, None) for t in live], 0)
+        L.call('risp_list_norm_eps', C.byref(d), _p(out), _stream())
+        return out
+
+    @staticmethod
+    def list_axpy_scalar(pairs, scalar, factor):
+        """p += (factor * scalar) * d for every (p, d), scalar a one-element device tensor"""
+        for at in range(0, len(pairs), L.LIST_MAX):
+            d, _keep = _tensor_table([(p, None, dd, None) for p, dd in pairs[at: at + L.LIST_MAX]], 0)
+            L.call('risp_list_axpy_scalar', C.byref(d), _p(scalar), float(factor), _stream())
+        _written([p for p, _ in pairs])
+
+    @staticmethod
+    def darts_alpha_grad(rows, eps, lr_meta):
+        """rows of (out, dalpha or None, pos or None, neg or None) -> out = dalpha - lr_meta * (pos - neg) / 2 * eps, zeros where an
+        input is missing or the finite-difference term holds a NaN; returns the (len(rows),) int32 NaN flags (on the device)"""
+        flags = torch.zeros(len(rows), device=rows[0][0].device, dtype=torch.int32)
+        d, _keep = _tensor_table(rows, 0)
+        L.call('risp_darts_alpha_grad', C.byref(d), _p(eps), float(lr_meta), C.c_void_p(flags.data_ptr()), _stream())
+        _written([r[0] for r in rows])
+        return flags
 
     @staticmethod
     def wb_manual(x, p):
@@ -702,6 +788,27 @@ def slot_mix(w, x, entries, w_host=None, stacks=None):
 
 def can_fuse_slot(x, names, tensors=()):
     return _IMPL.can_fuse_slot(x, names, tensors)
+
+
+def pixel_loss(y, gt, kind='l2'):
+    """nn.MSELoss ('l2') / nn.L1Loss ('l1') of the reference (models/darts_model.py:58-63, isp_model.py:29-34): a 0-dim tensor"""
+    return _IMPL.pixel_loss(y, gt, kind)
+
+
+def darts_virtual_step(rows, momentum, lr_meta):
+    return _IMPL.darts_virtual_step(rows, momentum, lr_meta)
+
+
+def list_norm_eps(tensors):
+    return _IMPL.list_norm_eps(tensors)
+
+
+def list_axpy_scalar(pairs, scalar, factor):
+    return _IMPL.list_axpy_scalar(pairs, scalar, factor)
+
+
+def darts_alpha_grad(rows, eps, lr_meta):
+    return _IMPL.darts_alpha_grad(rows, eps, lr_meta)
 
 
 def prune_softmax(alpha, threshold, unavailable=None):

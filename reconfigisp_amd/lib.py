@@ -70,6 +70,14 @@ class SlotMixDesc(C.Structure):
                 ('ptr', _f * MIX_MAX), ('go', _f * MIX_MAX), ('gp', _f * MIX_MAX), ('x', _f), ('y', _f)]
 
 
+LIST_MAX = 64
+
+
+class ListDesc(C.Structure):
+    """mirror of risp_list_desc"""
+    _fields_ = [('n', _i), ('numel', _i * LIST_MAX), ('a', _f * LIST_MAX), ('b', _f * LIST_MAX), ('c', _f * LIST_MAX), ('e', _f * LIST_MAX)]
+
+
 def _pw(n_extra=0):
     # forward: (x, p, y, N, HW, stream); backward (n_extra = 3): (x, p, gy, gx, gp, scratch, N, HW, stream)
     return [_f] * (3 + n_extra) + [_i, _i, _s]
@@ -157,6 +165,12 @@ SIGNATURES = {
     'risp_prune_softmax_bwd': (_i, [_f, _f, _f, _i, _f, _s]),
     'risp_param_blocks_fwd': (_i, [C.POINTER(ParamBlocksDesc), _s]),
     'risp_param_blocks_bwd': (_i, [C.POINTER(ParamBlocksDesc), _s]),
+    'risp_loss_scratch_floats': (_z, []),
+    'risp_pixel_loss': (_i, [_f, _f, _f, _f, _f, _z, _i, _s]),
+    'risp_darts_virtual_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _s]),
+    'risp_list_norm_eps': (_i, [C.POINTER(ListDesc), _f, _s]),
+    'risp_list_axpy_scalar': (_i, [C.POINTER(ListDesc), _f, _fl, _s]),
+    'risp_darts_alpha_grad': (_i, [C.POINTER(ListDesc), _f, _fl, _f, _s]),
     'risp_train_scratch_floats': (_z, [_i]),
     'risp_chain_train_step': (_i, [C.POINTER(TrainDesc), _s]),
 }

@@ -11,8 +11,51 @@ def _sd(module):
     return {k: v.detach() for k, v in module.state_dict().items()}
 
 
+def _virtual_step(rows, momentum, lr_meta):
+    # the reference's per-parameter loop, darts_model.py:208-218
+    with torch.no_grad():
+        for vp, p, g, buf in rows:
+            if g is None:
+                vp.copy_(p)
+            else:
+                upd = (buf * momentum if buf is not None else 0. * momentum) + g
+                vp.copy_(p - upd * lr_meta)
+
+
+def _norm_eps(tensors):
+    norm = torch.cat([w.reshape(-1) for w in tensors if w is not None]).norm()
+    return torch.stack([norm, torch.where(norm < 1e-6, torch.zeros_like(norm), 0.01 / norm)])
+
+
+def _axpy_scalar(pairs, scalar, factor):
+    with torch.no_grad():
+        for p, d in pairs:
+            p.add_(d * (factor * scalar.reshape(())))
+
+
+def _alpha_grad(rows, eps, lr_meta):
+    flags = torch.zeros(len(rows), dtype=torch.int32)
+    with torch.no_grad():
+        for t, (out, da, pos, neg) in enumerate(rows):
+            if da is None or pos is None or neg is None:
+                out.zero_()
+                continue
+            h = (pos - neg) / 2. * eps.reshape(())
+            if torch.isnan(h).any():
+                flags[t] = 1
+                out.zero_()
+            else:
+                out.copy_(da - lr_meta * h)
+    return flags
+
+
 class OracleImpl:
     skip = staticmethod(lambda x, p=None: x)
+    pixel_loss = staticmethod(lambda y, gt, kind: torch.nn.functional.mse_loss(y, gt) if kind == 'l2' else torch.nn.functional.l1_loss(y, gt))
+    darts_virtual_step = staticmethod(_virtual_step)
+    list_norm_eps = staticmethod(_norm_eps)
+    list_axpy_scalar = staticmethod(_axpy_scalar)
+    darts_alpha_grad = staticmethod(_alpha_grad)
     wb_manual = staticmethod(lambda x, gain: x * gain.view(-1, 3, 1, 1))     # the seam takes the gain (= 5p)
     gamma = staticmethod(O.gamma_manual)
     gtm_manual = staticmethod(O.gtm_manual)

@@ -83,6 +83,8 @@ def test_training_and_mixture_descriptors_match_header():
     assert [f for f, _ in lib.ParamBlocksDesc._fields_] == _struct_fields('risp_param_blocks_desc')
     assert [f for f, _ in lib.SrcnnGroupDesc._fields_] == _struct_fields('risp_srcnn_group_desc')
     assert [f for f, _ in lib.SlotMixDesc._fields_] == _struct_fields('risp_slot_mix_desc')
+    assert [f for f, _ in lib.ListDesc._fields_] == _struct_fields('risp_list_desc')
+    assert lib.LIST_MAX == 64 and '#define RISP_MAX_LIST 64' in open(os.path.join(ROOT, 'include', 'risp.h')).read()
     assert lib.MIX_MAX == 16 and '#define RISP_MAX_MIX 16' in open(os.path.join(ROOT, 'include', 'risp.h')).read()
     assert lib.TRAIN_MAX == 6 and lib.PARAM_OPS_MAX == 16           # RISP_MAX_TRAIN_CHAIN / RISP_MAX_PARAM_OPS
     assert lib.GROUP_MAX == 16 and '#define RISP_MAX_GROUP 16' in open(os.path.join(ROOT, 'include', 'risp.h')).read()

@@ -107,15 +107,14 @@ for name, l in libs.items():                       # diagnostic builds (-DRISP_H
         continue
     l.risp_conv_f16x2_occupancy.restype = C.c_int
     nwg = min(((w + 63) // 64) * ((h + 7) // 8) * n * (cout // 32 if K == 5 else 1), (1 if 'RISP_H2_WGS=1' in name else 2) * torch.cuda.get_device_properties(0).multi_processor_count)
-    buf = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device='cuda')
+    buf = torch.zeros(nwg * 4 * 10, dtype=torch.int64, device='cuda')
     ds = desc(ph)
     ds.cvals = buf.data_ptr()
     for _ in range(3):
         l.risp_conv2d_f16x2(C.byref(ds), None)
     torch.cuda.synchronize()
-    raw = buf.view(nwg * 4, 8)
-    steps = (raw[:, 6] >> 40).double()                # issue time of the matrix-instruction steps alone (upper bits of slot 6)
-    raw[:, 6] &= (1 << 40) - 1
+    raw = buf.view(nwg * 4, 10)
+    steps = raw[:, 8].double()                        # issue time of the matrix-instruction steps alone
     t = raw.double()
     life = t[:, 4]
     clk = (life / ((t[:, 6] - t[:, 5]) * 10e-9)).median().item() / 1e9       # s_memrealtime ticks at 100 MHz
@@ -123,12 +122,12 @@ for name, l in libs.items():                       # diagnostic builds (-DRISP_H
     print('%s: workgroups per CU %d; in-kernel clock %.2f GHz; wave life %.0f cycles (median); shares: wait for tile %.3f, staging '
           '(barrier A .. barrier B) %.3f, matrix phase %.3f, epilogue %.3f' % (
               name, l.risp_conv_f16x2_occupancy(), clk, life.median().item(), *(t[:, i].sum().item() / life.sum().item() for i in range(4))))
-    hw_id = buf.view(nwg * 4, 8)[:, 7]
+    hw_id = buf.view(nwg * 4, 10)[:, 7]
     cu = ((hw_id >> 8) & 0xf) | (((hw_id >> 13) & 0x7) << 4) | (((hw_id >> 32) & 0xf) << 8)        # cu_id, se_id (gfx9 HW_ID layout), xcc_id
     if nwg % 2 == 0:
         cw = cu.view(nwg, 4)[:, 0]
         print('   workgroups b and b + %d on the same CU: %d of %d' % (nwg // 2, int((cw[:nwg // 2] == cw[nwg // 2:]).sum().item()), nwg // 2))
-    start = buf.view(nwg * 4, 8)[:, 5]
+    start = buf.view(nwg * 4, 10)[:, 5]
     print('   start spread (100 MHz ticks): %d; distinct (se, cu) ids seen %d' % ((start.max() - start.min()).item(), len(set(cu.tolist()))))
 flop = 2.0 * cin * cout * K * K * n * h * w
 byts = 4.0 * n * h * w * (cin + cout * (1 + full_epi + use_mask))
