@@ -34,6 +34,8 @@ def test_one_rank_process_group_on_rccl_changes_no_bit(tmp_path):
     assert ranked['darts'].pop('comm_seconds').item() > 0          # the four all-reduces of the iteration really ran
     plain['darts'].pop('comm_seconds')
     calls = ranked['darts'].pop('allreduce_ops')                    # four gradient sets per iteration, each: copy in, collective, copy out
+    # (the first use of a gradient set also allocates its flat buffer and cuts the views: metadata, no launches)
+    calls = [[o for o in ops if not any(m in o for m in ('aten.empty', 'aten.split_with_sizes', 'aten.view'))] for ops in calls]
     assert len(calls) == 4 and all(len(ops) <= 3 for ops in calls), calls
     assert all(sum('allreduce' in o for o in ops) == 1 and sum('_foreach_copy_' in o for o in ops) == 2 for ops in calls), calls
     assert set(plain['darts']) == set(ranked['darts'])

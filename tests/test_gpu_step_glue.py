@@ -1,0 +1,92 @@
+"""GPU parity of the DARTS step glue (risp_step.hip): the pixel loss with its gradient against nn.MSELoss / nn.L1Loss, and the
+list-wide kernels against the reference's per-parameter loops (models/darts_model.py:159-180, 204-222, 254-265, 299-323) - the
+same arithmetic operation by operation, so the list kernels must give the SAME BITS as the torch loops."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.standard_normal(shape).astype(np.float32)).cuda()
+
+
+@pytest.mark.parametrize('kind', ['l2', 'l1'])
+@pytest.mark.parametrize('shape', [(4, 3, 256, 256), (1, 3, 8, 12), (2, 3, 62, 34)])
+def test_pixel_loss_value_and_gradient(kind, shape):
+    from reconfigisp_amd import functional as F
+    y, gt = rnd(*shape, seed=1).requires_grad_(True), rnd(*shape, seed=2)
+    ref_fn = torch.nn.functional.mse_loss if kind == 'l2' else torch.nn.functional.l1_loss
+    ref = ref_fn(y.double(), gt.double())
+    gref, = torch.autograd.grad(ref, y)
+    loss = F.pixel_loss(y, gt, kind)
+    assert loss.shape == () and abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    for gout in (None, torch.tensor(0.37, device='cuda')):
+        g, = torch.autograd.grad(loss, y, gout, retain_graph=True)
+        want = gref * (1.0 if gout is None else 0.37)
+        assert (g.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    assert torch.equal(F.pixel_loss(y, gt, kind), loss)                 # fixed summation order
+
+
+def test_pixel_loss_module_takes_what_the_kernel_does_not():
+    from reconfigisp_amd.codes.models.darts_model import PixelLoss
+    y, gt = rnd(1, 3, 5, 5, seed=3), rnd(1, 3, 5, 5, seed=4)            # 75 values: numel % 4 != 0 -> torch
+    assert torch.allclose(PixelLoss('l2')(y, gt), torch.nn.functional.mse_loss(y, gt))
+    v = rnd(2, 3, 16, 17, seed=5)[:, :, :, 1:]                          # a non-contiguous view
+    assert torch.allclose(PixelLoss('l1')(v, torch.zeros_like(v)), v.abs().mean())
+
+
+def _tensors(seed, sizes=(1, 3, 5, 15, 2, 64, 7)):
+    return [rnd(n, seed=seed + i) for i, n in enumerate(sizes)]
+
+
+def test_virtual_step_is_the_reference_loop_bit_for_bit():
+    from reconfigisp_amd import functional as F
+    p, g, buf = _tensors(10), _tensors(20), _tensors(30)
+    vp = [torch.full_like(t, float('nan')) for t in p]
+    g[2] = None                                                         # no gradient arrived: plain copy
+    buf[4] = None                                                       # no momentum buffer yet
+    mom, lr = 0.9, 1e-4
+    before = [t._version for t in vp]
+    F.darts_virtual_step(list(zip(vp, p, g, buf)), mom, lr)
+    for k in range(len(p)):
+        if g[k] is None:
+            want = p[k]
+        else:
+            upd = (buf[k] * mom if buf[k] is not None else 0. * mom) + g[k]
+            want = p[k] - upd * lr
+        assert torch.equal(vp[k], want), k
+    assert all(t._version > v for t, v in zip(vp, before))             # in-place through the C ABI, version counters bumped
+
+
+def test_norm_eps_shifts_and_architecture_gradient():
+    from reconfigisp_amd import functional as F
+    dp = _tensors(40)
+    ne = F.list_norm_eps(dp + [None])
+    norm = torch.cat([t.reshape(-1) for t in dp]).double().norm()
+    assert abs(ne[0].item() - norm.item()) <= 2e-6 * norm.item() and abs(ne[1].item() - 0.01 / norm.item()) <= 2e-6 * 0.01 / norm.item()
+    assert F.list_norm_eps([torch.zeros(5, device='cuda')])[1].item() == 0.0           # norm < 1e-6 -> eps = 0 (:276-277)
+    eps = ne[1:2]
+    p = _tensors(50)
+    q = [t.clone() for t in p]
+    F.list_axpy_scalar(list(zip(q, dp)), eps, -2.)
+    for a, b, d in zip(q, p, dp):
+        assert torch.equal(a, b + d * (-2. * eps.reshape(())))
+    # architecture gradient with a missing term and a NaN
+    da, pos, neg = _tensors(60, (4, 2, 15, 8)), _tensors(70, (4, 2, 15, 8)), _tensors(80, (4, 2, 15, 8))
+    pos[1] = None
+    neg[3][2] = float('nan')
+    out = [torch.full_like(t, 7.0) for t in da]
+    flags = F.darts_alpha_grad(list(zip(out, da, pos, neg)), eps, 1e-4)
+    assert flags.tolist() == [0, 0, 0, 1]
+    for k in (0, 2):
+        assert torch.equal(out[k], da[k] - 1e-4 * ((pos[k] - neg[k]) / 2. * eps.reshape(()))), k
+    assert out[1].abs().max().item() == 0 and out[3].abs().max().item() == 0
+
+
+def test_tables_refuse_cpu_tensors():
+    from reconfigisp_amd import functional as F
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        F.darts_virtual_step([(torch.zeros(3), torch.zeros(3), None, None)], 0.9, 1e-4)
