@@ -427,6 +427,12 @@ int risp_list_norm_eps(const risp_list_desc *d, float *out, void *stream);
 /* a[t] += (factor * scalar[0]) * c[t] (c NULL: untouched): the +eps, -2 eps, +eps shifts of the parameters (:299-312) with
  * eps on the device. */
 int risp_list_axpy_scalar(const risp_list_desc *d, const float *scalar, float factor, void *stream);
+/* The optimizers of the search (darts_model.py:78-81) over the table, in place, as torch.optim writes them (no weight decay,
+ * dampening, nesterov, amsgrad): SGD with momentum - e = momentum buffers: e = first ? c : e * momentum + c; a -= lr * e - and
+ * Adam - b = exp_avg, e = exp_avg_sq (both updated), lr_step = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t).  Rows whose
+ * gradient c is NULL are left alone. */
+int risp_sgd_momentum_step(const risp_list_desc *d, float lr, float momentum, int first, void *stream);
+int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float bias2_sqrt, float eps, void *stream);
 /* architecture gradient, :254-265 with :313-323: a = b - lr_meta * ((c - e) / 2 * eps[0]); zeros where b, c or e is NULL or
  * the finite-difference term holds a NaN (nan_flags[t] = 1 there; may be NULL).  numel <= 256. */
 int risp_darts_alpha_grad(const risp_list_desc *d, const float *eps, float lr_meta, int *nan_flags, void *stream);

@@ -27,6 +27,7 @@ from ..utils.util_loss import latency_loss, local_global_loss
 from . import networks
 from .base_model import BaseModel
 from .isp_model import make_schedulers
+from .list_optim import ListAdam, ListSGD
 
 logger = logging.getLogger('base')
 
@@ -91,10 +92,9 @@ class DartsModel(BaseModel):
             self.sync_arch_grads = bool(t.get('sync_arch_grads', True)) if hasattr(t, 'get') else True
             self.step_reuse = bool(t.get('step_reuse', True)) if hasattr(t, 'get') else True
             self.weight_step_alpha_grads = bool(t.get('weight_step_alpha_grads', False)) if hasattr(t, 'get') else False
-            self.optimizer_G = torch.optim.SGD(self.netG_attr.trainable_parameters, t['lr_G'],
-                                               momentum=self.momentum_G)
-            self.optimizer_alpha = torch.optim.Adam(self.netG_attr.alphas, lr=t['lr_G'],
-                                                    betas=(t['beta1'], t['beta2']))
+            # torch.optim.SGD / Adam with step() as one launch each (list_optim.py; same state, same arithmetic)
+            self.optimizer_G = ListSGD(self.netG_attr.trainable_parameters, t['lr_G'], momentum=self.momentum_G)
+            self.optimizer_alpha = ListAdam(self.netG_attr.alphas, lr=t['lr_G'], betas=(t['beta1'], t['beta2']))
             self.optimizers += [self.optimizer_G, self.optimizer_alpha]
             self.schedulers += make_schedulers(self.optimizers, t)
         else:
@@ -229,8 +229,9 @@ class DartsModel(BaseModel):
         self.log_dict['loss'] = l_pix.item()
         flags, self._nan_flags = getattr(self, '_nan_flags', None), None
         if flags is not None:                       # (the queue is drained by the read-out above anyway)
-            for idx in flags.nonzero().flatten().tolist():
-                print('Warning: NaN in hessian, for the {}-th alpha'.format(idx + 1))
+            for idx, bad in enumerate(flags.tolist()):
+                if bad:
+                    print('Warning: NaN in hessian, for the {}-th alpha'.format(idx + 1))
         if self.is_latency:
             self.log_dict['latency'] = self.latency.item()
             self.log_dict['latency_term'] = self.latency_term.item()

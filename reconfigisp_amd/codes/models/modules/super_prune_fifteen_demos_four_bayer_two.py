@@ -172,10 +172,10 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             members = [mods[index[i]] for i in pos]
             if len(pos) >= 2 and F.can_group(members, x):
                 if kind == 'res':
-                    fn = (lambda members=members, pos=pos: F.srcnn_res_group(x, [args[i] for i in pos], members, cache))
+                    fn = (lambda xj, members=members, pos=pos: F.srcnn_res_group(xj, [args[i] for i in pos], members, cache))
                 else:
                     rec = self._record(slot, index[pos[0]], token, members[0])
-                    fn = (lambda members=members, rec=rec: F.srcnn_demosaic_group(x, members, cache, rec))
+                    fn = (lambda xj, members=members, rec=rec: F.srcnn_demosaic_group(xj, members, cache, rec))
                 jobs.append((pos, fn))
                 taken.update(pos)
         heavy = [i for i in range(len(index)) if i not in taken and isinstance(mods[index[i]], (TP.PathRestore14lBgr,
@@ -183,12 +183,13 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         rest = [i for i in range(len(index)) if i not in taken and i not in heavy]
         for i in heavy:
             self._record(slot, index[i], token, mods[index[i]])      # read by F.path14l_* through the module
-        single = [([i], (lambda i=i: [mods[index[i]](x, args[i])])) for i in heavy + rest]
+        single = [([i], (lambda xj, i=i: [mods[index[i]](xj, args[i])])) for i in heavy + rest]
         # group, Path-Restore, then the light ops: with two streams the two heavy jobs land on different streams
         return jobs[:1] + single[:len(heavy)] + jobs[1:] + single[len(heavy):]
 
-    def _run_jobs(self, jobs, n_out, x, args):
-        """outs[i] for every surviving op.  The jobs of a slot are independent given the slot input, so they are issued
+    def _run_jobs(self, jobs, n_out, x, args, xs=None):
+        """outs[i] for every surviving op; ``xs``: the slot input per job (aliases of x with a one-launch gradient sum,
+        functional.fan_out).  The jobs of a slot are independent given the slot input, so they are issued
         round-robin on two HIP streams: launches of different jobs overlap and fill each other's gaps - a convolution
         launch runs its workgroups in lockstep rounds and leaves the matrix pipes idle through each prologue / store
         drain.  The backward pass inherits the streams (autograd runs a node on the stream of its forward).  Same
@@ -198,9 +199,10 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         pixels = x.shape[0] * x.shape[2] * x.shape[3]
         n_streams = SLOT_STREAMS if (x.is_cuda and len(jobs) >= SLOT_STREAMS_MIN_JOBS and pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
         outs = [None] * n_out
+        xs = xs if xs is not None else [x] * len(jobs)
         if n_streams <= 1:
-            for pos, fn in jobs:
-                for i, o in zip(pos, fn()):
+            for (pos, fn), xj in zip(jobs, xs):
+                for i, o in zip(pos, fn(xj)):
                     outs[i] = o
             return outs
         main = torch.cuda.current_stream()
@@ -219,7 +221,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                     if args[i] is not None:
                         args[i].record_stream(s)
             with torch.cuda.stream(s):
-                res = fn()
+                res = fn(xs[j])
             for i, o in zip(pos, res):
                 if s is not main and o is not x:
                     o.record_stream(main)                 # consumed by the mixture kernel on the main stream
@@ -296,7 +298,10 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
             jobs = self._jobs(slot, mods, index, args, x, token, skip=set(fused))
             if token is not None:       # value token of this slot's output
                 token = (token, slot, alpha.data_ptr(), alpha._version, tuple((p.data_ptr(), p._version) for p in live_pars))
-            outs = self._run_jobs(jobs, len(index), x, args)
+            # every consumer of the slot input gets its own alias: their gradients are added by one launch instead of autograd's
+            # pairwise additions
+            xs = F.fan_out(x, len(jobs) + (1 if fused else 0))
+            outs = self._run_jobs(jobs, len(index), x, args, xs[:len(jobs)])
             sel = self._select(post, index, len(weights))
             stacks = [pos for pos, _ in jobs if len(pos) > 1]
             if fused and not F.can_fuse_slot(x, list(fused.values()), [outs[i] for i in range(len(index)) if i not in fused]):
@@ -306,7 +311,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
                 fused = {}
             if fused:
                 entries = [('op', fused[i], args[i]) if i in fused else ('tensor', outs[i]) for i in range(len(index))]
-                y = F.slot_mix(sel, x, entries, w_host=[weights[k] for k in index], stacks=stacks)
+                y = F.slot_mix(sel, xs[-1], entries, w_host=[weights[k] for k in index], stacks=stacks)
             else:
                 y = F.mix(sel, outs, w_host=[weights[k] for k in index], stacks=stacks)
             if pruned_pars:

@@ -113,6 +113,41 @@ __global__ __launch_bounds__(64) void alpha_grad_kernel(const risp_list_desc d, 
     if (threadIdx.x == 0 && flags) flags[t] = any_bad ? 1 : 0;
 }
 
+// torch.optim.SGD with momentum (dampening 0, no weight decay / nesterov), one wave per tensor: buf = first ? g : buf * momentum + g;
+// p = p - lr * buf  (a = p, c = g, e = momentum buffer, all updated in place)
+__global__ __launch_bounds__(64) void sgd_momentum_kernel(const risp_list_desc d, float lr, float momentum, int first) {
+    const int t = blockIdx.x;
+    float *p = d.a[t], *buf = const_cast<float *>(d.e[t]);
+    const float *g = d.c[t];
+    if (!g) return;
+    for (int i = threadIdx.x; i < d.numel[t]; i += 64) {
+        const float b = first ? g[i] : buf[i] * momentum + g[i];
+        buf[i] = b;
+        p[i] = p[i] - lr * b;
+    }
+}
+
+// torch.optim.Adam (no weight decay / amsgrad), one wave per tensor, as torch writes it:
+//   exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+//   denom = exp_avg_sq.sqrt() / sqrt(1 - beta2^t) + eps; param.addcdiv_(exp_avg, denom, value = -lr / (1 - beta1^t))
+// a = p, c = g, b = exp_avg, e = exp_avg_sq (b and e updated in place)
+__global__ __launch_bounds__(64) void adam_kernel(const risp_list_desc d, float lr_step, float beta1, float beta2, float bias2_sqrt, float eps) {
+    const int t = blockIdx.x;
+    float *p = d.a[t], *ea = const_cast<float *>(d.b[t]), *es = const_cast<float *>(d.e[t]);
+    const float *g = d.c[t];
+    if (!g) return;
+    for (int i = threadIdx.x; i < d.numel[t]; i += 64) {
+        const float grad = g[i];
+        float m = ea[i], v = es[i];
+        m = __builtin_fmaf(1.f - beta1, grad - m, m);
+        v = __builtin_fmaf((1.f - beta2) * grad, grad, v * beta2);
+        const float denom = __builtin_sqrtf(v) / bias2_sqrt + eps;
+        ea[i] = m;
+        es[i] = v;
+        p[i] = p[i] - lr_step * (m / denom);
+    }
+}
+
 int check_list(const risp_list_desc *d, const char *name, int max_numel) {
     RISP_CHECK_ARG(d && d->n >= 0 && d->n <= RISP_MAX_LIST, "%s: 0..%d tensors", name, RISP_MAX_LIST);
     for (int t = 0; t < d->n; ++t)
@@ -167,6 +202,24 @@ int risp_list_axpy_scalar(const risp_list_desc *d, const float *scalar, float fa
     if (d->n == 0) return 0;
     hipLaunchKernelGGL(axpy_scalar_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, scalar, factor);
     RISP_LAUNCH_CHECK("risp_list_axpy_scalar");
+    return 0;
+}
+
+int risp_sgd_momentum_step(const risp_list_desc *d, float lr, float momentum, int first, void *stream) {
+    if (int st = check_list(d, "risp_sgd_momentum_step", 1 << 20)) return st;
+    for (int t = 0; t < d->n; ++t) RISP_CHECK_ARG(d->e[t], "risp_sgd_momentum_step: tensor %d has no momentum buffer", t);
+    if (d->n == 0) return 0;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, lr, momentum, first);
+    RISP_LAUNCH_CHECK("risp_sgd_momentum_step");
+    return 0;
+}
+
+int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float bias2_sqrt, float eps, void *stream) {
+    if (int st = check_list(d, "risp_adam_step", 1 << 20)) return st;
+    for (int t = 0; t < d->n; ++t) RISP_CHECK_ARG(d->b[t] && d->e[t], "risp_adam_step: tensor %d has no moment buffers", t);
+    if (d->n == 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, lr_step, beta1, beta2, bias2_sqrt, eps);
+    RISP_LAUNCH_CHECK("risp_adam_step");
     return 0;
 }
 

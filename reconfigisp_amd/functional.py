@@ -502,6 +502,36 @@ class BilateralChainPlan:
         return self.outs
 
 
+class _FanOut(torch.autograd.Function):
+    """k aliases of one tensor whose gradients are added by ONE launch (operand order, the order autograd's own pairwise
+    additions take: the same bits) - the slot input of a super-net feeds the proxy group, Path-Restore and the fused mixture, and
+    autograd otherwise spends k - 1 element-wise launches per slot and backward pass on the sum."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [_dev(g, 'grad') for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        y = torch.empty_like(live[0])
+        k = len(live)
+        L.call('risp_mix_fwd', L.ptr_array([g.data_ptr() for g in live]), (C.c_float * k)(*([1.0] * k)), k, _p(y), y.numel(), _stream())
+        return y, None
+
+
+def fan_out(x, k):
+    """[x] * k, or k aliases with a one-launch gradient sum (see _FanOut) when a gradient will flow into x on the device"""
+    if k < 2 or not (x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.dtype == torch.float32 and k <= L.MIX_MAX
+                     and x.is_contiguous() and x.numel() % 4 == 0 and x.data_ptr() % 16 == 0):
+        return [x] * k
+    return list(_FanOut.apply(x, k))
+
+
 class _PixelLoss(torch.autograd.Function):
     """mean((y - gt)^2) / mean(|y - gt|) with the gradient formed in the same pass (risp_pixel_loss): two launches forward, a
     scaling backward - nn.MSELoss / nn.L1Loss are an element-wise launch + a reduction forward and two launches backward."""

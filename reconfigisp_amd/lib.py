@@ -171,6 +171,8 @@ SIGNATURES = {
     'risp_list_norm_eps': (_i, [C.POINTER(ListDesc), _f, _s]),
     'risp_list_axpy_scalar': (_i, [C.POINTER(ListDesc), _f, _fl, _s]),
     'risp_darts_alpha_grad': (_i, [C.POINTER(ListDesc), _f, _fl, _f, _s]),
+    'risp_sgd_momentum_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _i, _s]),
+    'risp_adam_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _fl, _fl, _fl, _s]),
     'risp_train_scratch_floats': (_z, [_i]),
     'risp_chain_train_step': (_i, [C.POINTER(TrainDesc), _s]),
 }

@@ -90,3 +90,43 @@ def test_tables_refuse_cpu_tensors():
     from reconfigisp_amd import functional as F
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         F.darts_virtual_step([(torch.zeros(3), torch.zeros(3), None, None)], 0.9, 1e-4)
+
+
+def test_list_optimizers_follow_torch_optim():
+    """ListSGD / ListAdam (codes/models/list_optim.py): torch.optim's state keys and arithmetic, step() as one launch"""
+    from reconfigisp_amd.codes.models.list_optim import ListAdam, ListSGD
+    sizes = (1, 3, 15, 2, 30, 7)
+    for cls, ref_cls, kw in ((ListSGD, torch.optim.SGD, dict(lr=1e-2, momentum=0.9)),
+                             (ListAdam, torch.optim.Adam, dict(lr=1e-3, betas=(0.9, 0.99)))):
+        a = [torch.nn.Parameter(rnd(n, seed=100 + i)) for i, n in enumerate(sizes)]
+        b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        oa, ob = cls(a, **kw), ref_cls(b, **kw)
+        for it in range(4):
+            for k, (p, q) in enumerate(zip(a, b)):
+                g = rnd(p.numel(), seed=1000 * it + k)
+                p.grad, q.grad = (None, None) if (k == 3 and it == 1) else (g.clone(), g.clone())     # a parameter without a gradient
+            va = [p._version for p in a]
+            oa.step()
+            ob.step()
+            assert all(p._version > v for p, v, q in zip(a, va, b) if q.grad is not None)
+            for p, q in zip(a, b):
+                assert (p - q).abs().max().item() <= 1e-6 * max(q.abs().max().item(), 1e-3), (cls.__name__, it)
+        sa, sb = oa.state_dict()['state'], ob.state_dict()['state']
+        assert sa.keys() == sb.keys() and all(sa[k].keys() == sb[k].keys() for k in sa)
+        for k in sa:
+            for name in sa[k]:
+                assert torch.allclose(sa[k][name].float().cpu(), sb[k][name].float().cpu(), rtol=1e-5, atol=1e-8), (cls.__name__, k, name)
+
+
+def test_fan_out_sums_the_gradients_like_autograd():
+    from reconfigisp_amd import functional as F
+    x = rnd(2, 3, 16, 20, seed=200).requires_grad_(True)
+    a, b, c = F.fan_out(x, 3)
+    assert a.data_ptr() == x.data_ptr() and a is not b
+    ws = [rnd(2, 3, 16, 20, seed=201 + i) for i in range(3)]
+    g, = torch.autograd.grad((a * ws[0]).sum() + (b * ws[1]).sum() + (c * ws[2]).sum(), x)
+    assert torch.equal(g, (ws[0] + ws[1]) + ws[2])
+    a, b = F.fan_out(x, 2)
+    g, = torch.autograd.grad((a * ws[0]).sum(), x)               # an alias nobody differentiates through
+    assert torch.equal(g, ws[0])
+    assert F.fan_out(x.detach(), 3)[0] is not None and all(t.data_ptr() == x.data_ptr() for t in F.fan_out(x.detach(), 3))
