@@ -20,8 +20,8 @@
 // bits, below that the absolute error is 2^-39 of the maximum.  No inter-kernel state, deterministic, and a gradient tensor
 // of magnitude 1e-8 is as exact as an activation tensor of magnitude 1.
 //
-// Kernel.  Workgroup = 4 waves = 8 rows x 64 pixels x NT cout blocks of 32; a wave owns 2 rows x 64 pixels = 4 pixel tiles of
-// 32 (B operand) x NT cout blocks (A operand): lane (n, half) of pixel tile t holds row (n >> 4), column 4 (n & 15) + t, so that
+// Kernel.  Workgroup = 4 waves = 8 rows x 64 pixels x NT cout blocks of 32; a wave owns 2 rows (w, w + 4) x 64 pixels = 4 pixel tiles
+// of 32 (B operand) x NT cout blocks (A operand): lane (n, half) of pixel tile t holds row w + 4 (n >> 4), column 4 (n & 15) + t, so that
 // the four tiles give a lane four CONSECUTIVE pixels of a cout row - 16-byte stores, 16 lanes = 256 contiguous bytes, no LDS
 // transposition.  Per chunk of 16 input channels the halo tile is staged through registers (8 x 16-byte loads per thread = 4
 // pixels x 8 channels, scaled, split, 8 x ds_write_b128); the weights arrive pre-split by LDS-DMA, one STAGE = one filter row
@@ -243,10 +243,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
         *reinterpret_cast<unsigned *>(base + C::PART * 16) = __builtin_bit_cast(unsigned, ll);
     };
 
-    // operand addresses.  B = pixels: lane (n = lane & 31, hl) of pixel tile t holds row 2 wave + (n >> 4), column 4 (n & 15) + t;
+    // operand addresses.  B = pixels: lane (n = lane & 31, hl) of pixel tile t holds row wave + 4 (n >> 4), column 4 (n & 15) + t;
     // at tap (ky, kx) its slot is row + ky, ((t + kx) & 3) * S + (n & 15) + ((t + kx) >> 2): a compile-time offset from bbase.
     // A = weights: lane (m = lane & 31, hl) holds cout m of a block, channels 8 hl .. 8 hl + 7.
-    const int bbase = (hl * IH + 2 * wave + (l31 >> 4)) * RS + (l31 & 15);
+    // (a wave's two rows are FOUR apart - wave, wave + 4: a 16-byte LDS read is free of bank conflicts only if lanes 16-31 sit a
+    // multiple of 256 bytes from lanes 0-15 (tools/lds_bank_probe.hip: 3.9 conflict cycles per read at a stride of one 1088-byte
+    // tile row, 0 at four rows = 17 x 256 bytes; the offset of the upper half-wave does not matter))
+    const int bbase = (hl * IH + wave + 4 * (l31 >> 4)) * RS + (l31 & 15);
     const int abase = hl * NT * 32 + l31;
     // Weight stages (one filter row of one chunk each) go through a ring of LDS buffers, the LDS-DMA AHEAD stages in front of the
     // matrix instructions.  The wait in front of a stage's closing barrier is a COUNTED wait for the pieces of the NEXT stage that
@@ -476,13 +479,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
 #endif
         }
         // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias).  Lane (n, hl): couts 32 b + 8 (e >> 2) + 4 hl + (e & 3) of the
-        // tile's cout block(s), the four pixels 4 (n & 15) .. + 3 of row 2 wave + (n >> 4) sit in the four pixel tiles: one 16-byte
+        // tile's cout block(s), the four pixels 4 (n & 15) .. + 3 of row wave + 4 (n >> 4) sit in the four pixel tiles: one 16-byte
         // store per cout, 16 lanes = 256 contiguous bytes of a cout row.
 #ifdef RISP_H2_STAMPS
         const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
         {
-            const int oy = cur.y0 + 2 * wave + (l31 >> 4), ox = cur.x0 + 4 * (l31 & 15);
+            const int oy = cur.y0 + wave + 4 * (l31 >> 4), ox = cur.x0 + 4 * (l31 & 15);
             const int g = d.group_n > 0 ? cur.n / d.group_n : 0;
             const int na = (d.group_flags & RISP_GROUP_SHARED_ADD) ? cur.n - g * d.group_n : cur.n;
             const float inv_sw = *reinterpret_cast<const float *>(cur.w);
