@@ -313,6 +313,19 @@ int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
 size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
 
+/* The same arithmetic for layers with at most 4 output channels and a 5- or 9-tap filter row (round 4; SRCNNRes conv 5x5 32 -> 3,
+ * srcnn_res_arch.py:22; backward-data of its 9x9 first layer restricted to the 3 image channels, :18; backward-data of
+ * SRCNNDemosaic's 9x9 4 -> 64 through PixelShuffle, srcnn_demosaic_arch.py:14-16): the rows of the matrix instruction are
+ * (cout, position j inside a block of 8 pixels), its columns the 32 blocks of a 256-pixel row, its reduction index a window of 16
+ * input pixels of one input channel and filter row - a Toeplitz band of the filter row as the A operand.
+ * wpack: risp_conv_toep_wpack_bytes() bytes, 16-byte aligned: a 16-byte header whose first float is 1 / s_w, then
+ * [cin][ky][part: hi, lo][window half][row m = 8 cout + j, padded to 32][8 window slots] _Float16 with
+ * band[m][u] = w[co][ci][ky][u - j + k/2 - 4] s_w (0 outside the filter row; reconfigisp_amd/convnets.py::toep_weights).
+ * cout <= 4, any cin, ksize 5 or 9, W % 4 == 0, fewer than 2^30 input elements per image, 16-byte aligned tensors, load_mode PLAIN;
+ * epilogue RELU | ADD (add_c <= cout) | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout == 4; grouped launches. */
+size_t risp_conv_toep_wpack_bytes(int cin, int cout, int ksize);
+int risp_conv2d_toep(const risp_conv_desc *d, void *stream);
+
 /* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */

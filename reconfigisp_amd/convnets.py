@@ -136,6 +136,34 @@ def f16x2_weights(w, transpose):
     return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
 
 
+def toep_weights(w, transpose=False, keep=None):
+    """Pre-split Toeplitz-band pack of ``risp_conv2d_toep`` (include/risp.h) from a layer's (cout <= 4, cin, k, k) tensor, k = 5 or
+    9: a 16-byte header whose first float is 1 / s_w, then [cin][ky][part: hi, lo][window half][row m = 8 cout + j, padded to 32]
+    [8 window slots] halves with band[m][u] = w[co][ci][ky][u - j + k // 2 - 4] * s_w - the filter row as seen by the j-th pixel of
+    a block of 8 from a window of 16 input pixels that starts 4 pixels left of the block.  ``transpose``: the backward-data layer
+    of a FORWARD weight (roles swapped, taps rotated by 180 degrees) restricted to its first ``keep`` input channels.  Scale and
+    split as in ``f16x2_weights``; pure tensor algebra on the device of ``w``.  Returns a float16 tensor."""
+    if transpose:
+        w = w[:, :keep].flip(2, 3).transpose(0, 1)
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    if co > 4 or k not in (5, 9):
+        raise ValueError('Toeplitz-band pack: %d output channels (at most 4), %d taps (5 or 9)' % (co, k))
+    _, e = torch.frexp(w.detach().abs().max())
+    sw = torch.ldexp(torch.ones((), device=w.device), 15 - e)
+    ws = w.detach().float() * sw
+    hi = ws.half()
+    parts = (hi, (ws - hi.float()).half())
+    band = torch.zeros((2, ci, k, 4, 8, 16), device=w.device, dtype=torch.float16)      # (part, ci, ky, cout, j, u)
+    for j in range(8):
+        for part in range(2):
+            band[part, :, :, :co, j, j + 4 - k // 2:j + 4 - k // 2 + k] = parts[part].permute(1, 2, 0, 3)
+    #       (part, ci, ky, m, half, 8) -> (ci, ky, part, half, m, 8)
+    band = band.view(2, ci, k, 32, 2, 8).permute(1, 2, 0, 4, 3, 5).contiguous()
+    hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
+    hdr[0] = 1.0 / sw
+    return torch.cat([hdr.view(torch.float16), band.reshape(-1)])
+
+
 WINO_F45 = os.environ.get('RISP_WINO_F45', '1') != '0'       # 5x5: F(4,5) where cin % 4 == 0 (default), else F(2,5)
 # Arithmetic of the wide hidden layers (3x3, cin % 16 == 0, cout 32 / 64): 'f16x2' (default) = split precision on the f16 matrix
 # pipe - each fp32 operand as two f16 halves, three products, fp32 accumulation (risp_conv2d_f16x2: fp32 tensors in and out,
@@ -242,8 +270,11 @@ class SmallConv:
     FORWARD weight (roles swapped, taps rotated by 180 degrees), restricted to its first ``keep`` input channels."""
 
     def __init__(self, weight, bias=None, transpose=False, keep=None):
-        self.wpack, self.cout = small_weights(_dev(weight.detach(), 'weight'), transpose, keep)
+        w = _dev(weight.detach(), 'weight')
+        self.wpack, self.cout = small_weights(w, transpose, keep)
         self.cin, self.k = self.wpack.shape[0], self.wpack.shape[2]
+        # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts
+        self.toep = toep_weights(w, transpose, keep) if self.k in (5, 9) and self.cout <= 4 else None
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 
@@ -262,11 +293,26 @@ def _group_fields(d, n, group, wpack, bias):
     return g * n
 
 
+def toep_grid_ok(images, h, w):
+    """training launches: enough 16 x 256 tiles for the persistent grid of ``risp_conv2d_toep`` (else the vector-FMA kernel with
+    its input-channel split fills the chip better)"""
+    return images * ((h + 15) // 16) * ((w + 255) // 256) >= TOEP_MIN_TILES
+
+
+def _toep_ok(sc, h, w):
+    return CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
+
+
+TOEP_MIN_TILES = int(os.environ.get('RISP_TOEP_MIN_TILES', '256'))
+
+
 def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False, out=None, group=None, split=None):
     """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 12).  ``infer``: never split the input
     channels over workgroups - the split depends on the grid, and an inference result must not depend on the batch a
     tile travels in (test_split.py batches tiles).  ``group``: see ``_group_fields``; ``split``: force the channel split
-    (the per-member form of a grouped launch uses the split the grouped grid would take)."""
+    (the per-member form of a grouped launch uses the split the grouped grid would take; 0 = the Toeplitz-band kernel).
+    5- and 9-tap layers with at most 4 couts run on ``risp_conv2d_toep`` (f16 matrix pipe, split precision) when the grid is
+    large enough - always for inference, so that a tile's result does not depend on the batch - unless RISP_CONV_ARITH=f32."""
     if sc.bias is None:
         epi |= EPI_NOBIAS
     nn_ = n * (group[0] if group else 1)
@@ -276,6 +322,13 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
+    toep = getattr(sc, 'toep', None)
+    if _toep_ok(sc, h, w) and mask is None and (infer or (split == 0 if split is not None else toep_grid_ok(nn_, h, w))):
+        # the f16 matrix pipe (Toeplitz bands of the filter rows as the A operand): 2.5-3 x the vector-FMA kernel on full grids
+        d.wpack = _p(toep)
+        _group_fields(d, n, group, toep, sc.bias)
+        L.call('risp_conv2d_toep', C.byref(d), _stream())
+        return out
     _group_fields(d, n, group, sc.wpack, sc.bias)
     groups = 1 if infer else (split if split is not None else L.load().risp_conv_small_groups(C.byref(d)))
     if groups > 1:                                  # small grid: split the input channels over several workgroups per tile
@@ -716,7 +769,7 @@ def stack_packed(pcs):
 
 
 def stack_small(scs):
-    return _Stacked(scs, ('wpack', 'bias'), ('cin', 'cout', 'k'))
+    return _Stacked(scs, ('wpack', 'bias', 'toep'), ('cin', 'cout', 'k'))
 
 
 def _stack_grads(gys, like):
@@ -848,7 +901,10 @@ class _SrcnnResGroupFn(torch.autograd.Function):
 
 
 def _small_split(x, sc, n_total, h, w, epi, add_c):
-    """the channel split ``conv_small`` would take for the grouped launch (so that the per-member form uses the same)"""
+    """the channel split ``conv_small`` would take for the grouped launch (so that the per-member form uses the same); 0 = the
+    grouped launch runs on ``risp_conv2d_toep``"""
+    if _toep_ok(sc, h, w) and toep_grid_ok(n_total, h, w):
+        return 0
     d = L.ConvDesc(N=n_total, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=None, cvals=None, add=None, mask=None, y=None)
     return L.load().risp_conv_small_groups(C.byref(d))

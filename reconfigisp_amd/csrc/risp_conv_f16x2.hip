@@ -33,24 +33,7 @@
 // PERSISTENT workgroups, 2 per CU, each walks tiles id, id + gridDim.x, ...: a tile's stores are never waited for (they drain
 // while the next tile is staged), and nothing runs in chip-wide lockstep rounds.  Consecutive workgroup ids sit on different
 // XCDs (8 L2s): XCD k takes the k-th contiguous eighth of each sweep, so that tiles sharing halo rows share an L2.
-#include "risp_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// Buffer addressing (a 128-bit resource in scalar registers + one 32-bit byte offset per lane + a scalar byte offset): a tensor
-// plane costs a scalar add instead of a 64-bit address pair per lane and access.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t h2_rsrc(const void *base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ float4 h2_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ float h2_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
+#include "risp_f16x2.h"
 
 namespace {
 constexpr int H2_TH = 8, H2_TW = 64, H2_S = 17, H2_RS = 4 * H2_S, H2_CK = 16;
@@ -87,25 +70,6 @@ __device__ __forceinline__ void split8(const float (&a)[8], float s, uint4 &hi, 
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// largest of a wave's non-negative values, in every lane: butterflies inside the rows of 16 by DPP, then the four rows by
-// readlane (non-negative floats order like their bit patterns) - the shuffle form (six ds_bpermute round trips) sat on every
-// chunk's critical path
-__device__ __forceinline__ float h2_wave_max(float v) {
-    int x = __builtin_bit_cast(int, v);
-    x = max(x, __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
-    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
-    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true));     // row_half_mirror
-    x = max(x, __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true));     // row_mirror
-    const int r = max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)),
-                      max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
-    return __builtin_bit_cast(float, r);
-}
-
-__device__ __forceinline__ float amax4(float m, const float4 &v) {
-    return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
-}
-
-#define H2_WAIT_VM(keep) __builtin_amdgcn_s_waitcnt(0x0F70 | ((keep) & 15) | (((keep) >> 4) << 14))      /* s_waitcnt vmcnt(keep) */
 #ifdef RISP_H2_STAMPS
 #define H2STAMP(v) do { __builtin_amdgcn_s_waitcnt(0xC07F); v = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -570,15 +534,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
         o[7] = hwid | ((unsigned long long)xcc << 32);
     }
 #endif
-}
-
-inline int h2_cu_count() {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    return cus;
 }
 
 #ifndef RISP_H2_WGS

@@ -1,0 +1,216 @@
+"""GPU parity of ``risp_conv2d_toep`` (reconfigisp_amd/csrc/risp_conv_toep.hip) through the C ABI: the small-cout layers with 5-
+and 9-tap rows on the f16 matrix pipe, rows of the matrix instruction = (cout, position inside a block of 8 pixels), reduction
+index = a window of 16 input pixels (a Toeplitz band of the filter row as the A operand), split precision as in
+``risp_conv2d_f16x2``.  Against the float64 convolution next to the vector-FMA kernel ``risp_conv2d_small`` it replaces, every
+epilogue, grouped launches, ragged shapes, gradient-sized inputs, and the dispatch in ``convnets.conv_small``.
+Layers: srcnn_res_arch.py:18 (backward-data, 64 -> 3), :22 (5x5 32 -> 3); srcnn_demosaic_arch.py:14-16 (backward-data through
+PixelShuffle, 64 -> 4)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.standard_normal(shape).astype(np.float32)).cuda()
+
+
+def launch(entry, x, pack, bias, n, h, w, cin, cout, k, epi=0, add=None, add_c=0, group=None, out=None):
+    """one launch through the C ABI; ``group`` = (G, flags, stacked bias or None): ``pack`` then holds the G members' packs"""
+    from reconfigisp_amd import lib as L
+    G = group[0] if group else 1
+    shape = (G * n, cout // 4, 2 * h, 2 * w) if epi & 8 else (G * n, cout, h, w)
+    y = torch.full(shape, float('nan'), device='cuda') if out is None else out
+    d = L.ConvDesc(N=G * n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=0, cin_img=0, epilogue=epi | (0 if bias is not None else 16),
+                   add_c=add_c, x=x.data_ptr(), wpack=pack.data_ptr(), bias=bias.data_ptr() if bias is not None else None, cvals=None,
+                   add=add.data_ptr() if add is not None else None, mask=None, y=y.data_ptr())
+    if group:
+        d.group_n, d.group_flags = n, group[1]
+        d.wpack_gs = pack.stride(0) * pack.element_size() // 4
+        d.bias_gs = bias.stride(0) if bias is not None else 0
+    L.call(entry, C.byref(d), None)
+    torch.cuda.synchronize()
+    return y
+
+
+def err(y, ref):
+    m = ref.abs().max().item() or 1.0
+    e = y.double() - ref
+    return e.pow(2).mean().sqrt().item() / m, e.abs().max().item() / m
+
+
+SHAPES = [(1, 16, 256), (2, 37, 64), (3, 16, 260), (1, 5, 8), (2, 50, 512), (1, 33, 4), (5, 20, 132)]
+
+
+@pytest.mark.parametrize('k,cin,cout', [(9, 64, 3), (5, 32, 3), (9, 64, 4), (5, 7, 1), (9, 3, 2)])
+@pytest.mark.parametrize('nhw', SHAPES)
+def test_forward_against_float64_next_to_the_vector_kernel(k, cin, cout, nhw):
+    from reconfigisp_amd import convnets as CN
+    n, h, w = nhw
+    wt, b = rnd(cout, cin, k, k, seed=1) * 0.05, rnd(cout, seed=2) * 0.1
+    x = rnd(n, cin, h, w, seed=3)
+    ref = TF.conv2d(x.double(), wt.double(), b.double(), padding=k // 2)
+    y = launch('risp_conv2d_toep', x, CN.toep_weights(wt), b, n, h, w, cin, cout, k)
+    sc = CN.SmallConv(wt, b)
+    y32 = launch('risp_conv2d_small', x, sc.wpack, b, n, h, w, cin, cout, k)
+    (rms, mx), (rms32, mx32) = err(y, ref), err(y32, ref)
+    assert not torch.isnan(y).any()
+    # fp32-level accuracy: no worse than the fp32 vector-FMA kernel on the same data (slack for the tiny shapes), far inside 1e-4
+    assert rms <= 1.25 * rms32 + 1e-9 and mx <= 2.0 * mx32 + 1e-8, (rms, rms32, mx, mx32)
+    assert mx < 5e-6
+
+
+@pytest.mark.parametrize('nhw', [(2, 16, 256), (3, 13, 68), (1, 40, 300)])
+def test_epilogues_and_the_backward_data_packs(nhw):
+    from reconfigisp_amd import convnets as CN
+    n, h, w = nhw
+    E = CN
+    # SRCNNRes tail: 5x5 32 -> 3 with bias + residual of 3 channels
+    wt, b = rnd(3, 32, 5, 5, seed=5) * 0.05, rnd(3, seed=6) * 0.1
+    x, add = rnd(n, 32, h, w, seed=7), rnd(n, 3, h, w, seed=8)
+    lin = TF.conv2d(x.double(), wt.double(), b.double(), padding=2)
+    p = CN.toep_weights(wt)
+    for what, epi, a, ref in (('plain', 0, None, lin), ('relu', E.EPI_RELU, None, torch.relu(lin)), ('add', E.EPI_ADD, add, lin + add.double()),
+                              ('add+relu', E.EPI_ADD | E.EPI_RELU, add, torch.relu(lin + add.double()))):
+        y = launch('risp_conv2d_toep', x, p, b, n, h, w, 32, 3, 5, epi, a, 3 if a is not None else 0)
+        assert err(y, ref)[1] < 3e-6, what
+    # a residual narrower than the layer: only the first add_c couts take it
+    wt4 = rnd(4, 8, 5, 5, seed=9) * 0.05
+    x8, add2 = rnd(n, 8, h, w, seed=10), rnd(n, 2, h, w, seed=11)
+    ref = TF.conv2d(x8.double(), wt4.double(), padding=2)
+    ref[:, :2] += add2.double()
+    y = launch('risp_conv2d_toep', x8, CN.toep_weights(wt4), None, n, h, w, 8, 4, 5, E.EPI_ADD, add2, 2)
+    assert err(y, ref)[1] < 3e-6
+    # SRCNNRes first layer, backward-data restricted to the image channels: forward weight (64, 12, 9, 9), gradient (n, 64, h, w)
+    w1 = rnd(64, 12, 9, 9, seed=12) * 0.05
+    g, gy = rnd(n, 64, h, w, seed=13) * 1e-4, rnd(n, 3, h, w, seed=14) * 1e-4
+    ref = TF.conv_transpose2d(g.double(), w1[:, :3].double(), padding=4) + gy.double()
+    y = launch('risp_conv2d_toep', g, CN.toep_weights(w1, True, 3), None, n, h, w, 64, 3, 9, E.EPI_ADD, gy, 3)
+    assert err(y, ref)[1] < 5e-6
+    # SRCNNDemosaic first layer, backward-data through PixelShuffle: forward weight (64, 4, 9, 9) on the unshuffled mosaic
+    w1 = rnd(64, 4, 9, 9, seed=15) * 0.05
+    ref = TF.pixel_shuffle(TF.conv_transpose2d(g.double(), w1.double(), padding=4), 2)
+    y = launch('risp_conv2d_toep', g, CN.toep_weights(w1, True, 4), None, n, h, w, 64, 4, 9, E.EPI_SHUFFLE2)
+    assert y.shape == (n, 1, 2 * h, 2 * w) and err(y, ref)[1] < 5e-6
+    bias4 = rnd(4, seed=16) * 1e-4
+    ref = TF.pixel_shuffle(TF.conv_transpose2d(g.double(), w1.double(), padding=4) + bias4.double().view(1, 4, 1, 1), 2)
+    y = launch('risp_conv2d_toep', g, CN.toep_weights(w1, True, 4), bias4, n, h, w, 64, 4, 9, E.EPI_SHUFFLE2)
+    assert err(y, ref)[1] < 5e-6
+
+
+@pytest.mark.parametrize('scale', [1e-8, 1e-5, 1.0, 3e4])
+def test_accuracy_does_not_depend_on_the_magnitude_of_the_input(scale):
+    from reconfigisp_amd import convnets as CN
+    n, h, w = 2, 24, 256
+    w1 = rnd(64, 3, 9, 9, seed=21) * 0.05
+    g = rnd(n, 64, h, w, seed=22) * scale * (rnd(n, 64, h, w, seed=23) > 0)
+    ref = TF.conv_transpose2d(g.double(), w1.double(), padding=4)
+    y = launch('risp_conv2d_toep', g, CN.toep_weights(w1, True, 3), None, n, h, w, 64, 3, 9)
+    rms, mx = err(y, ref)
+    assert rms < 3e-7 and mx < 4e-6, (scale, rms, mx)
+
+
+def test_channels_of_very_different_magnitude_zeros_and_nan_locality():
+    """the scale is taken per input channel and tile: channels of magnitude 1e-6 and 1e3 in one layer, a channel of zeros; a NaN
+    poisons the outputs whose windows contain it - and, through the tile's maximum, nothing outside its own tile"""
+    from reconfigisp_amd import convnets as CN
+    n, h, w, c = 1, 48, 512, 16
+    wt = rnd(3, c, 5, 5, seed=31) * 0.05
+    x = rnd(n, c, h, w, seed=32)
+    x[:, :4] *= 1e-6
+    x[:, 8:12] *= 1e3
+    x[:, 12:] = 0
+    ref = TF.conv2d(x.double(), wt.double(), padding=2)
+    y = launch('risp_conv2d_toep', x, CN.toep_weights(wt), None, n, h, w, c, 3, 5)
+    assert err(y, ref)[1] < 3e-6
+    z = launch('risp_conv2d_toep', torch.zeros_like(x), CN.toep_weights(wt), None, n, h, w, c, 3, 5)
+    assert (z == 0).all()
+    x[0, 5, 20, 300] = float('nan')                          # tile rows 16-31, columns 256-511
+    y2 = launch('risp_conv2d_toep', x, CN.toep_weights(wt), None, n, h, w, c, 3, 5)
+    bad = torch.isnan(y2[0]).any(0)
+    assert bad[18:23, 298:303].all()
+    bad[16:32, 256:] = False                                  # the NaN's own tile may be poisoned through its maximum
+    assert not bad.any()
+    keep = torch.ones(h, w, dtype=torch.bool, device='cuda')
+    keep[16:32, 256:] = False
+    assert torch.equal(y2[0][:, keep], y[0][:, keep])
+
+
+def test_grouped_launch_equals_the_members_bit_for_bit_and_runs_are_repeatable():
+    from reconfigisp_amd import convnets as CN, lib as L
+    n, h, w, G = 2, 40, 260, 3
+    ws = [rnd(64, 12, 9, 9, seed=40 + g) * 0.05 * (g + 1) for g in range(G)]
+    packs = torch.stack([CN.toep_weights(wg, True, 3) for wg in ws])
+    g1 = rnd(G * n, 64, h, w, seed=44) * 1e-3
+    gy = rnd(G * n, 3, h, w, seed=45) * 1e-3
+    y = launch('risp_conv2d_toep', g1, packs, None, n, h, w, 64, 3, 9, CN.EPI_ADD, gy, 3, group=(G, 0, None))
+    for g in range(G):
+        s = slice(g * n, (g + 1) * n)
+        ym = launch('risp_conv2d_toep', g1[s].contiguous(), packs[g], None, n, h, w, 64, 3, 9, CN.EPI_ADD, gy[s].contiguous(), 3)
+        assert torch.equal(y[s], ym), g
+    assert torch.equal(y, launch('risp_conv2d_toep', g1, packs, None, n, h, w, 64, 3, 9, CN.EPI_ADD, gy, 3, group=(G, 0, None)))
+    # forward tails sharing the residual operand (SHARED_ADD) and with per-member bias
+    wt = [rnd(3, 32, 5, 5, seed=50 + g) * 0.05 for g in range(G)]
+    bs = torch.stack([rnd(3, seed=60 + g) * 0.1 for g in range(G)])
+    packs = torch.stack([CN.toep_weights(t) for t in wt])
+    t2, x = rnd(G * n, 32, h, w, seed=70), rnd(n, 3, h, w, seed=71)
+    y = launch('risp_conv2d_toep', t2, packs, bs, n, h, w, 32, 3, 5, CN.EPI_ADD, x, 3, group=(G, L.GROUP_SHARED_ADD, bs))
+    for g in range(G):
+        s = slice(g * n, (g + 1) * n)
+        ym = launch('risp_conv2d_toep', t2[s].contiguous(), packs[g], bs[g], n, h, w, 32, 3, 5, CN.EPI_ADD, x, 3)
+        assert torch.equal(y[s], ym), g
+    # an image's result does not depend on the batch it travels in
+    one = launch('risp_conv2d_toep', t2[3:4].contiguous(), packs[1], bs[1], 1, h, w, 32, 3, 5, CN.EPI_ADD, x[1:2].contiguous(), 3)
+    assert torch.equal(one, y[3:4])
+
+
+def test_arguments_outside_the_kernel_are_refused():
+    from reconfigisp_amd import convnets as CN, lib as L
+    x = rnd(1, 8, 16, 64, seed=80)
+    p = CN.toep_weights(rnd(3, 8, 5, 5, seed=81))
+    cases = [dict(cout=5), dict(k=3), dict(k=7), dict(w=62), dict(epi=4), dict(epi=8), dict(epi=2)]      # mask; shuffle with cout 3; add without tensor
+    for c in cases:
+        kw = dict(cout=3, k=5, w=64, epi=0)
+        kw.update(c)
+        with pytest.raises(RuntimeError, match='risp_conv2d_toep'):
+            launch('risp_conv2d_toep', x, p, None, 1, 16, kw['w'], 8, kw['cout'], kw['k'], kw['epi'])
+    assert L.load().risp_conv_toep_wpack_bytes(8, 3, 5) == p.numel() * 2
+
+
+def test_conv_small_dispatch(monkeypatch):
+    """``convnets.conv_small`` takes the matrix-pipe kernel for inference and for training grids that fill the chip, the vector
+    kernel otherwise and under RISP_CONV_ARITH=f32; the per-member form of a grouped layer follows the grouped decision"""
+    from reconfigisp_amd import convnets as CN, lib as L
+    calls = []
+    real = L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    monkeypatch.setattr(CN.L, 'call', spy)
+    wt, b = rnd(3, 32, 5, 5, seed=90) * 0.05, rnd(3, seed=91) * 0.1
+    sc = CN.SmallConv(wt, b)
+    x = rnd(2, 32, 32, 64, seed=92)
+    ref = TF.conv2d(x.double(), wt.double(), b.double(), padding=2)
+
+    def last():
+        return [c for c in calls if c.startswith('risp_conv2d')][-1]
+    y = CN.conv_small(x, sc, 2, 32, 64)                       # 4 tiles: the vector kernel (with its channel split)
+    assert last().startswith('risp_conv2d_small') and err(y, ref)[1] < 3e-6
+    y = CN.conv_small(x, sc, 2, 32, 64, infer=True)           # inference: always the same kernel, whatever the batch
+    assert last() == 'risp_conv2d_toep' and err(y, ref)[1] < 3e-6
+    monkeypatch.setattr(CN, 'TOEP_MIN_TILES', 4)
+    y = CN.conv_small(x, sc, 2, 32, 64)
+    assert last() == 'risp_conv2d_toep' and err(y, ref)[1] < 3e-6
+    assert CN._small_split(x, sc, 2, 32, 64, 0, 0) == 0
+    y = CN.conv_small(x, sc, 2, 32, 64, mask=torch.ones_like(ref, dtype=torch.float32), epi=CN.EPI_MASK)
+    assert last().startswith('risp_conv2d_small')              # epilogues the kernel does not have stay where they were
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
+    y = CN.conv_small(x, sc, 2, 32, 64, infer=True)
+    assert last().startswith('risp_conv2d_small') and err(y, ref)[1] < 3e-6
+    assert CN._small_split(x, sc, 2, 32, 64, 0, 0) != 0
