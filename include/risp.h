@@ -326,6 +326,16 @@ int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
 size_t risp_conv_toep_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_toep(const risp_conv_desc *d, void *stream);
 
+/* ... and for the 9x9 FIRST layers (few input channels, 64 couts: SRCNNRes 3 -> 64 with its broadcast planes folded out,
+ * srcnn_res_arch.py:18, 41-46; SRCNNDemosaic 4 -> 64 on the mosaic, srcnn_demosaic_arch.py:14-16, 39-43 - what risp_conv2d_k3
+ * does on the fp32 matrix pipe): rows = 32 couts, one accumulator per pixel position j of a block of 8, the 8 A operands are
+ * windows of one zero-padded filter row per lane.  wpack: risp_conv_toep_first_wpack_bytes() bytes, 16-byte aligned: a 16-byte
+ * header whose first float is 1 / s_w, then [cout block of 32][cin][ky][part: hi, lo][taps 0-7 | tap 8 and 7 zeros][cout][8] _Float16
+ * (reconfigisp_amd/convnets.py::toep_first_weights).  ksize 9, cin <= 16, W % 4 == 0, 16-byte aligned tensors; load_mode PLAIN, or
+ * UNSHUFFLE2 with cin == 4 (x = the (N,1,2H,2W) mosaic); epilogue RELU | NOBIAS | CASEBIAS; grouped launches. */
+size_t risp_conv_toep_first_wpack_bytes(int cin, int cout);
+int risp_conv2d_toep_first(const risp_conv_desc *d, void *stream);
+
 /* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */

@@ -164,6 +164,29 @@ def toep_weights(w, transpose=False, keep=None):
     return torch.cat([hdr.view(torch.float16), band.reshape(-1)])
 
 
+def toep_first_weights(w):
+    """Pre-split pack of ``risp_conv2d_toep_first`` (include/risp.h) from a 9x9 first layer's (cout, cin <= 16, 9, 9) tensor: a
+    16-byte header whose first float is 1 / s_w, then [cout block of 32][cin][ky][part: hi, lo][taps 0-7 | tap 8 and 7 zeros][cout][8]
+    halves of w * s_w - per cout the filter row in two 16-byte slots, from which the kernel cuts its 8 shifted windows.  Scale and
+    split as in ``f16x2_weights``.  Returns a float16 tensor."""
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    if k != 9 or ci > 16:
+        raise ValueError('first-layer band pack: a 9x9 layer with at most 16 input channels, got %dx%d with %d' % (k, k, ci))
+    nb = (co + 31) // 32
+    _, e = torch.frexp(w.detach().abs().max())
+    sw = torch.ldexp(torch.ones((), device=w.device), 15 - e)
+    ws = w.detach().float() * sw
+    hi = ws.half()
+    p = torch.zeros((2, nb * 32, ci, k, 16), device=w.device, dtype=torch.float16)
+    p[0, :co, :, :, :k] = hi
+    p[1, :co, :, :, :k] = (ws - hi.float()).half()
+    #       (part, block, cout, ci, ky, slot, 8) -> (block, ci, ky, part, slot, cout, 8)
+    p = p.view(2, nb, 32, ci, k, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).contiguous()
+    hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
+    hdr[0] = 1.0 / sw
+    return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
+
+
 WINO_F45 = os.environ.get('RISP_WINO_F45', '1') != '0'       # 5x5: F(4,5) where cin % 4 == 0 (default), else F(2,5)
 # Arithmetic of the wide hidden layers (3x3, cin % 16 == 0, cout 32 / 64): 'f16x2' (default) = split precision on the f16 matrix
 # pipe - each fp32 operand as two f16 halves, three products, fp32 accumulation (risp_conv2d_f16x2: fp32 tensors in and out,
@@ -251,6 +274,8 @@ class PackedConv:
             self.f16x2_bwd = f16x2_weights(w, True) if ok(self.cout, self.cin) else None
         # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
         self.k3 = k3_weights(w) if (self.k in (3, 9) and self.cin in (3, 4) and self.cout <= 64) else None
+        # ... and the 9x9 ones on the f16 matrix pipe in split precision (see CONV_ARITH), risp_conv_toep_first.hip
+        self.toep_first = toep_first_weights(w) if (self.k == 9 and self.cin in (3, 4)) else None
         if self.k == 3 and WINOGRAD:
             self.wino_fwd, self.wino_bwd, self.wino_entry = _wino3_pack(w, False), _wino3_pack(w, True), 'risp_conv2d_wino3'
             if WINO_F43:                              # inference forward and every backward-data pass (see conv())
@@ -407,6 +432,8 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
             and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
             and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS)) and (x.data_ptr() | out.data_ptr()) % 16 == 0):
         wpack, entry, use_wino = pc.k3, 'risp_conv2d_k3', True      # first layers: the linear-k kernel (risp_conv_k3.hip)
+        if CONV_ARITH == 'f16x2' and getattr(pc, 'toep_first', None) is not None and cin * h * w < (1 << 30):
+            wpack, entry = pc.toep_first, 'risp_conv2d_toep_first'  # 9x9: windows of the filter rows on the f16 matrix pipe
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wpack),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
@@ -415,6 +442,9 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     if entry == 'risp_conv2d_f16x2':
         if MFMA_ISSUED_F16 is not None:
             MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * pc.k * cin * cout * nn_ * h * w
+    elif entry == 'risp_conv2d_toep_first':
+        if MFMA_ISSUED_F16 is not None:                # 16 window slots per filter row (9 carry a tap), cout padded to 32
+            MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * 16 * cin * ((cout + 31) // 32 * 32) * nn_ * h * w
     elif MFMA_ISSUED is not None:
         MFMA_ISSUED[0] += _issued_flops(entry if use_wino else 'risp_conv2d', cin, cout, pc.k, nn_ * h * w)
     return out
@@ -764,7 +794,7 @@ class _Stacked:
 
 
 def stack_packed(pcs):
-    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd'),
+    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd', 'toep_first'),
                     ('cin', 'cout', 'k', 'wino_entry'))
 
 

@@ -107,6 +107,19 @@ __device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, vo
                  : "=&s"(keep_exec), "=&s"(keep_m0) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory");
 }
 
+// The lean form for the persistent convolution kernels: every lane copies, the LDS byte address is an integer the caller keeps in
+// scalar registers (lds_addr_of(base) once, scalar adds per piece).  The pointer form above converts a generic pointer per call
+// (readfirstlane pair, null check, select) and masks EXEC: ~20 dependent scalar instructions, 140 cycles per transfer measured in
+// risp_conv_toep.hip - 8 % of a tile where a stage is a handful of transfers.
+__device__ __forceinline__ unsigned lds_addr_of(const void *lds_ptr) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t *)lds_ptr);
+}
+__device__ __forceinline__ void lds_dma16_m(const void *sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
 // Workgroups per image of the element-wise BACKWARD kernels (stand-alone risp_*_bwd and the fused slot mixture share it, so
 // both cut an image into the same partial sums and give the same parameter-gradient bits): >= 4 vectors per thread so the
 // block reduction amortises, but enough workgroups for the chip when the batch is small (the per-GPU batch of the 8-GPU

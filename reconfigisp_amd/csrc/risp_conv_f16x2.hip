@@ -222,23 +222,24 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
     // 32 NT ncb couts of the layer: the lane offsets below pick this tile's cout block.
     constexpr int PW = C::PW, LOADS = 8 + 2 * P + 2 * NC2;           // vector-memory instructions of issue_weights / fetch
     const int row_slots = ncb * NT * 32;                             // pack slots per (kx, part, channel half) row
-    unsigned wvoff[PW];
-    int wpiece[PW];
+    unsigned wvoff[PW], wlds[PW];                                    // lane offset in the pack; LDS byte address in ring slot 0 (scalar)
+    const unsigned lds_wl = lds_addr_of(wl);
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
         // every wave issues PW instructions, so that the counted vmcnt waits are the same arithmetic for all of them: a wave
         // without a piece of its own repeats an earlier one (same bytes to the same place).  A transfer with EXEC = 0 is not
         // a substitute - it does not count in vmcnt, and the waves issuing it then waited for one transfer too few.
-        wpiece[p] = (wave + 4 * p) % (WST / 64);
-        const int L = wpiece[p] * 64 + lane, row = L / (NT * 32), col = L - row * (NT * 32);
+        const int piece = (wave + 4 * p) % (WST / 64);
+        const int L = piece * 64 + lane, row = L / (NT * 32), col = L - row * (NT * 32);
         wvoff[p] = 16u * (unsigned)(row * row_slots + col);
+        wlds[p] = lds_wl + 16u * (unsigned)(piece * 64);
     }
     int ring = 0;                                                    // ring slot of the stage being multiplied
     auto issue_weights = [&](int stage, int slot, const TileRef &r) {       // LDS-DMA of stage (chunk, ky) = stage / KS, stage % KS
-        uint4 *dst = wl + slot * WST;
         const uint4 *src = r.w + 1 + (size_t)stage * (KS * 4) * row_slots + r.cb * NT * 32;          // slot 0 of the pack = header
+        // (scalar LDS addresses: the pointer form of the transfer cost ~140 cycles of dependent scalar instructions each)
 #pragma unroll
-        for (int p = 0; p < PW; ++p) lds_dma16_s(src, wvoff[p], dst + wpiece[p] * 64);
+        for (int p = 0; p < PW; ++p) lds_dma16_m(src, wvoff[p], wlds[p] + (unsigned)slot * (WST * 16u));
     };
     auto ring_next = [&](int r, int k) { return r + k >= RING ? r + k - RING : r + k; };
 

@@ -99,18 +99,18 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
         for (int k = 0; k < NTASK; ++k) v[k] = h2_load16(rx, off[k], so);
     };
     // band pieces of 64 slots; every wave issues PW transfers (a wave without a piece of its own repeats an earlier one)
-    unsigned wvoff[PW];
-    int wpiece[PW];
+    unsigned wvoff[PW], wlds[PW];                                     // lane offset in the pack; LDS byte address in buffer 0 (scalar)
+    const unsigned lds_wl = lds_addr_of(wl);
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
-        wpiece[p] = (wave + 4 * p) % (WST / 64);
-        wvoff[p] = 16u * (unsigned)(wpiece[p] * 64 + lane);
+        const int piece = (wave + 4 * p) % (WST / 64);
+        wvoff[p] = 16u * (unsigned)(piece * 64 + lane);
+        wlds[p] = lds_wl + 16u * (unsigned)(piece * 64);
     }
     auto issue_bands = [&](int ci, int slot, const TileRef &r) {
-        uint4 *to = wl + slot * WST;
         const uint4 *src = r.w + 1 + (size_t)ci * WST;                 // slot 0 of the pack = header
 #pragma unroll
-        for (int p = 0; p < PW; ++p) lds_dma16_s(src, wvoff[p], to + wpiece[p] * 64);
+        for (int p = 0; p < PW; ++p) lds_dma16_m(src, wvoff[p], wlds[p] + (unsigned)slot * (WST * 16u));
     };
     // operands.  B: lane (b = lane & 31, half) of input row r reads slot b + half of that row (pixels 8 b - 4 + 8 half ..);
     // A: lane (m = lane & 31, half) reads row m, window half `half` of a band.
@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
             // the buffer every wave has left, the tile into registers
             if (ci + 1 < d.cin) {
                 issue_bands(ci + 1, ring ^ 1, cur);
+#ifdef RISP_TP_STAMPS
+                TPSTAMP(t_epi);                        // (diagnostic: the band transfers alone are booked on the epilogue's counter)
+#endif
                 fetch(ci + 1);
             } else if (more) {
                 issue_bands(0, ring ^ 1, nxt);

@@ -144,6 +144,8 @@ SIGNATURES = {
     'risp_conv2d_f16x2': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_toep_wpack_bytes': (_z, [_i, _i, _i]),
     'risp_conv2d_toep': (_i, [C.POINTER(ConvDesc), _s]),
+    'risp_conv_toep_first_wpack_bytes': (_z, [_i, _i]),
+    'risp_conv2d_toep_first': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wgrad_scratch_floats': (_z, [_i]),
     'risp_conv2d_wgrad': (_i, [C.POINTER(ConvDesc), _f, _f, _f, _s]),
     'risp_plane_sums': (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),

@@ -80,5 +80,55 @@ def main():
         print(line, flush=True)
 
 
+def border_case(v, L, P=4):
+    return v if v < P else (2 * P - (L - 1 - v) if v >= L - P else P)
+
+
+def first_layers():
+    """the 9x9 first layers: risp_conv2d_toep_first against risp_conv2d_k3 (fp32 matrix pipe)"""
+    n, hw, G = int(os.environ.get('RISP_AB_N', 32)), int(os.environ.get('RISP_AB_HW', 256)), int(os.environ.get('RISP_AB_G', 1))
+    gen = torch.Generator('cuda').manual_seed(2)
+    for name, cin, load in (('9x9 3->64 + case table + ReLU', 3, CN.LOAD_PLAIN), ('9x9 4->64 on the mosaic + ReLU', 4, CN.LOAD_UNSHUFFLE2)):
+        ws = [torch.randn(64, cin, 9, 9, device='cuda', generator=gen) * 0.05 for _ in range(G)]
+        bs = [torch.randn(64, device='cuda', generator=gen) * 0.1 for _ in range(G)]
+
+        class M:
+            pass
+        pcs = []
+        for w, b in zip(ws, bs):
+            pcs.append(CN.PackedConv(w, b))
+        pc = CN.stack_packed(pcs) if G > 1 else pcs[0]
+        group = (G, CN.L.GROUP_SHARED_X) if G > 1 else None
+        x = torch.rand((n, 1, 2 * hw, 2 * hw) if cin == 4 else (n, 3, hw, hw), device='cuda', generator=gen)
+        table = torch.randn(G * n, 64 * 81, device='cuda', generator=gen) * 0.1 if cin == 3 else None
+        epi = CN.EPI_RELU | (CN.EPI_CASEBIAS if cin == 3 else 0)
+
+        def run(arith):
+            CN.CONV_ARITH = arith
+            return CN.conv(x, pc, n, hw, hw, load=load, epi=epi, cvals=table, group=group)
+        ref = []
+        idx = torch.tensor([border_case(v, hw) for v in range(hw)], device='cuda')
+        for g, i in ((0, 0), (G - 1, n - 1)):
+            xi = x[i:i + 1].double()
+            if cin == 4:
+                xi = TF.pixel_unshuffle(xi, 2)
+            r = TF.conv2d(xi, ws[g].double(), bs[g].double(), padding=4)
+            if table is not None:
+                t = table[g * n + i].view(64, 9, 9).double()
+                r = r + t[:, idx][:, :, idx].unsqueeze(0)
+            ref.append((g * n + i, torch.relu(r)))
+        line = '%-40s N=%d x %d members %dx%d:' % (name, n, G, hw, hw)
+        for arith in ('f32', 'f16x2'):
+            y = run(arith)
+            m = max(r.abs().max().item() for _, r in ref)
+            e = torch.cat([(y[i:i + 1].double() - r).flatten() for i, r in ref])
+            us = timed(lambda: run(arith))
+            line += '  %s %8.1f us rms %.2e max %.2e' % (arith, us, e.pow(2).mean().sqrt().item() / m, e.abs().max().item() / m)
+        print(line, flush=True)
+
+
 if __name__ == '__main__':
-    main()
+    if os.environ.get('RISP_AB_FIRST', '1') != '0':
+        first_layers()
+    if os.environ.get('RISP_AB_SMALL', '1') != '0':
+        main()
