@@ -443,11 +443,13 @@ def test_random_layer_shapes(seed, monkeypatch):
 
 @pytest.mark.parametrize('hw', [(8, 8), (16, 32), (20, 36), (40, 72), (256, 256)])
 @pytest.mark.parametrize('cout', [64, 48])
-def test_linear_k_9x9_over_three_channels(cout, hw):
+def test_linear_k_9x9_over_three_channels(cout, hw, monkeypatch):
     """risp_conv2d_k3 (SRCNNRes' folded first layer, srcnn_res_arch.py:18): against PyTorch, with the border-case table
     and ReLU epilogue, ungrouped and as a grouped launch of three members on one shared input; and against the general
-    kernel (another summation order: float tolerance)."""
+    kernel (another summation order: float tolerance).  (RISP_CONV_ARITH=f32: by default the 9x9 first layers run on
+    risp_conv2d_toep_first - tests/test_gpu_toep.py.)"""
     from reconfigisp_amd import convnets as CN
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
     import ctypes as C
     from reconfigisp_amd import lib as L
     from reconfigisp_amd.functional import _p, _stream
@@ -503,11 +505,12 @@ def test_linear_k_9x9_over_three_channels(cout, hw):
 
 @pytest.mark.parametrize('hw', [(8, 8), (16, 32), (20, 36), (40, 72), (128, 128)])
 @pytest.mark.parametrize('k,cin,cout', [(3, 3, 64), (3, 4, 64), (9, 4, 64), (9, 4, 40), (3, 4, 24), (9, 3, 20)])
-def test_linear_k_first_layers(k, cin, cout, hw):
+def test_linear_k_first_layers(k, cin, cout, hw, monkeypatch):
     """risp_conv2d_k3 on every first-layer form (path_14l_bgr_arch.py:40-43, path_14l_bayer_arch.py:37-40 + :70-75,
     srcnn_demosaic_arch.py:14-16 + :39-43, srcnn_res_arch.py:18): 3 plain channels or the 4 planes of the space-to-depth
-    mosaic, bias + ReLU, against PyTorch; the launch really is the linear-k kernel."""
+    mosaic, bias + ReLU, against PyTorch; the launch really is the linear-k kernel (under RISP_CONV_ARITH=f32 for the 9x9 ones)."""
     from reconfigisp_amd import convnets as CN
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
     from reconfigisp_amd import lib as L
     h, w = hw
     n = 3

@@ -214,3 +214,123 @@ def test_conv_small_dispatch(monkeypatch):
     y = CN.conv_small(x, sc, 2, 32, 64, infer=True)
     assert last().startswith('risp_conv2d_small') and err(y, ref)[1] < 3e-6
     assert CN._small_split(x, sc, 2, 32, 64, 0, 0) != 0
+
+
+# --------------------------------------------------------------------------- the 9x9 first layers (risp_conv2d_toep_first)
+def border_case(v, L, P=4):
+    return v if v < P else (2 * P - (L - 1 - v) if v >= L - P else P)
+
+
+def first_launch(x, pack, bias, n, h, w, cin, cout, epi=0, table=None, load=0, group=None):
+    from reconfigisp_amd import lib as L
+    G = group[0] if group else 1
+    y = torch.full((G * n, cout, h, w), float('nan'), device='cuda')
+    d = L.ConvDesc(N=G * n, H=h, W=w, cin=cin, cout=cout, ksize=9, load_mode=load, cin_img=0, epilogue=epi | (0 if bias is not None else 16),
+                   add_c=0, x=x.data_ptr(), wpack=pack.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
+                   cvals=table.data_ptr() if table is not None else None, add=None, mask=None, y=y.data_ptr())
+    if group:
+        d.group_n, d.group_flags = n, group[1]
+        d.wpack_gs = pack.stride(0) * pack.element_size() // 4
+        d.bias_gs = bias.stride(0) if bias is not None else 0
+    L.call('risp_conv2d_toep_first', C.byref(d), None)
+    torch.cuda.synchronize()
+    return y
+
+
+def with_table(lin, table, h, w):
+    """lin (n, cout, h, w) float64 + table (n, cout, 9, 9) looked up by the border case of the row and of the column"""
+    iy = torch.tensor([border_case(v, h) for v in range(h)], device='cuda')
+    ix = torch.tensor([border_case(v, w) for v in range(w)], device='cuda')
+    return lin + table.double()[:, :, iy][:, :, :, ix]
+
+
+@pytest.mark.parametrize('cout', [64, 48, 20])
+@pytest.mark.parametrize('nhw', [(2, 8, 8), (1, 16, 32), (3, 20, 36), (2, 40, 72), (1, 64, 256), (2, 30, 260), (1, 9, 516)])
+def test_first_layer_three_channels_with_case_table_next_to_the_fp32_kernel(cout, nhw):
+    """SRCNNRes' folded first layer (srcnn_res_arch.py:18, 41-46): bias + border-case table + ReLU against float64, next to
+    risp_conv2d_k3 on the same data"""
+    from reconfigisp_amd import convnets as CN, lib as L
+    n, h, w = nhw
+    wt, b = rnd(cout, 3, 9, 9, seed=100) * 0.1, rnd(cout, seed=101) * 0.1
+    x, table = rnd(n, 3, h, w, seed=102), rnd(n, cout, 9, 9, seed=103) * 0.1
+    lin = TF.conv2d(x.double(), wt.double(), b.double(), padding=4)
+    pack = CN.toep_first_weights(wt)
+    assert L.load().risp_conv_toep_first_wpack_bytes(3, cout) == pack.numel() * 2
+    y = first_launch(x, pack, b, n, h, w, 3, cout)
+    assert err(y, lin)[1] < 3e-6
+    y = first_launch(x, pack, b, n, h, w, 3, cout, CN.EPI_RELU)
+    assert err(y, torch.relu(lin))[1] < 3e-6
+    ref = torch.relu(with_table(lin, table, h, w))
+    y = first_launch(x, pack, b, n, h, w, 3, cout, CN.EPI_RELU | CN.EPI_CASEBIAS, table)
+    pc = CN.PackedConv(wt, b)
+    y32 = torch.empty_like(y)
+    d = L.ConvDesc(N=n, H=h, W=w, cin=3, cout=cout, ksize=9, load_mode=0, cin_img=0, epilogue=CN.EPI_RELU | CN.EPI_CASEBIAS, add_c=0,
+                   x=x.data_ptr(), wpack=pc.k3.data_ptr(), bias=b.data_ptr(), cvals=table.data_ptr(), add=None, mask=None, y=y32.data_ptr())
+    L.call('risp_conv2d_k3', C.byref(d), None)
+    (rms, mx), (rms32, mx32) = err(y, ref), err(y32, ref)
+    assert rms <= 1.25 * rms32 + 1e-9 and mx <= 2.0 * mx32 + 1e-8, (rms, rms32, mx, mx32)
+    assert mx < 3e-6
+    y = first_launch(x, pack, None, n, h, w, 3, cout, CN.EPI_CASEBIAS, table)              # no bias, no ReLU
+    assert err(y, with_table(TF.conv2d(x.double(), wt.double(), padding=4), table, h, w))[1] < 3e-6
+
+
+@pytest.mark.parametrize('cout', [64, 40])
+@pytest.mark.parametrize('nhw', [(2, 8, 8), (3, 20, 36), (1, 128, 128), (2, 33, 260)])
+def test_first_layer_on_the_mosaic(cout, nhw):
+    """SRCNNDemosaic's first layer (srcnn_demosaic_arch.py:14-16, 39-43): the four planes are read out of the (N,1,2H,2W) mosaic"""
+    from reconfigisp_amd import convnets as CN
+    n, h, w = nhw
+    wt, b = rnd(cout, 4, 9, 9, seed=110) * 0.1, rnd(cout, seed=111) * 0.1
+    bay = rnd(n, 1, 2 * h, 2 * w, seed=112)
+    ref = torch.relu(TF.conv2d(TF.pixel_unshuffle(bay.double(), 2), wt.double(), b.double(), padding=4))
+    y = first_launch(bay, CN.toep_first_weights(wt), b, n, h, w, 4, cout, CN.EPI_RELU, load=CN.LOAD_UNSHUFFLE2)
+    assert not torch.isnan(y).any() and err(y, ref)[1] < 3e-6
+    planes = TF.pixel_unshuffle(bay, 2).contiguous()              # the same layer fed with the planes: same bits
+    assert torch.equal(y, first_launch(planes, CN.toep_first_weights(wt), b, n, h, w, 4, cout, CN.EPI_RELU))
+
+
+def test_first_layer_grouped_on_one_shared_input_and_small_inputs():
+    from reconfigisp_amd import convnets as CN, lib as L
+    n, h, w, G, cout = 2, 40, 72, 3, 64
+    ws = [rnd(cout, 3, 9, 9, seed=120 + g) * 0.1 * (g + 1) for g in range(G)]
+    bs = torch.stack([rnd(cout, seed=130 + g) * 0.1 for g in range(G)])
+    packs = torch.stack([CN.toep_first_weights(t) for t in ws])
+    x, table = rnd(n, 3, h, w, seed=140) * 1e-6, rnd(G * n, cout, 9, 9, seed=141) * 1e-7
+    epi = CN.EPI_RELU | CN.EPI_CASEBIAS
+    y = first_launch(x, packs, bs * 1e-7, n, h, w, 3, cout, epi, table, group=(G, L.GROUP_SHARED_X))
+    for g in range(G):
+        s = slice(g * n, (g + 1) * n)
+        ym = first_launch(x, packs[g], bs[g] * 1e-7, n, h, w, 3, cout, epi, table[s].contiguous())
+        assert torch.equal(y[s], ym), g
+        ref = torch.relu(with_table(TF.conv2d(x.double(), ws[g].double(), (bs[g] * 1e-7).double(), padding=4), table[s], h, w))
+        assert err(ym, ref)[1] < 3e-6                              # inputs of magnitude 1e-6: the scale is the tile's own
+    assert torch.equal(y, first_launch(x, packs, bs * 1e-7, n, h, w, 3, cout, epi, table, group=(G, L.GROUP_SHARED_X)))
+    with pytest.raises(RuntimeError, match='risp_conv2d_toep_first'):
+        first_launch(x, packs[0], bs[0], n, h, 70, 3, cout)                                 # W % 4
+    with pytest.raises(RuntimeError, match='risp_conv2d_toep_first'):
+        first_launch(x, packs[0], bs[0], n, h, w, 3, cout, CN.EPI_CASEBIAS)                # table missing
+    with pytest.raises(RuntimeError, match='risp_conv2d_toep_first'):
+        first_launch(x, packs[0], bs[0], n, h, w, 3, cout, CN.EPI_ADD)
+
+
+def test_first_layer_dispatch(monkeypatch):
+    """``convnets.conv`` sends the 9x9 first layers to risp_conv2d_toep_first, the 3x3 ones and RISP_CONV_ARITH=f32 to risp_conv2d_k3"""
+    from reconfigisp_amd import convnets as CN, lib as L
+    calls = []
+    real = L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    n, h, w = 2, 24, 40
+    x = rnd(n, 3, h, w, seed=150)
+    pc9, pc3 = CN.PackedConv(rnd(64, 3, 9, 9, seed=151) * 0.1, rnd(64, seed=152)), CN.PackedConv(rnd(64, 3, 3, 3, seed=153) * 0.1, rnd(64, seed=154))
+    monkeypatch.setattr(CN.L, 'call', spy)
+    y = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)
+    assert calls[-1] == 'risp_conv2d_toep_first'
+    CN.conv(x, pc3, n, h, w, epi=CN.EPI_RELU)
+    assert calls[-1] == 'risp_conv2d_k3'
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
+    y32 = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)
+    assert calls[-1] == 'risp_conv2d_k3'
+    assert (y - y32).abs().max().item() < 1e-5 * y32.abs().max().item()
