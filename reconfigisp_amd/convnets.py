@@ -325,9 +325,19 @@ def toep_grid_ok(images, h, w):
 
 
 def _toep_ok(sc, h, w):
-    return CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
+    return TOEP and CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
 
 
+# A/B switches of the two Toeplitz-band kernels (default on; RISP_CONV_ARITH=f32 switches both off as well)
+TOEP = os.environ.get('RISP_CONV_TOEP', '1') != '0'              # risp_conv2d_toep: 5- / 9-tap layers with at most 4 couts
+# risp_conv2d_toep_first (9x9 first layers): '1' (default) = inference launches, 'train' = training forwards too, '0' = never.
+# Training stays on the fp32 kernel by default because of ONE activation of the DARTS golden scenario (tests/golden/darts_step.npz;
+# tools/dbg_flips.py): its pre-activation is 1.5e-8 of the layer's magnitude - below what fp32 resolves - and the two kernels,
+# equally exact against float64 (tests/test_gpu_toep.py), round it to opposite sides of the ReLU; that one mask bit moves an alpha
+# gradient by 3e-5 and, through Adam's normalised first step, iteration 1 by 9e-4 - past the 1e-4 bar of the golden comparison.
+TOEP_FIRST = os.environ.get('RISP_CONV_TOEP_FIRST', '1')
+if TOEP_FIRST not in ('0', '1', 'train'):
+    raise ValueError("RISP_CONV_TOEP_FIRST must be '0', '1' or 'train', got %r" % TOEP_FIRST)
 TOEP_MIN_TILES = int(os.environ.get('RISP_TOEP_MIN_TILES', '256'))
 
 
@@ -432,7 +442,8 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
             and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
             and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS)) and (x.data_ptr() | out.data_ptr()) % 16 == 0):
         wpack, entry, use_wino = pc.k3, 'risp_conv2d_k3', True      # first layers: the linear-k kernel (risp_conv_k3.hip)
-        if CONV_ARITH == 'f16x2' and getattr(pc, 'toep_first', None) is not None and cin * h * w < (1 << 30):
+        if ((TOEP_FIRST == 'train' or (TOEP_FIRST == '1' and infer)) and CONV_ARITH == 'f16x2' and getattr(pc, 'toep_first', None) is not None
+                and cin * h * w < (1 << 30)):
             wpack, entry = pc.toep_first, 'risp_conv2d_toep_first'  # 9x9: windows of the filter rows on the f16 matrix pipe
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wpack),
@@ -631,7 +642,7 @@ class _SrcnnResFolded(torch.autograd.Function):
         table = torch.empty((n, fold.rcase.shape[1]), device=x.device, dtype=torch.float32)
         L.call('risp_srcnn_case_table', _p(stats), _p(pv), _p(fold.rcase), _p(table), n, P, h * w, fold.rcase.shape[1],
                _stream())                                                # (N, 64*81) border-case constants = cvals @ rcase
-        t1 = conv(x, fold.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table)
+        t1 = conv(x, fold.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table, infer=infer)
         t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
         y = conv_small(t2, fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, infer=infer)
         ctx.save_for_backward(t1, t2, arg)
@@ -725,7 +736,7 @@ class _SrcnnDemosaic(torch.autograd.Function):
         x = _dev(x, 'img')
         n, h, w = x.shape[0], x.shape[2] // 2, x.shape[3] // 2
         c1, c2, c3 = packs
-        t1 = conv(x, c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU)
+        t1 = conv(x, c1, n, h, w, load=LOAD_UNSHUFFLE2, epi=EPI_RELU, infer=infer)
         t2 = conv(t1, c2, n, h, w, epi=EPI_RELU)
         if getattr(c3, 'small', None) is not None:           # 5x5 32 -> 12 + PixelShuffle: direct small-cout kernel
             y = conv_small(t2, c3.small, n, h, w, epi=EPI_SHUFFLE2, infer=infer)

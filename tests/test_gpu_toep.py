@@ -326,11 +326,15 @@ def test_first_layer_dispatch(monkeypatch):
     x = rnd(n, 3, h, w, seed=150)
     pc9, pc3 = CN.PackedConv(rnd(64, 3, 9, 9, seed=151) * 0.1, rnd(64, seed=152)), CN.PackedConv(rnd(64, 3, 3, 3, seed=153) * 0.1, rnd(64, seed=154))
     monkeypatch.setattr(CN.L, 'call', spy)
-    y = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)
+    y = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU, infer=True)
     assert calls[-1] == 'risp_conv2d_toep_first'
-    CN.conv(x, pc3, n, h, w, epi=CN.EPI_RELU)
+    CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)                     # training forward: the fp32 kernel unless asked for (convnets.TOEP_FIRST)
+    assert calls[-1] == 'risp_conv2d_k3'
+    monkeypatch.setattr(CN, 'TOEP_FIRST', 'train')
+    assert torch.equal(y, CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)) and calls[-1] == 'risp_conv2d_toep_first'
+    CN.conv(x, pc3, n, h, w, epi=CN.EPI_RELU, infer=True)
     assert calls[-1] == 'risp_conv2d_k3'
     monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
-    y32 = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)
+    y32 = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU, infer=True)
     assert calls[-1] == 'risp_conv2d_k3'
     assert (y - y32).abs().max().item() < 1e-5 * y32.abs().max().item()
