@@ -363,6 +363,8 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
         d.wpack = _p(toep)
         _group_fields(d, n, group, toep, sc.bias)
         L.call('risp_conv2d_toep', C.byref(d), _stream())
+        if MFMA_ISSUED_F16 is not None:                # per (ci, ky) and block of 8 pixels: 3 products of 32 rows x 16 window slots
+            MFMA_ISSUED_F16[0] += 3 * 2.0 * 32 * 16 / 8 * sc.cin * sc.k * nn_ * h * w
         return out
     _group_fields(d, n, group, sc.wpack, sc.bias)
     groups = 1 if infer else (split if split is not None else L.load().risp_conv_small_groups(C.byref(d)))
