@@ -325,6 +325,12 @@ int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
  * epilogue RELU | ADD (add_c <= cout) | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout == 4; grouped launches. */
 size_t risp_conv_toep_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_toep(const risp_conv_desc *d, void *stream);
+/* The same launch also writing, per tile of 16 rows x 256 columns, the sum of every input channel over the tile's own pixels:
+ * psum [N][risp_conv_toep_tiles(H, W)][cin] floats.  risp_rect_sums_tiles (below, next to risp_rect_sums) finishes them into the
+ * rectangle sums of SRCNNRes' constant planes (srcnn_res_arch.py:41-46) from the border rows and columns alone - the 64-channel
+ * upstream gradient is read once, by the backward-data convolution. */
+int risp_conv_toep_tiles(int H, int W);
+int risp_conv2d_toep_sums(const risp_conv_desc *d, float *psum, void *stream);
 
 /* ... and for the 9x9 FIRST layers (few input channels, 64 couts: SRCNNRes 3 -> 64 with its broadcast planes folded out,
  * srcnn_res_arch.py:18, 41-46; SRCNNDemosaic 4 -> 64 on the mosaic, srcnn_demosaic_arch.py:14-16, 39-43 - what risp_conv2d_k3
@@ -340,6 +346,9 @@ int risp_conv2d_toep_first(const risp_conv_desc *d, void *stream);
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient
  * (d loss / d constant = sum_{co,tap} w[co][c][tap] * out[co][tap]).  k odd <= 9, H, W >= k/2. */
 int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksize, void *stream);
+/* out as risp_rect_sums with ksize 9, from psum [N][tiles][C] (risp_conv2d_toep_sums) and the 4 border rows / columns of the planes
+ * g (N,C,H,W); H, W >= 4, W % 4 == 0.  Another summation order than risp_rect_sums (agreement ~1e-6 of the plane's sum). */
+int risp_rect_sums_tiles(const float *g, const float *psum, float *out, int N, int C, int H, int W, int tiles, void *stream);
 /* ... and that product: gconst (N,C) = rs (N,M) @ wconst (M,C) (SRCNNRes: M = 64 * 81 rectangle sums per
  * image, C = 9+P constant planes, srcnn_res_arch.py:41-46).  Deterministic. */
 int risp_srcnn_const_grad(const float *rs, const float *wconst, float *gconst, int N, int M, int C, void *stream);

@@ -341,7 +341,7 @@ if TOEP_FIRST not in ('0', '1', 'train'):
 TOEP_MIN_TILES = int(os.environ.get('RISP_TOEP_MIN_TILES', '256'))
 
 
-def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False, out=None, group=None, split=None):
+def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False, out=None, group=None, split=None, tile_sums=None):
     """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 12).  ``infer``: never split the input
     channels over workgroups - the split depends on the grid, and an inference result must not depend on the batch a
     tile travels in (test_split.py batches tiles).  ``group``: see ``_group_fields``; ``split``: force the channel split
@@ -362,7 +362,12 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
         # the f16 matrix pipe (Toeplitz bands of the filter rows as the A operand): 2.5-3 x the vector-FMA kernel on full grids
         d.wpack = _p(toep)
         _group_fields(d, n, group, toep, sc.bias)
-        L.call('risp_conv2d_toep', C.byref(d), _stream())
+        if tile_sums is not None:                      # a list: receives the per-tile sums of the input planes (see rect_sums)
+            ps = torch.empty((nn_, L.load().risp_conv_toep_tiles(h, w), sc.cin), device=x.device, dtype=torch.float32)
+            L.call('risp_conv2d_toep_sums', C.byref(d), _p(ps), _stream())
+            tile_sums.append(ps)
+        else:
+            L.call('risp_conv2d_toep', C.byref(d), _stream())
         if MFMA_ISSUED_F16 is not None:                # per (ci, ky) and block of 8 pixels: 3 products of 32 rows x 16 window slots
             MFMA_ISSUED_F16[0] += 3 * 2.0 * 32 * 16 / 8 * sc.cin * sc.k * nn_ * h * w
         return out
@@ -374,6 +379,17 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
     else:
         L.call('risp_conv2d_small', C.byref(d), _stream())
     return out
+
+
+def rect_sums(g1, rs, images, planes, h, w, k, tile_sums):
+    """rs (images, planes * k * k) = the rectangle sums of the planes of g1 (include/risp.h: risp_rect_sums).  ``tile_sums``: what
+    ``conv_small(..., tile_sums=[])`` collected while the same planes went through the backward-data convolution - then only their
+    border rows and columns are read again (risp_rect_sums_tiles); empty or None: the whole planes (risp_rect_sums)."""
+    if tile_sums and k == 9:
+        ps = tile_sums[0]
+        L.call('risp_rect_sums_tiles', _p(g1), _p(ps), _p(rs), images, planes, h, w, ps.shape[1], _stream())
+    else:
+        L.call('risp_rect_sums', _p(g1), _p(rs), images * planes, h, w, k, _stream())
 
 
 # bench.py sets this to [0.0] to count the FLOPs the launches ISSUE on the matrix cores (diagnostic; None = off)
@@ -660,9 +676,10 @@ class _SrcnnResFolded(torch.autograd.Function):
         gy = _dev(gy, 'grad')
         g2 = conv(gy, c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2)
         g1 = conv(g2, c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1)
-        gx = conv_small(g1, fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3)     # image channels + residual path
+        ts = []
+        gx = conv_small(g1, fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3, tile_sums=ts)     # image channels + residual path
         rs = torch.empty((n, c1.cout * fold.k * fold.k), device=gy.device, dtype=torch.float32)
-        L.call('risp_rect_sums', _p(g1), _p(rs), n * c1.cout, h, w, fold.k, _stream())
+        rect_sums(g1, rs, n, c1.cout, h, w, fold.k, ts)
         gconst = torch.empty((n, 9 + P), device=gy.device, dtype=torch.float32)     # min, mean, max planes, then params
         L.call('risp_srcnn_const_grad', _p(rs), _p(fold.wconst), _p(gconst), n, rs.shape[1], 9 + P, _stream())
         row = gconst.shape[1]                                           # columns 0-2 / 3-5 / 6-8 of each row, read in place
@@ -909,6 +926,7 @@ class _SrcnnResGroupFn(torch.autograd.Function):
         # parameter gradients only and the slots below the first parametrised one have none: flags['skip_gx']); autograd
         # cannot tell a custom Function that - needs_input_grad is a property of the forward graph
         want_gx = not (ctx.flags is not None and ctx.flags.get('skip_gx'))
+        ts, tsm = [], []                                # per-tile plane sums out of the backward-data launch(es): see rect_sums
         if ctx.grouped and not want_gx:
             g2 = conv(gy, gp.c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2, group=(G, 0))
             g1 = conv(g2, gp.c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1, group=(G, 0))
@@ -917,7 +935,7 @@ class _SrcnnResGroupFn(torch.autograd.Function):
         elif ctx.grouped:
             g2 = conv(gy, gp.c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2, group=(G, 0))
             g1 = conv(g2, gp.c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1, group=(G, 0))
-            gxs = conv_small(g1, gp.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3, group=(G, 0))
+            gxs = conv_small(g1, gp.bwd_img, n, h, w, epi=EPI_ADD, add=gy, add_c=3, group=(G, 0), tile_sums=ts)
             _count(3)
         else:
             g2, g1 = torch.empty((G * n, 32, h, w), **dev), torch.empty((G * n, 64, h, w), **dev)
@@ -927,10 +945,12 @@ class _SrcnnResGroupFn(torch.autograd.Function):
                 s = slice(g * n, (g + 1) * n)
                 conv(gy[s], c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2[s], out=g2[s])
                 conv(g2[s], c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1[s], out=g1[s])
-                conv_small(g1[s], c1.fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy[s], add_c=3, out=gxs[s], split=split)
+                conv_small(g1[s], c1.fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy[s], add_c=3, out=gxs[s], split=split, tile_sums=tsm)
+            if tsm:
+                ts.append(torch.cat(tsm))
             _count(3 * G)
         rs = torch.empty((G * n, gp.M), **dev)
-        L.call('risp_rect_sums', _p(g1), _p(rs), G * n * 64, h, w, gp.k, _stream())
+        rect_sums(g1, rs, G * n, 64, h, w, gp.k, ts)
         row = 9 + max(gp.P)
         gconst = torch.empty((G * n, row), **dev)       # min, mean, max planes, then the members' parameters
         L.call('risp_srcnn_const_grad_group', _p(rs), C.byref(gp.desc(n, h * w)), _p(gconst), row, _stream())

@@ -347,6 +347,69 @@ __global__ __launch_bounds__(256) void rect_sums_kernel(const float *__restrict_
     if (tid < K * K) out[(size_t)blockIdx.x * K * K + tid] = sums[tid / K][tid % K];
 }
 
+// The same rectangle sums of a 9x9 layer from per-tile sums of the planes (risp_conv2d_toep_sums wrote them while it staged the
+// planes for the backward-data convolution) plus the 4 border rows and 4 border columns on each side - an eighth of the plane
+// instead of all of it:  S(dy, dx) = T - (dropped rows) - (dropped columns) + (dropped rows x dropped columns), where dy < 0 drops
+// the first -dy rows, dy > 0 the last dy, and the same for columns.  One workgroup per plane; every sum in a fixed order.
+__global__ __launch_bounds__(256) void rect_sums_tiles_kernel(const float *__restrict__ g, const float *__restrict__ psum,
+                                                              float *__restrict__ out, int C, int H, int W, int tiles) {
+    constexpr int P = 4, K = 9;
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float *gp = g + (size_t)plane * H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float part[4][9], tot[9], rowsum[8], corner[4][P][P];
+    float t = 0.f, cl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cl[k] = 0.f;
+    for (int i = tid; i < tiles; i += 256) t += psum[((size_t)n * tiles + i) * C + c];
+    for (int y = tid; y < H; y += 256) {                  // the 4 first and 4 last columns of every row
+        const float4 a = *reinterpret_cast<const float4 *>(gp + (size_t)y * W), b = *reinterpret_cast<const float4 *>(gp + (size_t)y * W + W - 4);
+        cl[0] += a.x; cl[1] += a.y; cl[2] += a.z; cl[3] += a.w;
+        cl[4] += b.x; cl[5] += b.y; cl[6] += b.z; cl[7] += b.w;
+    }
+    {                                                       // the 4 first and 4 last rows: 32 threads each
+        const int r = tid >> 5, y = r < P ? r : H - 2 * P + r;
+        float rs = 0.f;
+        for (int q = tid & 31; q < W / 4; q += 32) {
+            const float4 v = *reinterpret_cast<const float4 *>(gp + (size_t)y * W + 4 * q);
+            rs += (v.x + v.y) + (v.z + v.w);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) rs += __shfl_xor(rs, o);
+        if ((tid & 31) == 0) rowsum[r] = rs;
+    }
+    if (tid < 64) {                                         // the four 4 x 4 corners, element by element
+        const int q = tid >> 4, r = (tid >> 2) & 3, cc = tid & 3;
+        corner[q][r][cc] = gp[(size_t)((q & 2) ? H - P + r : r) * W + ((q & 1) ? W - P + cc : cc)];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        t += __shfl_xor(t, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cl[k] += __shfl_xor(cl[k], o);
+    }
+    if (lane == 0) {
+        part[wave][0] = t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part[wave][1 + k] = cl[k];
+    }
+    __syncthreads();
+    if (tid < 9) tot[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    __syncthreads();
+    if (tid < K * K) {
+        const int i = tid / K, j = tid - i * K, dy = i - P, dx = j - P;
+        const int nr = dy < 0 ? -dy : dy, nc = dx < 0 ? -dx : dx;           // dropped rows / columns
+        const int r0 = dy < 0 ? 0 : 2 * P - nr, c0 = dx < 0 ? 0 : 2 * P - nc;        // first dropped entry of rowsum[] / tot[1 ..]
+        float rd = 0.f, cd = 0.f, xd = 0.f;
+        for (int k = 0; k < nr; ++k) rd += rowsum[r0 + k];
+        for (int k = 0; k < nc; ++k) cd += tot[1 + c0 + k];
+        const int q = (dy > 0 ? 2 : 0) + (dx > 0 ? 1 : 0);
+        for (int a = 0; a < nr; ++a)
+            for (int b = 0; b < nc; ++b) xd += corner[q][(dy < 0 ? 0 : P - nr) + a][(dx < 0 ? 0 : P - nc) + b];
+        out[(size_t)plane * (K * K) + tid] = ((tot[0] - rd) - cd) + xd;
+    }
+}
+
 // gconst[n][c] = sum_j rs[n][j] * wconst[j][c]: the rectangle sums applied to the constant-plane weights (the backward
 // of the folded constants, C = 9 + P columns).  One workgroup per (image, column); every thread owns a fixed residue
 // class of j, the partial sums meet by wave shuffles and one LDS pass in a fixed order (deterministic).
@@ -503,6 +566,14 @@ int risp_rect_sums(const float *g, float *out, int planes, int H, int W, int ksi
     const size_t lds = sizeof(float) * (size_t)phases * W;
     hipLaunchKernelGGL(rect_sums_kernel, dim3(planes), dim3(256), lds, (hipStream_t)stream, g, out, H, W, ksize);
     RISP_LAUNCH_CHECK("risp_rect_sums");
+    return 0;
+}
+
+int risp_rect_sums_tiles(const float *g, const float *psum, float *out, int N, int C, int H, int W, int tiles, void *stream) {
+    RISP_CHECK_ARG(g && psum && out && N > 0 && C > 0 && tiles > 0 && H >= 4 && W >= 4 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0,
+                   "risp_rect_sums_tiles: bad arguments (9x9 windows: H, W >= 4, W %% 4 == 0, 16-byte aligned planes)");
+    hipLaunchKernelGGL(rect_sums_tiles_kernel, dim3((unsigned)((size_t)N * C)), dim3(256), 0, (hipStream_t)stream, g, psum, out, C, H, W, tiles);
+    RISP_LAUNCH_CHECK("risp_rect_sums_tiles");
     return 0;
 }
 

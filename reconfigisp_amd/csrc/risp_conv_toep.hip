@@ -39,7 +39,7 @@ struct TP {
 
 // SHUF: PixelShuffle(2) store (cout % 4 == 0).  HAS_ADD: y += add[:, :add_c].
 template <int KS, int NB, int T, bool HAS_ADD, bool SHUF>
-__global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ntiles) {
+__global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ntiles, float *__restrict__ psum) {
     using C = TP<KS, NB, T>;
     constexpr int P = C::P, IH = C::IH, RS = TP_RS, WST = C::WST, PW = C::PW, NTASK = C::NTASK;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -61,13 +61,15 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
     // code has no branches)
     auto task_id = [&](int k) { return tid + 256 * k < IH * TP_Q ? tid + 256 * k : tid + 256 * (k - 1); };
     static_assert((NTASK - 1) * 256 <= IH * TP_Q, "only the last task may be missing");
+    bool inner[NTASK];                                                 // the task's quad belongs to the tile itself (not to its halo)
 #pragma unroll
     for (int k = 0; k < NTASK; ++k) {
         const int id = task_id(k), row = id / TP_Q, q = id - row * TP_Q;
         dst[k] = (row * RS + (q >> 1)) * 16 + (q & 1) * 8;
+        inner[k] = tid + 256 * k < IH * TP_Q && row >= P && row < P + C::TH && q >= 1 && q <= TP_TW / 4;
     }
     struct TileRef {
-        int n, x0, y0;
+        int n, x0, y0, ti;                                                // image, corner, tile index inside the image
         const uint4 *w;
     };
     TileRef cur;
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
         r.n = q / tiles_y;
         r.x0 = tx * TP_TW;
         r.y0 = ty * C::TH;
+        r.ti = ty * tiles_x + tx;
         const int g = d.group_n > 0 ? r.n / d.group_n : 0;
         r.w = reinterpret_cast<const uint4 *>(d.wpack + (size_t)g * d.wpack_gs);
     };
@@ -153,8 +156,17 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
                 if (ok[k]) m = amax4(m, v[k]);
             m = h2_wave_max(m);
             if (lane == 0) red[wave] = m;
+            if (psum) {                                // the channel's sum over the tile's own pixels, in a fixed order (risp_rect_sums_tiles)
+                float sm = 0.f;
+#pragma unroll
+                for (int k = 0; k < NTASK; ++k)
+                    if (inner[k] && ok[k]) sm += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+                sm = h2_wave_sum(sm);
+                if (lane == 0) red[4 + wave] = sm;
+            }
             __syncthreads();                           // A: the maxima are visible; every wave has left the previous channel's tile and bands
             TPSTAMP(t_top);
+            if (psum && tid == 0) psum[((size_t)cur.n * (tiles_x * tiles_y) + cur.ti) * d.cin + ci] = (red[4] + red[5]) + (red[6] + red[7]);
             const float4 mx = *reinterpret_cast<const float4 *>(red);
             const float tmax = fmaxf(fmaxf(mx.x, mx.y), fmaxf(mx.z, mx.w));
             int eb = (int)(__builtin_bit_cast(unsigned, tmax) >> 23);
@@ -315,15 +327,12 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
 #endif
 }
 
-#ifndef RISP_TP_T5
-#define RISP_TP_T5 4         // output rows per wave of the 5-tap form
-#endif
 #ifndef RISP_TP_WGS
 #define RISP_TP_WGS 2        // persistent workgroups per CU
 #endif
 
 template <int KS, int NB, int T, bool HAS_ADD, bool SHUF>
-int launch_toep(const risp_conv_desc &d, void *stream) {
+int launch_toep(const risp_conv_desc &d, float *psum, void *stream) {
     using C = TP<KS, NB, T>;
     auto kern = &conv_toep_kernel<KS, NB, T, HAS_ADD, SHUF>;
     if (C::LDS_BYTES > 64 * 1024 &&
@@ -339,15 +348,15 @@ int launch_toep(const risp_conv_desc &d, void *stream) {
     }
     const int slots = RISP_TP_WGS * h2_cu_count();
     const int grid = ntiles < slots ? (int)ntiles : slots;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, (hipStream_t)stream, d, tx, ty, (int)ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, (hipStream_t)stream, d, tx, ty, (int)ntiles, psum);
     RISP_LAUNCH_CHECK("risp_conv2d_toep");
     return 0;
 }
 
 template <int KS, int NB, int T>
-int launch_toep_epi(const risp_conv_desc &d, void *stream) {
-    if (d.epilogue & RISP_EPI_SHUFFLE2) return launch_toep<KS, NB, T, false, true>(d, stream);
-    return (d.epilogue & RISP_EPI_ADD) ? launch_toep<KS, NB, T, true, false>(d, stream) : launch_toep<KS, NB, T, false, false>(d, stream);
+int launch_toep_epi(const risp_conv_desc &d, float *psum, void *stream) {
+    if (d.epilogue & RISP_EPI_SHUFFLE2) return launch_toep<KS, NB, T, false, true>(d, psum, stream);
+    return (d.epilogue & RISP_EPI_ADD) ? launch_toep<KS, NB, T, true, false>(d, psum, stream) : launch_toep<KS, NB, T, false, false>(d, psum, stream);
 }
 }  // namespace
 
@@ -358,7 +367,7 @@ size_t risp_conv_toep_wpack_bytes(int cin, int cout, int ksize) {
     return 16 + (size_t)cin * ksize * 2 * 2 * nb * 32 * 16;
 }
 
-int risp_conv2d_toep(const risp_conv_desc *dp, void *stream) {
+static int conv2d_toep_impl(const risp_conv_desc *dp, float *psum, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_toep: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_toep: null tensor");
@@ -378,8 +387,20 @@ int risp_conv2d_toep(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
                      reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_toep: tensors must be 16-byte aligned");
-    if (d.ksize == 9) return launch_toep_epi<9, 1, 4>(d, stream);
-    return launch_toep_epi<5, 1, RISP_TP_T5>(d, stream);
+    if (d.ksize == 9) return launch_toep_epi<9, 1, 4>(d, psum, stream);
+    return launch_toep_epi<5, 1, 4>(d, psum, stream);      // (6 rows per wave: no faster, 8 spill)
+}
+
+int risp_conv2d_toep(const risp_conv_desc *dp, void *stream) { return conv2d_toep_impl(dp, nullptr, stream); }
+
+/* ... and, on the way, the sum of every input channel over every tile's own pixels: psum [N][tiles per image][cin] floats, tile
+ * t = (y / 16) * ceil(W / 256) + x / 256 (risp_conv_toep_tiles per image).  What risp_rect_sums_tiles finishes into the
+ * rectangle sums of the constant-plane gradient (srcnn_res_arch.py:41-46) without reading the 64-channel tensor again. */
+int risp_conv_toep_tiles(int H, int W) { return ((H + 15) / 16) * ((W + TP_TW - 1) / TP_TW); }
+
+int risp_conv2d_toep_sums(const risp_conv_desc *dp, float *psum, void *stream) {
+    RISP_CHECK_ARG(psum, "risp_conv2d_toep_sums: needs the buffer of partial sums");
+    return conv2d_toep_impl(dp, psum, stream);
 }
 
 }  // extern "C"

@@ -123,6 +123,7 @@ SIGNATURES = {
     'risp_conv_k3_wpack_floats': (_z, [_i, _i, _i]),
     'risp_conv2d_k3': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_rect_sums': (_i, [_f, _f, _i, _i, _i, _i, _s]),
+    'risp_rect_sums_tiles': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _s]),
     'risp_srcnn_const_grad': (_i, [_f, _f, _f, _i, _i, _i, _s]),
     'risp_srcnn_case_table_group': (_i, [_f, C.POINTER(SrcnnGroupDesc), _f, _s]),
     'risp_srcnn_const_grad_group': (_i, [_f, C.POINTER(SrcnnGroupDesc), _f, _i, _s]),
@@ -144,6 +145,8 @@ SIGNATURES = {
     'risp_conv2d_f16x2': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_toep_wpack_bytes': (_z, [_i, _i, _i]),
     'risp_conv2d_toep': (_i, [C.POINTER(ConvDesc), _s]),
+    'risp_conv_toep_tiles': (_i, [_i, _i]),
+    'risp_conv2d_toep_sums': (_i, [C.POINTER(ConvDesc), _f, _s]),
     'risp_conv_toep_first_wpack_bytes': (_z, [_i, _i]),
     'risp_conv2d_toep_first': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wgrad_scratch_floats': (_z, [_i]),

@@ -338,3 +338,46 @@ def test_first_layer_dispatch(monkeypatch):
     y32 = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU, infer=True)
     assert calls[-1] == 'risp_conv2d_k3'
     assert (y - y32).abs().max().item() < 1e-5 * y32.abs().max().item()
+
+
+# --------------------------------------------------------------------------- rectangle sums out of the backward-data launch
+@pytest.mark.parametrize('nchw', [(2, 64, 40, 72), (1, 64, 16, 256), (3, 16, 33, 260), (1, 8, 5, 8), (2, 3, 4, 4), (1, 64, 70, 516)])
+def test_tile_sums_finish_into_the_rectangle_sums(nchw):
+    """risp_conv2d_toep_sums writes per-tile sums of its input planes; risp_rect_sums_tiles turns them plus the border rows and
+    columns into what risp_rect_sums computes from the whole planes (srcnn_res_arch.py:41-46: the gradient of the constant planes).
+    Summation order: per thread its staged quads in task order, DPP butterflies, the four waves, the tiles in index order, then
+    T - rows - columns + corner - another order than risp_rect_sums: agreement to 2e-6 of the largest sum, float64 as the referee."""
+    from reconfigisp_amd import convnets as CN, lib as L
+    n, c, h, w = nchw
+    w1 = rnd(c, 3, 9, 9, seed=200) * 0.05
+    g = rnd(n, c, h, w, seed=201)
+    pack = CN.toep_weights(w1, True, 3)
+    y0 = launch('risp_conv2d_toep', g, pack, None, n, h, w, c, 3, 9)
+    tiles = L.load().risp_conv_toep_tiles(h, w)
+    assert tiles == ((h + 15) // 16) * ((w + 255) // 256)
+    ps = torch.full((n, tiles, c), float('nan'), device='cuda')
+    y = torch.full((n, 3, h, w), float('nan'), device='cuda')
+    d = L.ConvDesc(N=n, H=h, W=w, cin=c, cout=3, ksize=9, load_mode=0, cin_img=0, epilogue=16, add_c=0, x=g.data_ptr(), wpack=pack.data_ptr(),
+                   bias=None, cvals=None, add=None, mask=None, y=y.data_ptr())
+    L.call('risp_conv2d_toep_sums', C.byref(d), C.c_void_p(ps.data_ptr()), None)
+    assert torch.equal(y, y0)                                     # the convolution itself is untouched
+    assert (ps.sum(1).double() - g.double().sum((2, 3))).abs().max().item() <= 2e-6 * g.double().abs().sum((2, 3)).max().item()
+    rs_t, rs_f = torch.empty(n, c * 81, device='cuda'), torch.empty(n, c * 81, device='cuda')
+    L.call('risp_rect_sums_tiles', C.c_void_p(g.data_ptr()), C.c_void_p(ps.data_ptr()), C.c_void_p(rs_t.data_ptr()), n, c, h, w, tiles, None)
+    L.call('risp_rect_sums', C.c_void_p(g.data_ptr()), C.c_void_p(rs_f.data_ptr()), n * c, h, w, 9, None)
+    torch.cuda.synchronize()
+    gd = g.double().cpu().numpy()
+    ref = np.zeros((n, c, 9, 9))
+    for i in range(9):
+        for j in range(9):
+            dy, dx = i - 4, j - 4
+            ys = slice(max(0, -dy), h - max(0, dy))
+            xs = slice(max(0, -dx), w - max(0, dx))
+            ref[:, :, i, j] = gd[:, :, ys, xs].sum((2, 3))
+    ref = torch.from_numpy(ref.reshape(n, -1)).cuda()
+    scale = np.abs(gd).sum((2, 3)).max()
+    assert (rs_t.double() - ref).abs().max().item() <= 2e-6 * scale
+    assert (rs_f.double() - ref).abs().max().item() <= 2e-6 * scale
+    again = torch.empty_like(rs_t)
+    L.call('risp_rect_sums_tiles', C.c_void_p(g.data_ptr()), C.c_void_p(ps.data_ptr()), C.c_void_p(again.data_ptr()), n, c, h, w, tiles, None)
+    assert torch.equal(again, rs_t)
