@@ -321,8 +321,9 @@ int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
  * wpack: risp_conv_toep_wpack_bytes() bytes, 16-byte aligned: a 16-byte header whose first float is 1 / s_w, then
  * [cin][ky][part: hi, lo][window half][row m = 8 cout + j, padded to 32][8 window slots] _Float16 with
  * band[m][u] = w[co][ci][ky][u - j + k/2 - 4] s_w (0 outside the filter row; reconfigisp_amd/convnets.py::toep_weights).
- * cout <= 4, any cin, ksize 5 or 9, W % 4 == 0, fewer than 2^30 input elements per image, 16-byte aligned tensors, load_mode PLAIN;
- * epilogue RELU | ADD (add_c <= cout) | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout == 4; grouped launches. */
+ * cout <= 4 (ksize 9 or 5), or 5 .. 12 with ksize 5 (SRCNNDemosaic's 5x5 32 -> 12 tail, srcnn_demosaic_arch.py:21: three row blocks,
+ * rows padded to 96); any cin, W % 4 == 0, fewer than 2^30 input elements per image, 16-byte aligned tensors, load_mode PLAIN;
+ * epilogue RELU | ADD (add_c <= cout) | NOBIAS, or SHUFFLE2 [| NOBIAS] with cout % 4 == 0; grouped launches. */
 size_t risp_conv_toep_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_toep(const risp_conv_desc *d, void *stream);
 /* The same launch also writing, per tile of 16 rows x 256 columns, the sum of every input channel over the tile's own pixels:

@@ -138,27 +138,28 @@ def f16x2_weights(w, transpose):
 
 def toep_weights(w, transpose=False, keep=None):
     """Pre-split Toeplitz-band pack of ``risp_conv2d_toep`` (include/risp.h) from a layer's (cout <= 4, cin, k, k) tensor, k = 5 or
-    9: a 16-byte header whose first float is 1 / s_w, then [cin][ky][part: hi, lo][window half][row m = 8 cout + j, padded to 32]
-    [8 window slots] halves with band[m][u] = w[co][ci][ky][u - j + k // 2 - 4] * s_w - the filter row as seen by the j-th pixel of
+    9: a 16-byte header whose first float is 1 / s_w, then [cin][ky][part: hi, lo][window half][row m = 8 cout + j, padded to 32 - or to
+    96 for the 5 to 12 couts of a 5-tap layer][8 window slots] halves with band[m][u] = w[co][ci][ky][u - j + k // 2 - 4] * s_w - the filter row as seen by the j-th pixel of
     a block of 8 from a window of 16 input pixels that starts 4 pixels left of the block.  ``transpose``: the backward-data layer
     of a FORWARD weight (roles swapped, taps rotated by 180 degrees) restricted to its first ``keep`` input channels.  Scale and
     split as in ``f16x2_weights``; pure tensor algebra on the device of ``w``.  Returns a float16 tensor."""
     if transpose:
         w = w[:, :keep].flip(2, 3).transpose(0, 1)
     co, ci, k = w.shape[0], w.shape[1], w.shape[2]
-    if co > 4 or k not in (5, 9):
-        raise ValueError('Toeplitz-band pack: %d output channels (at most 4), %d taps (5 or 9)' % (co, k))
+    if k not in (5, 9) or co > (12 if k == 5 else 4):
+        raise ValueError('Toeplitz-band pack: %d output channels (at most 4; 12 for 5 taps), %d taps (5 or 9)' % (co, k))
+    nb = 1 if co <= 4 else 3                                        # row blocks of 4 couts x 8 positions
     _, e = torch.frexp(w.detach().abs().max())
     sw = torch.ldexp(torch.ones((), device=w.device), 15 - e)
     ws = w.detach().float() * sw
     hi = ws.half()
     parts = (hi, (ws - hi.float()).half())
-    band = torch.zeros((2, ci, k, 4, 8, 16), device=w.device, dtype=torch.float16)      # (part, ci, ky, cout, j, u)
+    band = torch.zeros((2, ci, k, 4 * nb, 8, 16), device=w.device, dtype=torch.float16)      # (part, ci, ky, cout, j, u)
     for j in range(8):
         for part in range(2):
             band[part, :, :, :co, j, j + 4 - k // 2:j + 4 - k // 2 + k] = parts[part].permute(1, 2, 0, 3)
     #       (part, ci, ky, m, half, 8) -> (ci, ky, part, half, m, 8)
-    band = band.view(2, ci, k, 32, 2, 8).permute(1, 2, 0, 4, 3, 5).contiguous()
+    band = band.view(2, ci, k, 32 * nb, 2, 8).permute(1, 2, 0, 4, 3, 5).contiguous()
     hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
     hdr[0] = 1.0 / sw
     return torch.cat([hdr.view(torch.float16), band.reshape(-1)])
@@ -299,7 +300,7 @@ class SmallConv:
         self.wpack, self.cout = small_weights(w, transpose, keep)
         self.cin, self.k = self.wpack.shape[0], self.wpack.shape[2]
         # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts
-        self.toep = toep_weights(w, transpose, keep) if self.k in (5, 9) and self.cout <= 4 else None
+        self.toep = toep_weights(w, transpose, keep) if (self.k == 9 and self.cout <= 4) or (self.k == 5 and self.cout <= 12) else None
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 
@@ -369,7 +370,7 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
         else:
             L.call('risp_conv2d_toep', C.byref(d), _stream())
         if MFMA_ISSUED_F16 is not None:                # per (ci, ky) and block of 8 pixels: 3 products of 32 rows x 16 window slots
-            MFMA_ISSUED_F16[0] += 3 * 2.0 * 32 * 16 / 8 * sc.cin * sc.k * nn_ * h * w
+            MFMA_ISSUED_F16[0] += 3 * 2.0 * (32 if sc.cout <= 4 else 96) * 16 / 8 * sc.cin * sc.k * nn_ * h * w
         return out
     _group_fields(d, n, group, sc.wpack, sc.bias)
     groups = 1 if infer else (split if split is not None else L.load().risp_conv_small_groups(C.byref(d)))

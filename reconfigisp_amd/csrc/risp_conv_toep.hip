@@ -217,39 +217,71 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
             // ---- matrix phase
             const uint4 *ws = wl + ring * WST + abase;
             const uint4 *ts = tile + bbase;
-            h8 a[KS][NB][2], bv[3][2];
-            auto load_a = [&](int ky) {
+            if constexpr (NB == 1) {
+                // the band operands of all KS filter rows stay in registers; the wave walks the T + KS - 1 input rows it needs: each
+                // row's operand is read once and serves every (output row t, filter row ky) pair with t + ky = row
+                h8 a[KS][2], bv[3][2];
+                auto load_a = [&](int ky) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
+                    for (int part = 0; part < 2; ++part) a[ky][part] = __builtin_bit_cast(h8, ws[((ky * 2 + part) * 2) * 32]);
+                };
+                auto load_b = [&](int r, int buf) {
+                    bv[buf][0] = __builtin_bit_cast(h8, ts[r * RS]);
+                    bv[buf][1] = __builtin_bit_cast(h8, ts[C::PART + r * RS]);
+                };
+                load_a(0);
+                load_b(0, 0);
+                load_b(1, 1);
 #pragma unroll
-                    for (int part = 0; part < 2; ++part) a[ky][b][part] = __builtin_bit_cast(h8, ws[((ky * 2 + part) * 2) * NB * 32 + b * 32]);
-            };
-            auto load_b = [&](int r, int buf) {
-                bv[buf][0] = __builtin_bit_cast(h8, ts[r * RS]);
-                bv[buf][1] = __builtin_bit_cast(h8, ts[C::PART + r * RS]);
-            };
-            load_a(0);
-            load_b(0, 0);
-            load_b(1, 1);
+                for (int r = 0; r < T + KS - 1; ++r) {
+                    if (r + 2 < T + KS - 1) load_b(r + 2, (r + 2) % 3);
+                    if (r + 1 < KS) load_a(r + 1);
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < T + KS - 1; ++r) {
-                if (r + 2 < T + KS - 1) load_b(r + 2, (r + 2) % 3);
-                if (r + 1 < KS) load_a(r + 1);
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int ky = r - t;
-                    if (ky >= 0 && ky < KS) {
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][b][0], bv[r % 3][1], acc[t][b], 0, 0, 0);
-                            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][b][1], bv[r % 3][0], acc[t][b], 0, 0, 0);
-                            acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][b][0], bv[r % 3][0], acc[t][b], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) {
+                        const int ky = r - t;
+                        if (ky >= 0 && ky < KS) {
+                            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][0], bv[r % 3][1], acc[t][0], 0, 0, 0);
+                            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][1], bv[r % 3][0], acc[t][0], 0, 0, 0);
+                            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][0], bv[r % 3][0], acc[t][0], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // several row blocks (5x5 32 -> 12): the bands of ONE filter row at a time (2 NB operands, double-buffered), steps
+                // (ky, t) with the pixel operand of the next step read under the 3 NB products of this one
+                h8 a[2][NB][2], bv[2][2];
+                auto load_a = [&](int ky, int buf) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) a[buf][b][part] = __builtin_bit_cast(h8, ws[((ky * 2 + part) * 2) * NB * 32 + b * 32]);
+                };
+                auto load_b = [&](int r, int buf) {
+                    bv[buf][0] = __builtin_bit_cast(h8, ts[r * RS]);
+                    bv[buf][1] = __builtin_bit_cast(h8, ts[C::PART + r * RS]);
+                };
+                load_a(0, 0);
+                load_b(0, 0);
+#pragma unroll
+                for (int step = 0; step < KS * T; ++step) {
+                    const int ky = step / T, t = step - ky * T;
+                    if (step + 1 < KS * T) {
+                        load_b((step + 1) / T + (step + 1) % T, (step + 1) & 1);
+                        if (t == T - 1) load_a(ky + 1, (ky + 1) & 1);
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky & 1][b][0], bv[step & 1][1], acc[t][b], 0, 0, 0);
+                        acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky & 1][b][1], bv[step & 1][0], acc[t][b], 0, 0, 0);
+                        acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky & 1][b][0], bv[step & 1][0], acc[t][b], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             ring ^= 1;
             TPSTAMP(t_mat);
@@ -363,7 +395,7 @@ int launch_toep_epi(const risp_conv_desc &d, float *psum, void *stream) {
 extern "C" {
 
 size_t risp_conv_toep_wpack_bytes(int cin, int cout, int ksize) {
-    const int nb = (cout + 3) / 4;
+    const int nb = cout <= 4 ? 1 : 3;
     return 16 + (size_t)cin * ksize * 2 * 2 * nb * 32 * 16;
 }
 
@@ -372,9 +404,9 @@ static int conv2d_toep_impl(const risp_conv_desc *dp, float *psum, void *stream)
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_toep: null tensor");
     RISP_CHECK_GROUP(d, "risp_conv2d_toep");
-    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 4 && (d.ksize == 5 || d.ksize == 9) &&
+    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && (d.cout <= 4 || (d.cout <= 12 && d.ksize == 5)) && (d.ksize == 5 || d.ksize == 9) &&
                        (unsigned long long)d.cin * d.H * d.W < (1ull << 30),
-                   "risp_conv2d_toep: needs a 5x5 or 9x9 layer with cout <= 4, W %% 4 == 0, fewer than 2^30 input elements per image "
+                   "risp_conv2d_toep: needs a 9x9 layer with cout <= 4 or a 5x5 layer with cout <= 12, W %% 4 == 0, fewer than 2^30 input elements per image "
                    "(N=%d H=%d W=%d cin=%d cout=%d k=%d)",
                    d.N, d.H, d.W, d.cin, d.cout, d.ksize);
     RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_toep: only plain loads");
@@ -388,6 +420,9 @@ static int conv2d_toep_impl(const risp_conv_desc *dp, float *psum, void *stream)
                      reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_toep: tensors must be 16-byte aligned");
     if (d.ksize == 9) return launch_toep_epi<9, 1, 4>(d, psum, stream);
+    // three row blocks: 2 output rows per wave (8-row tiles).  (3 rows: 1.4 x the tile time for 1.5 x the rows, but the tile shape must
+    // not depend on the launch - the per-tile scale would make an inference result depend on the batch it travels in)
+    if (d.cout > 4) return launch_toep_epi<5, 3, 2>(d, psum, stream);
     return launch_toep_epi<5, 1, 4>(d, psum, stream);      // (6 rows per wave: no faster, 8 spill)
 }
 
@@ -396,10 +431,10 @@ int risp_conv2d_toep(const risp_conv_desc *dp, void *stream) { return conv2d_toe
 /* ... and, on the way, the sum of every input channel over every tile's own pixels: psum [N][tiles per image][cin] floats, tile
  * t = (y / 16) * ceil(W / 256) + x / 256 (risp_conv_toep_tiles per image).  What risp_rect_sums_tiles finishes into the
  * rectangle sums of the constant-plane gradient (srcnn_res_arch.py:41-46) without reading the 64-channel tensor again. */
-int risp_conv_toep_tiles(int H, int W) { return ((H + 15) / 16) * ((W + TP_TW - 1) / TP_TW); }
+int risp_conv_toep_tiles(int H, int W) { return ((H + 15) / 16) * ((W + TP_TW - 1) / TP_TW); }      /* cout <= 4 */
 
 int risp_conv2d_toep_sums(const risp_conv_desc *dp, float *psum, void *stream) {
-    RISP_CHECK_ARG(psum, "risp_conv2d_toep_sums: needs the buffer of partial sums");
+    RISP_CHECK_ARG(psum && dp && dp->cout <= 4, "risp_conv2d_toep_sums: needs the buffer of partial sums and a layer with cout <= 4 (16-row tiles)");
     return conv2d_toep_impl(dp, psum, stream);
 }
 

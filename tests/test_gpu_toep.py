@@ -47,7 +47,7 @@ def err(y, ref):
 SHAPES = [(1, 16, 256), (2, 37, 64), (3, 16, 260), (1, 5, 8), (2, 50, 512), (1, 33, 4), (5, 20, 132)]
 
 
-@pytest.mark.parametrize('k,cin,cout', [(9, 64, 3), (5, 32, 3), (9, 64, 4), (5, 7, 1), (9, 3, 2)])
+@pytest.mark.parametrize('k,cin,cout', [(9, 64, 3), (5, 32, 3), (9, 64, 4), (5, 7, 1), (9, 3, 2), (5, 32, 12), (5, 8, 6)])
 @pytest.mark.parametrize('nhw', SHAPES)
 def test_forward_against_float64_next_to_the_vector_kernel(k, cin, cout, nhw):
     from reconfigisp_amd import convnets as CN
@@ -97,6 +97,11 @@ def test_epilogues_and_the_backward_data_packs(nhw):
     ref = TF.pixel_shuffle(TF.conv_transpose2d(g.double(), w1.double(), padding=4), 2)
     y = launch('risp_conv2d_toep', g, CN.toep_weights(w1, True, 4), None, n, h, w, 64, 4, 9, E.EPI_SHUFFLE2)
     assert y.shape == (n, 1, 2 * h, 2 * w) and err(y, ref)[1] < 5e-6
+    # SRCNNDemosaic tail: 5x5 32 -> 12 through PixelShuffle, with bias (srcnn_demosaic_arch.py:21-22)
+    w3, b3 = rnd(12, 32, 5, 5, seed=17) * 0.05, rnd(12, seed=18) * 0.1
+    ref = TF.pixel_shuffle(TF.conv2d(x.double(), w3.double(), b3.double(), padding=2), 2)
+    y = launch('risp_conv2d_toep', x, CN.toep_weights(w3), b3, n, h, w, 32, 12, 5, E.EPI_SHUFFLE2)
+    assert y.shape == (n, 3, 2 * h, 2 * w) and err(y, ref)[1] < 3e-6
     bias4 = rnd(4, seed=16) * 1e-4
     ref = TF.pixel_shuffle(TF.conv_transpose2d(g.double(), w1.double(), padding=4) + bias4.double().view(1, 4, 1, 1), 2)
     y = launch('risp_conv2d_toep', g, CN.toep_weights(w1, True, 4), bias4, n, h, w, 64, 4, 9, E.EPI_SHUFFLE2)
@@ -173,7 +178,7 @@ def test_arguments_outside_the_kernel_are_refused():
     from reconfigisp_amd import convnets as CN, lib as L
     x = rnd(1, 8, 16, 64, seed=80)
     p = CN.toep_weights(rnd(3, 8, 5, 5, seed=81))
-    cases = [dict(cout=5), dict(k=3), dict(k=7), dict(w=62), dict(epi=4), dict(epi=8), dict(epi=2)]      # mask; shuffle with cout 3; add without tensor
+    cases = [dict(cout=13), dict(cout=5, k=9), dict(k=3), dict(k=7), dict(w=62), dict(epi=4), dict(epi=8), dict(epi=2)]   # mask; shuffle with cout 3; add without tensor
     for c in cases:
         kw = dict(cout=3, k=5, w=64, epi=0)
         kw.update(c)
@@ -193,6 +198,7 @@ def test_conv_small_dispatch(monkeypatch):
         calls.append(name)
         return real(name, *a)
     monkeypatch.setattr(CN.L, 'call', spy)
+    monkeypatch.setattr(CN, 'TOEP_MIN_TILES', 256)
     wt, b = rnd(3, 32, 5, 5, seed=90) * 0.05, rnd(3, seed=91) * 0.1
     sc = CN.SmallConv(wt, b)
     x = rnd(2, 32, 32, 64, seed=92)

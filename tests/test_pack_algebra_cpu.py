@@ -330,7 +330,7 @@ def test_f16x2_weight_pack_layout_and_scale():
 
 
 # --------------------------------------------------------------------------- Toeplitz bands (risp_conv2d_toep)
-@pytest.mark.parametrize('k,co,ci,tr', [(9, 3, 5, False), (5, 3, 6, False), (9, 3, 7, True), (9, 4, 3, True), (5, 1, 2, False)])
+@pytest.mark.parametrize('k,co,ci,tr', [(9, 3, 5, False), (5, 3, 6, False), (9, 3, 7, True), (9, 4, 3, True), (5, 1, 2, False), (5, 12, 4, False), (5, 7, 3, False)])
 def test_toeplitz_band_pack_reproduces_the_convolution(k, co, ci, tr):
     """convnets.toep_weights: header = 1 / s_w, body [cin][ky][hi, lo][window half][row 8 cout + j][8]; with the window of block b
     starting 4 pixels left of it, band @ window == the filter row applied at the block's 8 pixels - the whole convolution (or the
@@ -339,14 +339,15 @@ def test_toeplitz_band_pack_reproduces_the_convolution(k, co, ci, tr):
     torch.manual_seed(k + co)
     w = torch.randn(co, ci, k, k) * 0.05 if not tr else torch.randn(ci, co + 2, k, k) * 0.05
     p = CN.toep_weights(w, tr, co if tr else None)
-    assert p.dtype == torch.float16 and p.numel() == 8 + ci * k * 2 * 2 * 32 * 8
+    rows = 32 if co <= 4 else 96
+    assert p.dtype == torch.float16 and p.numel() == 8 + ci * k * 2 * 2 * rows * 8
     inv = p[:2].view(torch.float32).item()
     wt = w[:, :co].flip(2, 3).transpose(0, 1) if tr else w
     sw = 1.0 / inv
     assert 2.0 ** 14 <= wt.abs().max().item() * sw < 2.0 ** 15 and sw == 2.0 ** round(np.log2(sw))
-    body = p[8:].view(ci, k, 2, 2, 32, 8).double()
-    band = ((body[:, :, 0] + body[:, :, 1]) * inv).permute(0, 1, 3, 2, 4).reshape(ci, k, 32, 16)      # (ci, ky, m, u)
-    assert co == 4 or band[:, :, 8 * co:].abs().max().item() == 0                                      # rows of couts the layer has not
+    body = p[8:].view(ci, k, 2, 2, rows, 8).double()
+    band = ((body[:, :, 0] + body[:, :, 1]) * inv).permute(0, 1, 3, 2, 4).reshape(ci, k, rows, 16)      # (ci, ky, m, u)
+    assert 8 * co == rows or band[:, :, 8 * co:].abs().max().item() == 0                                      # rows of couts the layer has not
     h, wd, pad = 7, 24, k // 2
     x = torch.randn(1, ci, h, wd, dtype=torch.float64)
     ref = torch.nn.functional.conv2d(x, wt.double(), padding=pad)[0]

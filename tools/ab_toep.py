@@ -27,7 +27,8 @@ def main():
     n, hw, G = int(os.environ.get('RISP_AB_N', 32)), int(os.environ.get('RISP_AB_HW', 256)), int(os.environ.get('RISP_AB_G', 1))
     gen = torch.Generator('cuda').manual_seed(1)
     cases = [('9x9 64->3 backward-data + add', 9, 64, 3, True, CN.EPI_ADD), ('5x5 32->3 forward + add', 5, 32, 3, False, CN.EPI_ADD),
-             ('9x9 64->4 backward-data, PixelShuffle', 9, 64, 4, True, CN.EPI_SHUFFLE2)]
+             ('9x9 64->4 backward-data, PixelShuffle', 9, 64, 4, True, CN.EPI_SHUFFLE2),
+             ('5x5 32->12 forward, PixelShuffle', 5, 32, 12, False, CN.EPI_SHUFFLE2)]
     for name, k, cin, cout, tr, epi in cases:
         if tr:
             ws = [torch.randn(cin, cout + 9, k, k, device='cuda', generator=gen) * 0.05 for _ in range(G)]
