@@ -325,8 +325,15 @@ def toep_grid_ok(images, h, w):
     return images * ((h + 15) // 16) * ((w + 255) // 256) >= TOEP_MIN_TILES
 
 
+def toep_width_ok(w):
+    """the Toeplitz-band kernels cut rows into strips of 256 pixels = the 32 columns of a matrix instruction: a 128-pixel plane
+    (the Bayer-domain proxies on 256 x 256 patches) would leave half of every instruction idle - those stay on the fp32 kernels"""
+    return w * 4 >= 3 * 256 * ((w + 255) // 256)
+
+
 def _toep_ok(sc, h, w):
-    return TOEP and CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
+    return (TOEP and CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and toep_width_ok(w)
+            and sc.cin * h * w < (1 << 30))
 
 
 # A/B switches of the two Toeplitz-band kernels (default on; RISP_CONV_ARITH=f32 switches both off as well)
@@ -462,7 +469,7 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
             and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS)) and (x.data_ptr() | out.data_ptr()) % 16 == 0):
         wpack, entry, use_wino = pc.k3, 'risp_conv2d_k3', True      # first layers: the linear-k kernel (risp_conv_k3.hip)
         if ((TOEP_FIRST == 'train' or (TOEP_FIRST == '1' and infer)) and CONV_ARITH == 'f16x2' and getattr(pc, 'toep_first', None) is not None
-                and cin * h * w < (1 << 30)):
+                and toep_width_ok(w) and cin * h * w < (1 << 30)):
             wpack, entry = pc.toep_first, 'risp_conv2d_toep_first'  # 9x9: windows of the filter rows on the f16 matrix pipe
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wpack),

@@ -201,25 +201,27 @@ def test_conv_small_dispatch(monkeypatch):
     monkeypatch.setattr(CN, 'TOEP_MIN_TILES', 256)
     wt, b = rnd(3, 32, 5, 5, seed=90) * 0.05, rnd(3, seed=91) * 0.1
     sc = CN.SmallConv(wt, b)
-    x = rnd(2, 32, 32, 64, seed=92)
+    x = rnd(2, 32, 32, 256, seed=92)
     ref = TF.conv2d(x.double(), wt.double(), b.double(), padding=2)
 
     def last():
         return [c for c in calls if c.startswith('risp_conv2d')][-1]
-    y = CN.conv_small(x, sc, 2, 32, 64)                       # 4 tiles: the vector kernel (with its channel split)
+    y = CN.conv_small(x, sc, 2, 32, 256)                       # 4 tiles: the vector kernel (with its channel split)
     assert last().startswith('risp_conv2d_small') and err(y, ref)[1] < 3e-6
-    y = CN.conv_small(x, sc, 2, 32, 64, infer=True)           # inference: always the same kernel, whatever the batch
+    y = CN.conv_small(x, sc, 2, 32, 256, infer=True)           # inference: always the same kernel, whatever the batch
     assert last() == 'risp_conv2d_toep' and err(y, ref)[1] < 3e-6
     monkeypatch.setattr(CN, 'TOEP_MIN_TILES', 4)
-    y = CN.conv_small(x, sc, 2, 32, 64)
+    y = CN.conv_small(x, sc, 2, 32, 256)
     assert last() == 'risp_conv2d_toep' and err(y, ref)[1] < 3e-6
-    assert CN._small_split(x, sc, 2, 32, 64, 0, 0) == 0
-    y = CN.conv_small(x, sc, 2, 32, 64, mask=torch.ones_like(ref, dtype=torch.float32), epi=CN.EPI_MASK)
+    assert CN._small_split(x, sc, 2, 32, 256, 0, 0) == 0
+    CN.conv_small(x[..., :128].contiguous(), sc, 2, 32, 128, infer=True)       # half-empty 256-pixel strips: not worth it
+    assert last().startswith('risp_conv2d_small') and not CN.toep_width_ok(128) and CN.toep_width_ok(200) and CN.toep_width_ok(4000)
+    y = CN.conv_small(x, sc, 2, 32, 256, mask=torch.ones_like(ref, dtype=torch.float32), epi=CN.EPI_MASK)
     assert last().startswith('risp_conv2d_small')              # epilogues the kernel does not have stay where they were
     monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
-    y = CN.conv_small(x, sc, 2, 32, 64, infer=True)
+    y = CN.conv_small(x, sc, 2, 32, 256, infer=True)
     assert last().startswith('risp_conv2d_small') and err(y, ref)[1] < 3e-6
-    assert CN._small_split(x, sc, 2, 32, 64, 0, 0) != 0
+    assert CN._small_split(x, sc, 2, 32, 256, 0, 0) != 0
 
 
 # --------------------------------------------------------------------------- the 9x9 first layers (risp_conv2d_toep_first)
@@ -328,7 +330,7 @@ def test_first_layer_dispatch(monkeypatch):
     def spy(name, *a):
         calls.append(name)
         return real(name, *a)
-    n, h, w = 2, 24, 40
+    n, h, w = 2, 24, 200
     x = rnd(n, 3, h, w, seed=150)
     pc9, pc3 = CN.PackedConv(rnd(64, 3, 9, 9, seed=151) * 0.1, rnd(64, seed=152)), CN.PackedConv(rnd(64, 3, 3, 3, seed=153) * 0.1, rnd(64, seed=154))
     monkeypatch.setattr(CN.L, 'call', spy)
