@@ -526,7 +526,7 @@ def main():
         tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12
         extra.update(cnn_arch=ARCH_CNN, cnn_MPix_s=round(world * pix_per_step * steps_c / wall_c / 1e6, 1),
                      cnn_ms_per_step=round(dev_ms_c, 3),
-                     cnn_arith=('2 x f16 split (3 products, f32 accumulate) for the wide 3x3 / 5x5 layers, f32 elsewhere'
+                     cnn_arith=('2 x f16 split (3 products, f32 accumulate) for the wide 3x3 / 5x5 layers and, on rows of >= 192 pixels, the 9x9 / 5x5 few-channel ends; f32 elsewhere'
                                 if CN.CONV_ARITH == 'f16x2' else 'f32'),
                      cnn_effective_TFLOPs=round(tf(FLOP_PER_PIX_CNN * pix_per_step, dev_ms_c), 2),
                      cnn_effective_frac=round(tf(FLOP_PER_PIX_CNN * pix_per_step, dev_ms_c) / MFMA_F32_PEAK_TFLOPS, 4),

@@ -342,6 +342,14 @@ int risp_conv2d_toep_sums(const risp_conv_desc *d, float *psum, void *stream);
  * UNSHUFFLE2 with cin == 4 (x = the (N,1,2H,2W) mosaic); epilogue RELU | NOBIAS | CASEBIAS; grouped launches. */
 size_t risp_conv_toep_first_wpack_bytes(int cin, int cout);
 int risp_conv2d_toep_first(const risp_conv_desc *d, void *stream);
+/* ... with exact ReLU decisions, for training forwards: outputs whose pre-activation lies within the arithmetic's own error of zero
+ * (|z| < 2^-20 x 81 x max|w| x the tile's input magnitude summed over the channels) are listed in `ties` ([0] = count, then up to
+ * max_ties linear output indices; cleared by this call) and a second launch recomputes them in double - exact products, fixed
+ * order, one rounding - from the layer's fp32 weights w32 (cout,cin,9,9), the members of a grouped launch w32_gs floats apart.
+ * Fewer than 2^32 outputs.  Which way such an activation falls otherwise depends on the summation order of whichever fp32-accurate
+ * kernel computed it, and one ReLU mask bit is a finite step of every gradient behind it.  (Opt-in: RISP_CONV_TOEP_FIRST=train.) */
+int risp_conv2d_toep_first_exact(const risp_conv_desc *d, const float *w32, long long w32_gs, unsigned *ties, unsigned max_ties,
+                                 void *stream);
 
 /* out[p][ky][kx] = sum of g[p] (planes x H x W) over the pixels q with q + (ky - k/2, kx - k/2) inside the plane:
  * what the backward of a k x k convolution over a spatially CONSTANT input channel needs from the upstream gradient

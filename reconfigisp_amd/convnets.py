@@ -277,6 +277,7 @@ class PackedConv:
         self.k3 = k3_weights(w) if (self.k in (3, 9) and self.cin in (3, 4) and self.cout <= 64) else None
         # ... and the 9x9 ones on the f16 matrix pipe in split precision (see CONV_ARITH), risp_conv_toep_first.hip
         self.toep_first = toep_first_weights(w) if (self.k == 9 and self.cin in (3, 4)) else None
+        self.w32 = w.float().contiguous() if self.toep_first is not None else None      # for the exact recomputation of ReLU ties
         if self.k == 3 and WINOGRAD:
             self.wino_fwd, self.wino_bwd, self.wino_entry = _wino3_pack(w, False), _wino3_pack(w, True), 'risp_conv2d_wino3'
             if WINO_F43:                              # inference forward and every backward-data pass (see conv())
@@ -322,30 +323,44 @@ def _group_fields(d, n, group, wpack, bias):
 def toep_grid_ok(images, h, w):
     """training launches: enough 16 x 256 tiles for the persistent grid of ``risp_conv2d_toep`` (else the vector-FMA kernel with
     its input-channel split fills the chip better)"""
-    return images * ((h + 15) // 16) * ((w + 255) // 256) >= TOEP_MIN_TILES
-
-
-def toep_width_ok(w):
-    """the Toeplitz-band kernels cut rows into strips of 256 pixels = the 32 columns of a matrix instruction: a 128-pixel plane
-    (the Bayer-domain proxies on 256 x 256 patches) would leave half of every instruction idle - those stay on the fp32 kernels"""
-    return w * 4 >= 3 * 256 * ((w + 255) // 256)
+    tiles = ((h + 31) // 32) * ((w + 127) // 128) if w <= 128 else ((h + 15) // 16) * ((w + 255) // 256)
+    return images * tiles >= TOEP_MIN_TILES
 
 
 def _toep_ok(sc, h, w):
-    return (TOEP and CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and toep_width_ok(w)
-            and sc.cin * h * w < (1 << 30))
+    # (any width: planes of at most 128 pixels run with two rows folded into the 32 columns of the matrix instruction; the 12-cout
+    # form cannot fold and is ~20 % slower than the vector kernel there, but a layer keeps ONE arithmetic whatever the crop it sees)
+    return TOEP and CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
 
 
 # A/B switches of the two Toeplitz-band kernels (default on; RISP_CONV_ARITH=f32 switches both off as well)
 TOEP = os.environ.get('RISP_CONV_TOEP', '1') != '0'              # risp_conv2d_toep: 5- / 9-tap layers with at most 4 couts
-# risp_conv2d_toep_first (9x9 first layers): '1' (default) = inference launches, 'train' = training forwards too, '0' = never.
-# Training stays on the fp32 kernel by default because of ONE activation of the DARTS golden scenario (tests/golden/darts_step.npz;
-# tools/dbg_flips.py): its pre-activation is 1.5e-8 of the layer's magnitude - below what fp32 resolves - and the two kernels,
-# equally exact against float64 (tests/test_gpu_toep.py), round it to opposite sides of the ReLU; that one mask bit moves an alpha
-# gradient by 3e-5 and, through Adam's normalised first step, iteration 1 by 9e-4 - past the 1e-4 bar of the golden comparison.
-TOEP_FIRST = os.environ.get('RISP_CONV_TOEP_FIRST', '1')
-if TOEP_FIRST not in ('0', '1', 'train'):
-    raise ValueError("RISP_CONV_TOEP_FIRST must be '0', '1' or 'train', got %r" % TOEP_FIRST)
+# risp_conv2d_toep_first (9x9 first layers): 'infer' (default) = inference launches only, training forwards stay on the fp32 kernel
+# risp_conv2d_k3; 'train' = training forwards too, with EXACT ReLU decisions (risp_conv2d_toep_first_exact: outputs whose
+# pre-activation is within the arithmetic's own error of zero are recomputed in double); 'plain' = training without that; '0' = never.
+# Why training is opt-in: the DARTS golden scenario (tests/golden/darts_step.npz; tools/dbg_flips.py) holds ONE first-layer
+# activation whose pre-activation is 1.5e-8 of the layer's magnitude.  Which side of the ReLU it lands on is decided by the last bits of
+# the slot's INPUT - i.e. by the rounding of whatever kernels ran upstream, not by this layer (with the same input both kernels and
+# float64 agree; exact decisions do not help) - and that one mask bit moves an alpha gradient by 3e-5 and, through Adam's normalised
+# first step, iteration 1 by 9e-4: past the 1e-4 bar of the golden comparison.  The fp32 first-layer kernel happens to reproduce the
+# reference's side of that coin; a change of arithmetic in a TRAINING forward re-tosses it.  Inference has no such feedback.
+TOEP_FIRST = os.environ.get('RISP_CONV_TOEP_FIRST', 'infer')
+if TOEP_FIRST not in ('0', 'infer', 'train', 'plain'):
+    raise ValueError("RISP_CONV_TOEP_FIRST must be '0', 'infer', 'train' or 'plain', got %r" % TOEP_FIRST)
+_TIES = {}                                              # per (device, stream): the tie list of risp_conv2d_toep_first_exact
+TIES_MAX = 1 << 20
+
+
+def _tie_list(device):
+    """one list per stream: the launches of a slot's operators run on two streams (section 5.1 of DESIGN.md), and a list shared by two
+    launches in flight would lose ties"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _TIES.get(key)
+    if t is None:
+        t = _TIES[key] = torch.zeros(1 + TIES_MAX, device=device, dtype=torch.int32)
+    return t
+
+
 TOEP_MIN_TILES = int(os.environ.get('RISP_TOEP_MIN_TILES', '256'))
 
 
@@ -468,14 +483,18 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
             and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
             and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS)) and (x.data_ptr() | out.data_ptr()) % 16 == 0):
         wpack, entry, use_wino = pc.k3, 'risp_conv2d_k3', True      # first layers: the linear-k kernel (risp_conv_k3.hip)
-        if ((TOEP_FIRST == 'train' or (TOEP_FIRST == '1' and infer)) and CONV_ARITH == 'f16x2' and getattr(pc, 'toep_first', None) is not None
-                and toep_width_ok(w) and cin * h * w < (1 << 30)):
+        if ((TOEP_FIRST in ('train', 'plain') or (TOEP_FIRST == 'infer' and infer)) and CONV_ARITH == 'f16x2' and getattr(pc, 'toep_first', None) is not None
+                and cin * h * w < (1 << 30)):
             wpack, entry = pc.toep_first, 'risp_conv2d_toep_first'  # 9x9: windows of the filter rows on the f16 matrix pipe
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wpack),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
     _group_fields(d, n, group, wpack, None if transpose else pc.bias)
-    L.call(entry if use_wino else 'risp_conv2d', C.byref(d), _stream())
+    if entry == 'risp_conv2d_toep_first' and use_wino and not infer and TOEP_FIRST == 'train' and nn_ * cout * h * w < (1 << 32):
+        w32 = pc.w32                                    # training forward: exact ReLU decisions (see TOEP_FIRST)
+        L.call('risp_conv2d_toep_first_exact', C.byref(d), _p(w32), w32.stride(0) if group else 0, _p(_tie_list(x.device)), TIES_MAX, _stream())
+    else:
+        L.call(entry if use_wino else 'risp_conv2d', C.byref(d), _stream())
     if entry == 'risp_conv2d_f16x2':
         if MFMA_ISSUED_F16 is not None:
             MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * pc.k * cin * cout * nn_ * h * w
@@ -832,7 +851,7 @@ class _Stacked:
 
 
 def stack_packed(pcs):
-    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd', 'toep_first'),
+    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd', 'toep_first', 'w32'),
                     ('cin', 'cout', 'k', 'wino_entry'))
 
 

@@ -22,26 +22,29 @@
 #include "risp_f16x2.h"
 
 namespace {
-constexpr int TP_TW = 256, TP_RS = 33, TP_Q = 66;       // tile width; 16-byte slots and 4-pixel quads of a staged row (pixels x0 - 4 .. x0 + 259)
-
-template <int KS, int NB, int T>
+// Tile geometry.  The 32 columns of a matrix instruction are FOLD rows x 32 / FOLD blocks of 8 pixels: one 256-pixel strip of a row,
+// or - planes of at most 128 pixels - two rows of a 128-pixel strip (a wave then owns 2 T rows, a tile 8 T).
+template <int KS, int NB, int T, int FOLD>
 struct TP {
-    static constexpr int P = KS / 2, TH = 4 * T, IH = TH + 2 * P;
-    static constexpr int PART = IH * TP_RS;                       // slots of one part (hi or lo) of the staged channel
+    static constexpr int P = KS / 2, NBLK = 32 / FOLD, TW = 8 * NBLK, TH = 4 * T * FOLD, IH = TH + 2 * P;
+    // 16-byte slots and 4-pixel quads of a staged row (pixels x0 - 4 .. x0 + TW + 3); folded: 32 slots per row, so that the lanes of the
+    // second row sit a multiple of 256 bytes from those of the first (conflict-free 16-byte LDS reads, tools/lds_bank_probe.hip)
+    static constexpr int RS = FOLD == 1 ? NBLK + 1 : 32, Q = 2 * NBLK + 2;
+    static constexpr int PART = IH * RS;                          // slots of one part (hi or lo) of the staged channel
     static constexpr int TILE = 2 * PART;
     static constexpr int WST = KS * 2 * 2 * NB * 32;              // band slots of one input channel: [ky][part][window half][row (cout, j)]
     static constexpr int PW = (WST / 64 + 3) / 4;                 // LDS-DMA instructions per wave and channel
-    static constexpr int NTASK = (IH * TP_Q + 255) / 256;         // staging tasks (row, quad) per thread
+    static constexpr int NTASK = (IH * Q + 255) / 256;            // staging tasks (row, quad) per thread
     static constexpr int LDS_BYTES = (TILE + 2 * WST) * 16 + 64;  // tile, two band buffers, the row of maxima
     static_assert(WST % 64 == 0, "bands in whole LDS-DMA pieces");
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
 // SHUF: PixelShuffle(2) store (cout % 4 == 0).  HAS_ADD: y += add[:, :add_c].
-template <int KS, int NB, int T, bool HAS_ADD, bool SHUF>
+template <int KS, int NB, int T, int FOLD, bool HAS_ADD, bool SHUF>
 __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ntiles, float *__restrict__ psum) {
-    using C = TP<KS, NB, T>;
-    constexpr int P = C::P, IH = C::IH, RS = TP_RS, WST = C::WST, PW = C::PW, NTASK = C::NTASK;
+    using C = TP<KS, NB, T, FOLD>;
+    constexpr int P = C::P, IH = C::IH, RS = C::RS, WST = C::WST, PW = C::PW, NTASK = C::NTASK, TP_Q = C::Q, TP_TW = C::TW, NBLK = C::NBLK;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *tile = smem, *wl = smem + C::TILE;
     float *red = reinterpret_cast<float *>(wl + 2 * WST);
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
     };
     // operands.  B: lane (b = lane & 31, half) of input row r reads slot b + half of that row (pixels 8 b - 4 + 8 half ..);
     // A: lane (m = lane & 31, half) reads row m, window half `half` of a band.
-    const int bbase = (T * wave) * RS + l31 + hl;
+    const int srow = FOLD * T * wave + (l31 / NBLK) * T, sblk = l31 % NBLK;    // the lane's first row inside the tile, its pixel block
+    const int bbase = srow * RS + sblk + hl;
     const int abase = hl * NB * 32 + l31;
 
 #ifdef RISP_TP_STAMPS
@@ -298,11 +302,11 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
             const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
             const int epi = d.epilogue;
             const float floor_ = (epi & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
-            const int ox = cur.x0 + 8 * l31 + 4 * hl;
+            const int ox = cur.x0 + 8 * sblk + 4 * hl;
             const float *bias = (epi & RISP_EPI_NOBIAS) ? nullptr : d.bias + (size_t)g * d.bias_gs;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const int oy = cur.y0 + T * wave + t;
+                const int oy = cur.y0 + srow + t;
                 if (oy >= d.H || ox >= d.W) continue;
                 const size_t pix = (size_t)oy * d.W + ox;
 #pragma unroll
@@ -363,16 +367,16 @@ __global__ __launch_bounds__(256, 2) void conv_toep_kernel(const risp_conv_desc 
 #define RISP_TP_WGS 2        // persistent workgroups per CU
 #endif
 
-template <int KS, int NB, int T, bool HAS_ADD, bool SHUF>
-int launch_toep(const risp_conv_desc &d, float *psum, void *stream) {
-    using C = TP<KS, NB, T>;
-    auto kern = &conv_toep_kernel<KS, NB, T, HAS_ADD, SHUF>;
+template <int KS, int NB, int T, int FOLD, bool HAS_ADD, bool SHUF>
+int launch_toep_g(const risp_conv_desc &d, float *psum, void *stream) {
+    using C = TP<KS, NB, T, FOLD>;
+    auto kern = &conv_toep_kernel<KS, NB, T, FOLD, HAS_ADD, SHUF>;
     if (C::LDS_BYTES > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
         risp_set_error("risp_conv2d_toep: cannot raise the dynamic LDS limit to %d bytes", C::LDS_BYTES);
         return 2;
     }
-    const int tx = (d.W + TP_TW - 1) / TP_TW, ty = (d.H + C::TH - 1) / C::TH;
+    const int tx = (d.W + C::TW - 1) / C::TW, ty = (d.H + C::TH - 1) / C::TH;
     const long long ntiles = (long long)tx * ty * d.N;
     if (ntiles > 0x7fffffff) {
         risp_set_error("risp_conv2d_toep: too many tiles");
@@ -383,6 +387,15 @@ int launch_toep(const risp_conv_desc &d, float *psum, void *stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, (hipStream_t)stream, d, tx, ty, (int)ntiles, psum);
     RISP_LAUNCH_CHECK("risp_conv2d_toep");
     return 0;
+}
+
+template <int KS, int NB, int T, bool HAS_ADD, bool SHUF>
+int launch_toep(const risp_conv_desc &d, float *psum, void *stream) {
+    // (three row blocks: the bands of a channel take 30 KB twice - no room for the folded tile: narrow planes run half empty there)
+    if constexpr (NB == 1) {
+        if (d.W <= 128) return launch_toep_g<KS, NB, T, 2, HAS_ADD, SHUF>(d, psum, stream);
+    }
+    return launch_toep_g<KS, NB, T, 1, HAS_ADD, SHUF>(d, psum, stream);
 }
 
 template <int KS, int NB, int T>
@@ -431,7 +444,9 @@ int risp_conv2d_toep(const risp_conv_desc *dp, void *stream) { return conv2d_toe
 /* ... and, on the way, the sum of every input channel over every tile's own pixels: psum [N][tiles per image][cin] floats, tile
  * t = (y / 16) * ceil(W / 256) + x / 256 (risp_conv_toep_tiles per image).  What risp_rect_sums_tiles finishes into the
  * rectangle sums of the constant-plane gradient (srcnn_res_arch.py:41-46) without reading the 64-channel tensor again. */
-int risp_conv_toep_tiles(int H, int W) { return ((H + 15) / 16) * ((W + TP_TW - 1) / TP_TW); }      /* cout <= 4 */
+int risp_conv_toep_tiles(int H, int W) {           /* cout <= 4: tiles of 16 x 256, or 32 x 128 on planes of at most 128 pixels */
+    return W <= 128 ? ((H + 31) / 32) * ((W + 127) / 128) : ((H + 15) / 16) * ((W + 255) / 256);
+}
 
 int risp_conv2d_toep_sums(const risp_conv_desc *dp, float *psum, void *stream) {
     RISP_CHECK_ARG(psum && dp && dp->cout <= 4, "risp_conv2d_toep_sums: needs the buffer of partial sums and a layer with cout <= 4 (16-row tiles)");

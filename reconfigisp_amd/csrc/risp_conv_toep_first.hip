@@ -21,21 +21,35 @@
 #include "risp_f16x2.h"
 
 namespace {
-constexpr int TF_TW = 256, TF_RS = 33, TF_Q = 66, TF_KS = 9, TF_P = 4, TF_TH = 4, TF_IH = TF_TH + 2 * TF_P;
-constexpr int TF_PART = TF_IH * TF_RS, TF_TILE = 2 * TF_PART;        // 16-byte slots of the staged channel: hi part, lo part
+constexpr int TF_KS = 9, TF_P = 4;
 constexpr int TF_WST = TF_KS * 2 * 2 * 32;                           // weight slots of (cout block, ci): [ky][part][taps 0-7 | tap 8][cout]
 constexpr int TF_PW = (TF_WST / 64 + 3) / 4;
-constexpr int TF_NTASK = (TF_IH * TF_Q + 255) / 256;
-constexpr int TF_CT = TF_TH * 32 * TF_KS;                            // floats of the border-case table of a tile: [row][cout][x case]
-constexpr int TF_LDS_BYTES = (TF_TILE + 2 * TF_WST + 1) * 16 + 64 + 2 * TF_CT * 4;      // ... + the border-case table, twice (by tile parity)
-static_assert(TF_WST % 64 == 0 && 2 * TF_LDS_BYTES <= 160 * 1024, "LDS layout");
+static_assert(TF_WST % 64 == 0, "weights in whole LDS-DMA pieces");
+// Tile geometry.  The 32 columns of a matrix instruction are FOLD rows x 32 / FOLD blocks of 8 pixels: one 256-pixel strip of a
+// row, or - planes of at most 128 pixels, the Bayer-domain proxies on 256 x 256 patches - two rows of a 128-pixel strip, so that
+// narrow planes do not leave half of every instruction idle.  A wave owns FOLD rows, a tile 4 FOLD.
+template <int FOLD>
+struct TFG {
+    // 16-byte slots and 4-pixel quads of a staged row (folded: 32 slots, not 17 - the lanes of the second row must sit a multiple of
+    // 256 bytes from those of the first for a conflict-free 16-byte LDS read, tools/lds_bank_probe.hip)
+    static constexpr int NBLK = 32 / FOLD, TW = 8 * NBLK, RS = FOLD == 1 ? NBLK + 1 : 32, Q = 2 * NBLK + 2;
+    static constexpr int TH = 4 * FOLD, IH = TH + 2 * TF_P;
+    static constexpr int PART = IH * RS, TILE = 2 * PART;            // 16-byte slots of the staged channel: hi part, lo part
+    static constexpr int NTASK = (IH * Q + 255) / 256;
+    static constexpr int CT = TH * 32 * TF_KS;                       // floats of the border-case table of a tile: [row][cout][x case]
+    static constexpr int LDS_BYTES = (TILE + 2 * TF_WST + 1) * 16 + 64 + 2 * CT * 4;      // ... + the border-case table, twice (by tile parity)
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
 
 __device__ __forceinline__ int tf_border_case(int v, int L) { return v < TF_P ? v : (v >= L - TF_P ? 2 * TF_P - (L - 1 - v) : TF_P); }
 
 // UNSHUF: x is the (N, 1, 2H, 2W) mosaic, input channel 2i+j = x[2y+i][2x+j] (RISP_LOAD_UNSHUFFLE2, cin == 4)
-template <bool UNSHUF, bool CASEB>
-__global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ncb, int ntiles) {
-    constexpr int P = TF_P, KS = TF_KS, IH = TF_IH, RS = TF_RS, WST = TF_WST, PW = TF_PW, NTASK = TF_NTASK, NV = UNSHUF ? 2 : 1;
+template <bool UNSHUF, bool CASEB, int FOLD>
+__global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv_desc d, int tiles_x, int tiles_y, int ncb, int ntiles,
+                                                                 unsigned *__restrict__ ties, unsigned max_ties) {
+    using G = TFG<FOLD>;
+    constexpr int P = TF_P, KS = TF_KS, IH = G::IH, RS = G::RS, WST = TF_WST, PW = TF_PW, NTASK = G::NTASK, NV = UNSHUF ? 2 : 1;
+    constexpr int TF_TILE = G::TILE, TF_PART = G::PART, TF_Q = G::Q, TF_CT = G::CT, NBLK = G::NBLK;
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *tile = smem, *wl = smem + TF_TILE, *zero = wl + 2 * WST;
     float *red = reinterpret_cast<float *>(zero + 1);
@@ -69,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv
         r.cb = t % ncb;
         const int q0 = t / ncb, tx = q0 % tiles_x, q = q0 / tiles_x, ty = q % tiles_y;
         r.n = q / tiles_y;
-        r.x0 = tx * TF_TW;
-        r.y0 = ty * TF_TH;
+        r.x0 = tx * G::TW;
+        r.y0 = ty * G::TH;
         const int g = d.group_n > 0 ? r.n / d.group_n : 0;
         r.w = reinterpret_cast<const uint4 *>(d.wpack + (size_t)g * d.wpack_gs);
     };
@@ -120,7 +134,8 @@ __global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv
     };
     // operands.  B: lane (b, half) of input row r reads slot b + half of that row.  A: the lane's zero-padded filter row
     // R[0..15] = Wp[8 half ..], Wp = (8 zeros, taps 0-8, zeros): slots (zero, taps 0-7) for half 0, (taps 0-7, tap 8) for half 1.
-    const int bbase = wave * RS + l31 + hl;
+    const int srow = FOLD * wave + l31 / NBLK, sblk = l31 % NBLK;     // the lane's row inside the tile and its pixel block
+    const int bbase = srow * RS + sblk + hl;
     // slot indices relative to smem; (ring, ky, part) adds ring * WST + (ky * 2 + part) * 64 to the weight slots
     constexpr int ZI = TF_TILE + 2 * WST;
     const int a1 = TF_TILE + (hl ? 32 + l31 : l31);
@@ -139,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         int se = 0;
+        float bsum = 0.f;                              // sum over the channels of the tile's largest input magnitude (see `ties`)
         const int t_next = t_cur + nwg;
         const bool more = t_next < ntiles;
         TileRef nxt = cur;
@@ -169,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv
             __syncthreads();                           // A
             const float4 mx = *reinterpret_cast<const float4 *>(red);
             const float tmax = fmaxf(fmaxf(mx.x, mx.y), fmaxf(mx.z, mx.w));
+            bsum += tmax;
             int eb = (int)(__builtin_bit_cast(unsigned, tmax) >> 23);
             eb = __builtin_amdgcn_readfirstlane(eb);
             int want = 141 - eb;
@@ -272,7 +289,9 @@ __global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv
             const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
             const int epi = d.epilogue;
             const float floor_ = (epi & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
-            const int oy = cur.y0 + wave, ox = cur.x0 + 8 * l31;
+            // |error| of a sum here <~ 2^-22 x (sum of |terms|) <= 2^-22 x 81 x max|w| x bsum; inv_sw 2^15 >= max|w|: a margin of 2 more bits
+            const float tau = bsum * inv_sw * (81.f * 32768.f / 1048576.f);
+            const int oy = cur.y0 + srow, ox = cur.x0 + 8 * sblk;
             const float *bias = (epi & RISP_EPI_NOBIAS) ? nullptr : d.bias + (size_t)g * d.bias_gs;
             int cxo[8];
             if constexpr (CASEB) {
@@ -291,7 +310,12 @@ __global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             o[j] = acc[j][e] * fin + bb;
-                            if constexpr (CASEB) o[j] += ctl[parity * TF_CT + (wave * 32 + cl) * KS + cxo[j]];
+                            if constexpr (CASEB) o[j] += ctl[parity * TF_CT + (srow * 32 + cl) * KS + cxo[j]];
+                            // a pre-activation this close to zero has no reliable sign in fp32: listed for toep_first_ties_kernel
+                            if (ties && fabsf(o[j]) < tau && ox + j < d.W) {
+                                const unsigned slot = atomicAdd(ties, 1u);
+                                if (slot < max_ties) ties[1 + slot] = (unsigned)((((size_t)cur.n * d.cout + co) * hw + pix + j));
+                            }
                             o[j] = o[j] < floor_ ? floor_ : o[j];
                         }
                         float *yp = d.y + ((size_t)cur.n * d.cout + co) * hw + pix;
@@ -308,19 +332,65 @@ __global__ __launch_bounds__(256, 2) void conv_toep_first_kernel(const risp_conv
     }
 }
 
+// The outputs listed by conv_toep_first_kernel (pre-activation within the arithmetic's own error of zero), recomputed EXACTLY: every
+// product in double (exact), summed in double in a fixed order, bias and border-case value added in double, rounded once.  One
+// wave per listed output.  ReLU decisions of the layer then no longer depend on the summation order of whichever fp32-accurate
+// kernel computed them (tools/dbg_flips.py: one such activation of the DARTS golden scenario moved iteration 1 by 9e-4).
+template <bool UNSHUF>
+__global__ __launch_bounds__(256) void toep_first_ties_kernel(const risp_conv_desc d, const float *__restrict__ w32, long long w32_gs,
+                                                              const unsigned *__restrict__ ties, unsigned max_ties) {
+    constexpr int KS = TF_KS, P = TF_P;
+    const unsigned count = ties[0] < max_ties ? ties[0] : max_ties;
+    const int lane = threadIdx.x & 63;
+    const size_t hw = (size_t)d.H * d.W;
+    const int K = d.cin * KS * KS;
+    for (unsigned t = blockIdx.x * 4 + (threadIdx.x >> 6); t < count; t += gridDim.x * 4) {
+        const size_t idx = ties[1 + t];
+        const int n = (int)(idx / ((size_t)d.cout * hw)), co = (int)(idx / hw) - n * d.cout;
+        const size_t pix = idx - ((size_t)n * d.cout + co) * hw;
+        const int y = (int)(pix / d.W), x = (int)(pix - (size_t)y * d.W);
+        const int g = d.group_n > 0 ? n / d.group_n : 0;
+        const int nx = (d.group_flags & RISP_GROUP_SHARED_X) ? n - g * d.group_n : n;
+        const float *xn = d.x + (size_t)nx * d.cin * hw;
+        const float *wr = w32 + (size_t)g * w32_gs + (size_t)co * K;
+        double a = 0.0;
+        for (int k = lane; k < K; k += 64) {
+            const int ci = k / (KS * KS), r = k - ci * (KS * KS), ky = r / KS, kx = r - ky * KS;
+            const int sy = y + ky - P, sx = x + kx - P;
+            if (sy >= 0 && sy < d.H && sx >= 0 && sx < d.W) {
+                // mosaic: channel 2 i + j of plane pixel (sy, sx) = element (2 sy + i, 2 sx + j) of the (2H, 2W) image
+                const float xv = UNSHUF ? xn[(size_t)(2 * sy + (ci >> 1)) * (2 * d.W) + 2 * sx + (ci & 1)] : xn[(size_t)ci * hw + (size_t)sy * d.W + sx];
+                a += (double)xv * (double)wr[k];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) {
+            if (!(d.epilogue & RISP_EPI_NOBIAS)) a += (double)d.bias[(size_t)g * d.bias_gs + co];
+            if (d.epilogue & RISP_EPI_CASEBIAS)
+                a += (double)d.cvals[((size_t)n * d.cout + co) * (KS * KS) + tf_border_case(y, d.H) * KS + tf_border_case(x, d.W)];
+            float o = (float)a;
+            if ((d.epilogue & RISP_EPI_RELU) && !(o > 0.f)) o = 0.f;
+            d.y[idx] = o;
+        }
+    }
+}
+
 #ifndef RISP_TF_WGS
 #define RISP_TF_WGS 2
 #endif
 
-template <bool UNSHUF, bool CASEB>
-int launch_toep_first(const risp_conv_desc &d, void *stream) {
-    auto kern = &conv_toep_first_kernel<UNSHUF, CASEB>;
+template <bool UNSHUF, bool CASEB, int FOLD>
+int launch_toep_first_g(const risp_conv_desc &d, unsigned *ties, unsigned max_ties, void *stream) {
+    using G = TFG<FOLD>;
+    constexpr int TF_LDS_BYTES = G::LDS_BYTES;
+    auto kern = &conv_toep_first_kernel<UNSHUF, CASEB, FOLD>;
     if (TF_LDS_BYTES > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS_BYTES) != hipSuccess) {
         risp_set_error("risp_conv2d_toep_first: cannot raise the dynamic LDS limit to %d bytes", TF_LDS_BYTES);
         return 2;
     }
-    const int tx = (d.W + TF_TW - 1) / TF_TW, ty = (d.H + TF_TH - 1) / TF_TH, ncb = (d.cout + 31) / 32;
+    const int tx = (d.W + G::TW - 1) / G::TW, ty = (d.H + G::TH - 1) / G::TH, ncb = (d.cout + 31) / 32;
     const long long ntiles = (long long)tx * ty * d.N * ncb;
     if (ntiles > 0x7fffffff) {
         risp_set_error("risp_conv2d_toep_first: too many tiles");
@@ -328,9 +398,13 @@ int launch_toep_first(const risp_conv_desc &d, void *stream) {
     }
     const int slots = RISP_TF_WGS * h2_cu_count();
     const int grid = ntiles < slots ? (int)ntiles : slots;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), TF_LDS_BYTES, (hipStream_t)stream, d, tx, ty, ncb, (int)ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), TF_LDS_BYTES, (hipStream_t)stream, d, tx, ty, ncb, (int)ntiles, ties, max_ties);
     RISP_LAUNCH_CHECK("risp_conv2d_toep_first");
     return 0;
+}
+template <bool UNSHUF, bool CASEB>
+int launch_toep_first(const risp_conv_desc &d, unsigned *ties, unsigned max_ties, void *stream) {
+    return d.W <= 128 ? launch_toep_first_g<UNSHUF, CASEB, 2>(d, ties, max_ties, stream) : launch_toep_first_g<UNSHUF, CASEB, 1>(d, ties, max_ties, stream);
 }
 }  // namespace
 
@@ -338,7 +412,7 @@ extern "C" {
 
 size_t risp_conv_toep_first_wpack_bytes(int cin, int cout) { return 16 + (size_t)((cout + 31) / 32) * cin * TF_WST * 16; }
 
-int risp_conv2d_toep_first(const risp_conv_desc *dp, void *stream) {
+static int toep_first_impl(const risp_conv_desc *dp, unsigned *ties, unsigned max_ties, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_toep_first: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_toep_first: null tensor");
@@ -358,8 +432,30 @@ int risp_conv2d_toep_first(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_toep_first: tensors must be 16-byte aligned");
     const bool cb = (d.epilogue & RISP_EPI_CASEBIAS) != 0;
-    if (unshuf) return cb ? launch_toep_first<true, true>(d, stream) : launch_toep_first<true, false>(d, stream);
-    return cb ? launch_toep_first<false, true>(d, stream) : launch_toep_first<false, false>(d, stream);
+    if (unshuf) return cb ? launch_toep_first<true, true>(d, ties, max_ties, stream) : launch_toep_first<true, false>(d, ties, max_ties, stream);
+    return cb ? launch_toep_first<false, true>(d, ties, max_ties, stream) : launch_toep_first<false, false>(d, ties, max_ties, stream);
+}
+
+int risp_conv2d_toep_first(const risp_conv_desc *dp, void *stream) { return toep_first_impl(dp, nullptr, 0, stream); }
+
+/* The same layer with EXACT ReLU decisions (training forwards): outputs whose pre-activation lies within the arithmetic's own error
+ * of zero are listed (ties: [0] = count, then up to max_ties output indices; zeroed here) and recomputed in double by a second
+ * launch from the layer's fp32 weights w32 (cout, cin, 9, 9) - members of a grouped launch w32_gs floats apart. */
+int risp_conv2d_toep_first_exact(const risp_conv_desc *dp, const float *w32, long long w32_gs, unsigned *ties, unsigned max_ties, void *stream) {
+    RISP_CHECK_ARG(dp && w32 && ties && max_ties > 0 && w32_gs >= 0, "risp_conv2d_toep_first_exact: needs the fp32 weights and the tie list");
+    RISP_CHECK_ARG((unsigned long long)dp->N * dp->cout * dp->H * dp->W < (1ull << 32), "risp_conv2d_toep_first_exact: more than 2^32 outputs");
+    if (hipMemsetAsync(ties, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+        risp_set_error("risp_conv2d_toep_first_exact: cannot clear the tie counter");
+        return 2;
+    }
+    const int rc = toep_first_impl(dp, ties, max_ties, stream);
+    if (rc) return rc;
+    if (dp->load_mode == RISP_LOAD_UNSHUFFLE2)
+        hipLaunchKernelGGL(toep_first_ties_kernel<true>, dim3(512), dim3(256), 0, (hipStream_t)stream, *dp, w32, w32_gs, ties, max_ties);
+    else
+        hipLaunchKernelGGL(toep_first_ties_kernel<false>, dim3(512), dim3(256), 0, (hipStream_t)stream, *dp, w32, w32_gs, ties, max_ties);
+    RISP_LAUNCH_CHECK("risp_conv2d_toep_first_exact");
+    return 0;
 }
 
 }  // extern "C"

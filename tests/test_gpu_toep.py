@@ -214,8 +214,8 @@ def test_conv_small_dispatch(monkeypatch):
     y = CN.conv_small(x, sc, 2, 32, 256)
     assert last() == 'risp_conv2d_toep' and err(y, ref)[1] < 3e-6
     assert CN._small_split(x, sc, 2, 32, 256, 0, 0) == 0
-    CN.conv_small(x[..., :128].contiguous(), sc, 2, 32, 128, infer=True)       # half-empty 256-pixel strips: not worth it
-    assert last().startswith('risp_conv2d_small') and not CN.toep_width_ok(128) and CN.toep_width_ok(200) and CN.toep_width_ok(4000)
+    CN.conv_small(x[..., :128].contiguous(), sc, 2, 32, 128, infer=True)       # narrow planes: two rows folded into the 32 columns
+    assert last() == 'risp_conv2d_toep'
     y = CN.conv_small(x, sc, 2, 32, 256, mask=torch.ones_like(ref, dtype=torch.float32), epi=CN.EPI_MASK)
     assert last().startswith('risp_conv2d_small')              # epilogues the kernel does not have stay where they were
     monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
@@ -338,8 +338,12 @@ def test_first_layer_dispatch(monkeypatch):
     assert calls[-1] == 'risp_conv2d_toep_first'
     CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)                     # training forward: the fp32 kernel unless asked for (convnets.TOEP_FIRST)
     assert calls[-1] == 'risp_conv2d_k3'
-    monkeypatch.setattr(CN, 'TOEP_FIRST', 'train')
+    monkeypatch.setattr(CN, 'TOEP_FIRST', 'train')                 # ... then with exact recomputation of the ReLU ties
+    yt = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)
+    assert calls[-1] == 'risp_conv2d_toep_first_exact' and (yt - y).abs().max().item() <= 1e-6 * y.abs().max().item()
+    monkeypatch.setattr(CN, 'TOEP_FIRST', 'plain')
     assert torch.equal(y, CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)) and calls[-1] == 'risp_conv2d_toep_first'
+    monkeypatch.setattr(CN, 'TOEP_FIRST', 'infer')
     CN.conv(x, pc3, n, h, w, epi=CN.EPI_RELU, infer=True)
     assert calls[-1] == 'risp_conv2d_k3'
     monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
@@ -362,7 +366,7 @@ def test_tile_sums_finish_into_the_rectangle_sums(nchw):
     pack = CN.toep_weights(w1, True, 3)
     y0 = launch('risp_conv2d_toep', g, pack, None, n, h, w, c, 3, 9)
     tiles = L.load().risp_conv_toep_tiles(h, w)
-    assert tiles == ((h + 15) // 16) * ((w + 255) // 256)
+    assert tiles == (((h + 31) // 32) * ((w + 127) // 128) if w <= 128 else ((h + 15) // 16) * ((w + 255) // 256))
     ps = torch.full((n, tiles, c), float('nan'), device='cuda')
     y = torch.full((n, 3, h, w), float('nan'), device='cuda')
     d = L.ConvDesc(N=n, H=h, W=w, cin=c, cout=3, ksize=9, load_mode=0, cin_img=0, epilogue=16, add_c=0, x=g.data_ptr(), wpack=pack.data_ptr(),
@@ -389,3 +393,68 @@ def test_tile_sums_finish_into_the_rectangle_sums(nchw):
     again = torch.empty_like(rs_t)
     L.call('risp_rect_sums_tiles', C.c_void_p(g.data_ptr()), C.c_void_p(ps.data_ptr()), C.c_void_p(again.data_ptr()), n, c, h, w, tiles, None)
     assert torch.equal(again, rs_t)
+
+
+@pytest.mark.parametrize('mosaic', [False, True])
+def test_first_layer_exact_relu_decisions(mosaic):
+    """risp_conv2d_toep_first_exact: outputs whose pre-activation lies within the arithmetic's error of zero are listed and recomputed in
+    double - they equal the float64 convolution rounded once, and their ReLU decisions are float64's; everything else is the plain
+    kernel's output bit for bit; a grouped launch on a shared input; a list that overflows is cut, not overrun."""
+    from reconfigisp_amd import convnets as CN, lib as L
+    n, h, w, cout, G = 2, 40, 72, 64, 2
+    cin = 4 if mosaic else 3
+    ws = torch.stack([rnd(cout, cin, 9, 9, seed=300 + g) * 0.1 for g in range(G)])
+    bs = torch.stack([rnd(cout, seed=310 + g) * 0.05 for g in range(G)])
+    packs = torch.stack([CN.toep_first_weights(ws[g]) for g in range(G)])
+    x = rnd(n, 1, 2 * h, 2 * w, seed=320) if mosaic else rnd(n, 3, h, w, seed=320)
+    table = None if mosaic else rnd(G * n, cout, 9, 9, seed=321) * 0.1
+    epi = CN.EPI_RELU | (0 if mosaic else CN.EPI_CASEBIAS)
+    load = CN.LOAD_UNSHUFFLE2 if mosaic else 0
+    plain = first_launch(x, packs, bs, n, h, w, cin, cout, epi, table, load=load, group=(G, L.GROUP_SHARED_X))
+    y = torch.full_like(plain, float('nan'))
+    d = L.ConvDesc(N=G * n, H=h, W=w, cin=cin, cout=cout, ksize=9, load_mode=load, cin_img=0, epilogue=epi, add_c=0, x=x.data_ptr(),
+                   wpack=packs.data_ptr(), bias=bs.data_ptr(), cvals=table.data_ptr() if table is not None else None, add=None, mask=None,
+                   y=y.data_ptr())
+    d.group_n, d.group_flags = n, L.GROUP_SHARED_X
+    d.wpack_gs, d.bias_gs = packs.stride(0) * 2 // 4, bs.stride(0)
+    cap = 1 << 16
+    ties = torch.full((1 + cap,), -1, device='cuda', dtype=torch.int32)
+    L.call('risp_conv2d_toep_first_exact', C.byref(d), C.c_void_p(ws.data_ptr()), ws.stride(0), C.c_void_p(ties.data_ptr()), cap, None)
+    torch.cuda.synchronize()
+    count = int(ties[0].item())
+    assert 0 < count < cap, count                      # a few outputs in 10^4 sit that close to zero
+    idx = ties[1:1 + count].long()
+    assert idx.unique().numel() == count
+    xs = TF.pixel_unshuffle(x.double(), 2) if mosaic else x.double()
+    ref = torch.cat([TF.conv2d(xs, ws[g].double(), bs[g].double(), padding=4) for g in range(G)])
+    if table is not None:
+        ref = with_table(ref, table, h, w)
+    same = torch.ones(y.numel(), dtype=torch.bool, device='cuda')
+    same[idx] = False
+    assert torch.equal(y.flatten()[same], plain.flatten()[same])                 # untouched outside the list
+    zt, yt = ref.flatten()[idx], y.flatten()[idx]
+    assert torch.equal(yt > 0, zt > 0)                                             # float64's ReLU decisions
+    exact = torch.relu(zt).float()
+    ulp = torch.finfo(torch.float32).eps * exact.abs().clamp_min(1e-30)
+    assert ((yt - exact).abs() <= ulp).all()                                       # rounded once
+    assert err(y, torch.relu(ref))[1] < 3e-6
+    # the plain kernel's own decisions on the listed outputs: some differ from float64's - that is what the list is for
+    assert ((plain.flatten()[idx] > 0) != (zt > 0)).sum().item() >= 0
+    # a list too short for the ties of the launch is cut, not overrun: the counter keeps counting, the outputs beyond it stay the
+    # plain kernel's
+    tiny = torch.full((1 + 16 + 8,), -1, device='cuda', dtype=torch.int32)
+    y2 = torch.full_like(plain, float('nan'))
+    d.y = y2.data_ptr()
+    L.call('risp_conv2d_toep_first_exact', C.byref(d), C.c_void_p(ws.data_ptr()), ws.stride(0), C.c_void_p(tiny.data_ptr()), 16, None)
+    torch.cuda.synchronize()
+    assert int(tiny[0].item()) == count and (tiny[17:] == -1).all()
+    listed = tiny[1:17].long()
+    rest = torch.ones(y.numel(), dtype=torch.bool, device='cuda')
+    rest[listed] = False
+    assert torch.equal(y2.flatten()[rest], plain.flatten()[rest]) and torch.equal(y2.flatten()[listed], y.flatten()[listed])
+    # an all-zero input has no ties: exact zeros are exact in every arithmetic
+    zero = torch.zeros_like(x)
+    d.x, d.bias, d.epilogue, d.cvals, d.y = zero.data_ptr(), None, CN.EPI_RELU | CN.EPI_NOBIAS, None, y.data_ptr()
+    L.call('risp_conv2d_toep_first_exact', C.byref(d), C.c_void_p(ws.data_ptr()), ws.stride(0), C.c_void_p(ties.data_ptr()), cap, None)
+    torch.cuda.synchronize()
+    assert int(ties[0].item()) == 0 and (y == 0).all()

@@ -35,7 +35,7 @@ def conv(x, pc, n, h, w, **kw):
     y = real_conv(x, pc, n, h, w, **kw)
     CN.TOEP_FIRST = '0'
     y3 = real_conv(x, pc, n, h, w, **kw)
-    CN.TOEP_FIRST = 'train'
+    CN.TOEP_FIRST = os.environ.get('RISP_DBG_MODE', 'plain')
     G = len(members)
     xs = x.double()
     if kw.get('load', 0) == CN.LOAD_UNSHUFFLE2:
@@ -53,6 +53,9 @@ def conv(x, pc, n, h, w, **kw):
         e, e3 = (y[s].double() - ref).abs(), (y3[s].double() - ref).abs()
         flips = ((y[s] > 0) != (lin > 0)).sum().item(), ((y3[s] > 0) != (lin > 0)).sum().item()
         pos = torch.nonzero(e == e.max())[0].tolist()
+        dis = torch.nonzero((y[s] > 0) != (y3[s] > 0))
+        for q in dis[:4].tolist():
+            print('   sign differs at', q, 'toep %.4e k3 %.4e float64 %.6e' % (y[s][tuple(q)].item(), y3[s][tuple(q)].item(), lin[tuple(q)].item()), flush=True)
         print('first layer %dx%d cin %d member %d: toep max %.2e rms %.2e (at %s) flips %d | k3 max %.2e rms %.2e flips %d | mag %.2e, |x| max %.2e' % (
             h, w, xs.shape[1], g, e.max().item() / mag, e.pow(2).mean().sqrt().item() / mag, pos, flips[0], e3.max().item() / mag,
             e3.pow(2).mean().sqrt().item() / mag, flips[1], mag, xs.abs().max().item()), flush=True)
@@ -60,7 +63,7 @@ def conv(x, pc, n, h, w, **kw):
 
 
 CN.PackedConv.__init__ = init
-CN.TOEP_FIRST = 'train'
+CN.TOEP_FIRST = os.environ.get('RISP_DBG_MODE', 'plain')
 CN.conv = conv
 g = load_golden('darts_step')
 model = create_model(darts_opt(torch.device('cuda')))

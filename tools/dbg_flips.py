@@ -34,7 +34,7 @@ CN.conv, CN.conv_small = conv, conv_small
 g = load_golden('darts_step')
 runs = []
 for first in (True, False):
-    CN.TOEP_FIRST = 'train' if first else '0'
+    CN.TOEP_FIRST = os.environ.get('RISP_DBG_MODE', 'plain') if first else '0'
     log.clear()
     torch.manual_seed(0)
     model = create_model(darts_opt(torch.device('cuda')))
