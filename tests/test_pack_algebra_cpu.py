@@ -358,3 +358,39 @@ def test_toeplitz_band_pack_reproduces_the_convolution(k, co, ci, tr):
             acc = sum(band[c, ky] @ xp[c, y + ky, 8 * b:8 * b + 16] for c in range(ci) for ky in range(k))
             out[:, y, 8 * b:8 * b + 8] = acc[:8 * co].view(co, 8)
     assert (out - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('co,ci', [(64, 3), (40, 4), (7, 2)])
+def test_first_layer_window_pack_reproduces_the_convolution(co, ci):
+    """convnets.toep_first_weights: header = 1 / s_w, body [cout block][cin][ky][hi, lo][taps 0-7 | tap 8 + zeros][cout][8].  The kernel
+    pads a filter row to (8 zeros, 9 taps, zeros) and takes the operand of pixel position j as slots 8 - j .. 15 - j of the 16 the
+    lane holds (lanes of the upper window half hold the row from slot 8 on): with the window of block b starting 4 pixels left of
+    it, sum_u A_j[u] window[u] is the filter row applied at pixel 8 b + j."""
+    from reconfigisp_amd import convnets as CN
+    torch.manual_seed(co)
+    w = torch.randn(co, ci, 9, 9) * 0.05
+    p = CN.toep_first_weights(w)
+    nb = (co + 31) // 32
+    assert p.dtype == torch.float16 and p.numel() == 8 + nb * ci * 9 * 2 * 2 * 32 * 8
+    inv = p[:2].view(torch.float32).item()
+    body = p[8:].view(nb, ci, 9, 2, 2, 32, 8).double()
+    rows = ((body[:, :, :, 0] + body[:, :, :, 1]) * inv).permute(0, 4, 1, 2, 3, 5).reshape(nb * 32, ci, 9, 16)   # (cout, ci, ky, 16): taps 0-8, zeros
+    assert (rows[:co, :, :, :9] - w.double()).abs().max().item() <= 2.0 ** -22 * w.abs().max().item()
+    assert rows[:, :, :, 9:].abs().max().item() == 0 and (co == nb * 32 or rows[co:].abs().max().item() == 0)
+    padded = torch.cat([torch.zeros(nb * 32, ci, 9, 8, dtype=torch.float64), rows, torch.zeros(nb * 32, ci, 9, 8, dtype=torch.float64)], dim=3)
+    h, wd = 5, 16
+    x = torch.randn(1, ci, h, wd, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(x, w.double(), padding=4)[0]
+    xp = torch.nn.functional.pad(x, (4, 12, 4, 4))[0]
+    out = torch.zeros(co, h, wd, dtype=torch.float64)
+    for y in range(h):
+        for b in range(wd // 8):
+            for j in range(8):
+                acc = torch.zeros(nb * 32, dtype=torch.float64)
+                for c in range(ci):
+                    for ky in range(9):
+                        window = xp[c, y + ky, 8 * b:8 * b + 16]
+                        a_j = torch.cat([padded[:, c, ky, 8 - j:16 - j], padded[:, c, ky, 16 - j:24 - j]], dim=1)     # lower / upper half lanes
+                        acc += a_j @ window
+                out[:, y, 8 * b + j] = acc[:co]
+    assert (out - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
