@@ -395,13 +395,14 @@ def test_tile_sums_finish_into_the_rectangle_sums(nchw):
     assert torch.equal(again, rs_t)
 
 
+@pytest.mark.parametrize('hw', [(40, 72), (20, 260)])            # two rows folded into an instruction's columns / one 256-pixel strip
 @pytest.mark.parametrize('mosaic', [False, True])
-def test_first_layer_exact_relu_decisions(mosaic):
+def test_first_layer_exact_relu_decisions(mosaic, hw):
     """risp_conv2d_toep_first_exact: outputs whose pre-activation lies within the arithmetic's error of zero are listed and recomputed in
     double - they equal the float64 convolution rounded once, and their ReLU decisions are float64's; everything else is the plain
     kernel's output bit for bit; a grouped launch on a shared input; a list that overflows is cut, not overrun."""
     from reconfigisp_amd import convnets as CN, lib as L
-    n, h, w, cout, G = 2, 40, 72, 64, 2
+    n, (h, w), cout, G = 2, hw, 64, 2
     cin = 4 if mosaic else 3
     ws = torch.stack([rnd(cout, cin, 9, 9, seed=300 + g) * 0.1 for g in range(G)])
     bs = torch.stack([rnd(cout, seed=310 + g) * 0.05 for g in range(G)])
