@@ -565,7 +565,11 @@ int launch_f16x2(const risp_conv_desc &d, void *stream) {
 
 template <int KS, int NT>
 int launch_f16x2_epi(const risp_conv_desc &d, void *stream) {
+#ifdef RISP_H2_NOMASK      /* timing experiment only (wrong results): what the fp32 mask reads of the backward-data passes cost */
+    const bool a = (d.epilogue & RISP_EPI_ADD) != 0, m = false;
+#else
     const bool a = (d.epilogue & RISP_EPI_ADD) != 0, m = (d.epilogue & RISP_EPI_MASK) != 0;
+#endif
     return a ? (m ? launch_f16x2<KS, NT, true, true>(d, stream) : launch_f16x2<KS, NT, true, false>(d, stream))
              : (m ? launch_f16x2<KS, NT, false, true>(d, stream) : launch_f16x2<KS, NT, false, false>(d, stream));
 }
