@@ -49,9 +49,23 @@ __global__ __launch_bounds__(256) void bgr_bwd_kernel(const float *__restrict__ 
     float acc[Ctx::NP];
 #pragma unroll
     for (int j = 0; j < Ctx::NP; ++j) acc[j] = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
-        float4 b = xb[i], g = xb[hw4 + i], r = xb[2 * hw4 + i];
-        float4 db = gb[i], dg = gb[hw4 + i], dr = gb[2 * hw4 + i];
+    // the six 16-byte loads of the NEXT vector are issued before this one is worked on: the quadratic white balance holds 186
+    // registers (30 parameter sums) = two waves per SIMD, too few to cover a load round trip per iteration by occupancy alone
+    // (64 x 256 x 256: 63 us = 0.30 of the HBM rate with the loads at the top of the loop)
+    const int step = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 nb, ng, nr, ndb, ndg, ndr;
+    if (i < hw4) {
+        nb = xb[i]; ng = xb[hw4 + i]; nr = xb[2 * hw4 + i];
+        ndb = gb[i]; ndg = gb[hw4 + i]; ndr = gb[2 * hw4 + i];
+    }
+    for (; i < hw4; i += step) {
+        const float4 b = nb, g = ng, r = nr, db = ndb, dg = ndg, dr = ndr;
+        const int j = i + step;
+        if (j < hw4) {
+            nb = xb[j]; ng = xb[hw4 + j]; nr = xb[2 * hw4 + j];
+            ndb = gb[j]; ndg = gb[hw4 + j]; ndr = gb[2 * hw4 + j];
+        }
         f3 o0 = ctx.bwd({b.x, g.x, r.x}, {db.x, dg.x, dr.x}, acc);
         f3 o1 = ctx.bwd({b.y, g.y, r.y}, {db.y, dg.y, dr.y}, acc);
         f3 o2 = ctx.bwd({b.z, g.z, r.z}, {db.z, dg.z, dr.z}, acc);
