@@ -155,6 +155,30 @@ struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR 
         }
         return o;
     }
+    // the input gradient alone (the same operations in the same order as bwd, without the 30 parameter sums)
+    __device__ f3 bwd_gx(f3 x, f3 gy) const {
+        float f[10];
+        feats(x, f);
+        float g[3] = {gy.b * gate01(pre(f, 0)), gy.g * gate01(pre(f, 1)), gy.r * gate01(pre(f, 2))};
+        f3 o = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            o.b += g[ch] * (2.f * x.b * c[ch][0] + x.g * c[ch][3] + x.r * c[ch][4] + c[ch][6]);
+            o.g += g[ch] * (2.f * x.g * c[ch][1] + x.b * c[ch][3] + x.r * c[ch][5] + c[ch][7]);
+            o.r += g[ch] * (2.f * x.r * c[ch][2] + x.b * c[ch][4] + x.g * c[ch][5] + c[ch][8]);
+        }
+        return o;
+    }
+    // ... and the parameter sums alone
+    __device__ void bwd_gp(f3 x, f3 gy, float *acc) const {
+        float f[10];
+        feats(x, f);
+        float g[3] = {gy.b * gate01(pre(f, 0)), gy.g * gate01(pre(f, 1)), gy.r * gate01(pre(f, 2))};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[ch * 10 + j] += g[ch] * f[j];
+    }
     __device__ static float pscale(int) { return 10.f; }
     __host__ __device__ static int prow(int n) { return n; }
 };

@@ -214,15 +214,19 @@ __global__ __launch_bounds__(256) void slot_mix_fwd_kernel(const risp_slot_mix_d
 constexpr int SO_WM = RISP_MAX_MIX, SO_GA = SO_WM + 3, SO_GT = SO_GA + 1, SO_WQ = SO_GT + 3, SO_G3 = SO_WQ + 30;
 static_assert(SO_G3 + 3 == RISP_SLOT_ROW, "row layout");
 
-template <bool WBQ>
+// WBQ: 0 = no quadratic white balance in the slot; 1 = with it, its 30 parameter sums carried here (256 registers: one wave per
+// SIMD, 0.34 of the HBM rate); 2 = with it, input gradient only - the 30 sums come from slot_wbq_params_kernel, which reads x and
+// gy once more (24 of ~250 B/pixel) at five waves per SIMD.  Same operations in the same order per thread and the same block
+// partition: the same bits.
+template <int WBQ>
 __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy,
                                                            float *__restrict__ gx, float *__restrict__ part, int hw4) {
-    constexpr int NACC = WBQ ? RISP_SLOT_ROW : RISP_SLOT_ROW - 30;       // without WbQuadratic its 30 slots are not carried
-    constexpr int G3 = WBQ ? SO_G3 : SO_WQ;
+    constexpr int NACC = WBQ == 1 ? RISP_SLOT_ROW : RISP_SLOT_ROW - 30;       // without WbQuadratic's sums its 30 slots are not carried
+    constexpr int G3 = WBQ == 1 ? SO_G3 : SO_WQ;
     __shared__ float red[RISP_SLOT_ROW * 4];
     const int n = blockIdx.y;
     WbManualCtx wm; GammaCtx ga; GtmCtx gt; WbqCtx wq; float g3[3] = {0.f, 0.f, 0.f};
-    slot_contexts<WBQ>(d, n, wm, ga, gt, wq, g3);
+    slot_contexts<WBQ != 0>(d, n, wm, ga, gt, wq, g3);
     // operand index of each element-wise kind (-1: absent); the element-wise input gradients are added in KIND order
     // (skip, white balance, gamma, tone curve, quadratic, gray-world gain) - a fixed order, whatever the operand order
     int at[RISP_OP_GAIN3 + 1];
@@ -286,9 +290,11 @@ __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_d
             if (at[RISP_OP_WB_MANUAL] >= 0) term(RISP_OP_WB_MANUAL, wm.fwd(px), wm.bwd(px, up(RISP_OP_WB_MANUAL), acc + SO_WM));
             if (at[RISP_OP_GAMMA] >= 0) term(RISP_OP_GAMMA, ga.fwd(px), ga.bwd(px, up(RISP_OP_GAMMA), acc + SO_GA));
             if (at[RISP_OP_GTM_MANUAL] >= 0) term(RISP_OP_GTM_MANUAL, gt.fwd(px), gt.bwd(px, up(RISP_OP_GTM_MANUAL), acc + SO_GT));
-            if constexpr (WBQ) {
+            if constexpr (WBQ == 1) {
                 if (at[RISP_OP_WB_QUADRATIC] >= 0)
                     term(RISP_OP_WB_QUADRATIC, wq.fwd(px), wq.bwd(px, up(RISP_OP_WB_QUADRATIC), acc + SO_WQ));
+            } else if constexpr (WBQ == 2) {
+                if (at[RISP_OP_WB_QUADRATIC] >= 0) term(RISP_OP_WB_QUADRATIC, wq.fwd(px), wq.bwd_gx(px, up(RISP_OP_WB_QUADRATIC)));
             }
             if (at[RISP_OP_GAIN3] >= 0) term(RISP_OP_GAIN3, gain3_fwd(g3, px), gain3_bwd(g3, px, up(RISP_OP_GAIN3), acc + G3));
             ob_[q] = sx.b; og_[q] = sx.g; or_[q] = sx.r;
@@ -309,12 +315,57 @@ __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_d
         float *row = part + ((size_t)n * gridDim.x + blockIdx.x) * RISP_SLOT_ROW;
 #pragma unroll
         for (int j = 0; j < SO_WQ; ++j) row[j] = acc[j];
-        if constexpr (WBQ) {
+        if constexpr (WBQ == 1) {
 #pragma unroll
             for (int j = 0; j < 30; ++j) row[SO_WQ + j] = acc[SO_WQ + j] * 10.f;       // WbqCtx::pscale
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) row[SO_G3 + j] = acc[G3 + j];
+    }
+}
+
+// The 30 parameter sums of the slot's quadratic white balance (see slot_mix_bwd_kernel, WBQ = 2): slots SO_WQ .. SO_WQ + 29 of the
+// same partial rows.  The loads of the next vector are issued before the current one is worked on.
+__global__ __launch_bounds__(256) void slot_wbq_params_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy, float *__restrict__ part,
+                                                              int hw4) {
+    __shared__ float red[30 * 4];
+    const int n = blockIdx.y;
+    int at = -1;
+    for (int k = 0; k < d.K; ++k)
+        if (d.kind[k] == RISP_OP_WB_QUADRATIC) at = k;
+    if (at < 0) return;
+    const WbqCtx wq(d.ptr[at], n);
+    const float w = d.w[at];
+    const size_t base = (size_t)n * 3 * hw4;
+    const float4 *xb = reinterpret_cast<const float4 *>(d.x) + base;
+    const float4 *gb = reinterpret_cast<const float4 *>(gy) + base;
+    float acc[30];
+#pragma unroll
+    for (int j = 0; j < 30; ++j) acc[j] = 0.f;
+    const int step = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 nb, ng, nr, ndb, ndg, ndr;
+    if (i < hw4) {
+        nb = xb[i]; ng = xb[hw4 + i]; nr = xb[2 * hw4 + i];
+        ndb = gb[i]; ndg = gb[hw4 + i]; ndr = gb[2 * hw4 + i];
+    }
+    for (; i < hw4; i += step) {
+        const float4 b = nb, g = ng, r = nr, db = ndb, dg = ndg, dr = ndr;
+        const int j = i + step;
+        if (j < hw4) {
+            nb = xb[j]; ng = xb[hw4 + j]; nr = xb[2 * hw4 + j];
+            ndb = gb[j]; ndg = gb[hw4 + j]; ndr = gb[2 * hw4 + j];
+        }
+        wq.bwd_gp({b.x, g.x, r.x}, {db.x * w, dg.x * w, dr.x * w}, acc);
+        wq.bwd_gp({b.y, g.y, r.y}, {db.y * w, dg.y * w, dr.y * w}, acc);
+        wq.bwd_gp({b.z, g.z, r.z}, {db.z * w, dg.z * w, dr.z * w}, acc);
+        wq.bwd_gp({b.w, g.w, r.w}, {db.w * w, dg.w * w, dr.w * w}, acc);
+    }
+    block_sum<30>(acc, red);
+    if (threadIdx.x == 0) {
+        float *row = part + ((size_t)n * gridDim.x + blockIdx.x) * RISP_SLOT_ROW;
+#pragma unroll
+        for (int j = 0; j < 30; ++j) row[SO_WQ + j] = acc[j] * 10.f;                   // WbqCtx::pscale
     }
 }
 
@@ -444,8 +495,17 @@ int risp_slot_mix_bwd(const risp_slot_mix_desc *d, const float *gy, float *gx, f
     RISP_CHECK_ARG(gy && gw && scratch && (gx || !pw) && ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0,
                    "risp_slot_mix_bwd: null or unaligned argument");
     const int hw4 = d->HW / 4, bx = risp_bwd_blocks(d->N, d->HW);
-    if (wbq) hipLaunchKernelGGL(slot_mix_bwd_kernel<true>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
-    else hipLaunchKernelGGL(slot_mix_bwd_kernel<false>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
+#ifndef RISP_SLOT_WBQ_ONE_PASS
+#define RISP_SLOT_WBQ_ONE_PASS 0      /* A/B switch (tools/ab_build.sh): 1 = the 30 sums inside the main backward kernel */
+#endif
+    if (wbq && RISP_SLOT_WBQ_ONE_PASS) {
+        hipLaunchKernelGGL(slot_mix_bwd_kernel<1>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
+    } else if (wbq) {
+        hipLaunchKernelGGL(slot_mix_bwd_kernel<2>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
+        hipLaunchKernelGGL(slot_wbq_params_kernel, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, scratch, hw4);
+    } else {
+        hipLaunchKernelGGL(slot_mix_bwd_kernel<0>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
+    }
     int elems = d->K;
     for (int k = 0; k < d->K; ++k) {
         const int np = d->kind[k] == RISP_OP_WB_MANUAL || d->kind[k] == RISP_OP_GTM_MANUAL || d->kind[k] == RISP_OP_GAIN3 ? 3 :
