@@ -34,7 +34,7 @@ ALG = [('origin_demosaic_kernel<false>', 'demosaic bilinear', 16), ('origin_demo
        ('param_finish_kernel', 'parameter-gradient finish', 0), ('chain_kernel', 'nearest demosaic (chain of 1)', 16),
        ('mix_fwd_kernel', 'mixture forward, 8 operands', 108), ('mix_bwd_kernel', 'mixture backward, 8 operands', 204), ('mix_finish_kernel', 'mixture alpha-gradient finish', 0),
        ('slot_mix_fwd_kernel', 'fused slot mixture forward (9 tensors + 6 element-wise)', 132), ('slot_mix_bwd_kernel', 'fused slot mixture backward', 252),
-       ('slot_mix_finish_kernel', 'fused slot mixture finish', 0)]
+       ('slot_wbq_params_kernel', 'fused slot mixture backward: the 30 WbQuadratic sums (second launch)', 24), ('slot_mix_finish_kernel', 'fused slot mixture finish', 0)]
 f = glob.glob(os.path.join(root, 'prof', '**', '*kernel_stats.csv'), recursive=True)
 with open(os.path.join(root, 'summary.txt'), 'w') as out:
     out.write('# tools/profile_ops.sh: rocprofv3 kernel durations at 64 x 256 x 256 (4.19 MPix); rate = algorithmic bytes (tensors read + written once) / duration\n')
