@@ -308,7 +308,7 @@ int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
  * wpack: risp_conv_f16x2_wpack_bytes() bytes, 16-byte aligned: a 16-byte header whose first float is 1 / s_w (s_w = 2^k with
  * max|w| s_w in [2^14, 2^15)), then [chunk of 16 cin][tap][part: hi, lo][channel half][cout padded to 32 or 64][8 channels]
  * _Float16 (reconfigisp_amd/convnets.py::f16x2_weights).  ksize 3 or 5, cin % 16 == 0, cout 32 or 64, add_c == cout, W % 4 == 0,
- * fewer than 2^30 elements per image, 16-byte aligned tensors, load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS; grouped
+ * max(cin, cout) * H * W * 4 < 2^31 bytes per image, 16-byte aligned tensors, load_mode PLAIN; epilogue RELU | ADD | MASK | NOBIAS; grouped
  * launches (group_n, strides in floats).  A tile's result does not depend on the batch it travels in. */
 size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
@@ -463,17 +463,23 @@ typedef struct risp_list_desc {
  * (no gradient arrived, or an alpha copied to the twin network).  Operation by operation the reference's arithmetic. */
 int risp_darts_virtual_step(const risp_list_desc *d, float momentum, float lr_meta, void *stream);
 /* out[0] = 2-norm of the concatenation of the c[t] (NULL entries skipped), out[1] = eps = out[0] < 1e-6 ? 0 : 0.01 / out[0]
- * (:274-277); fixed summation order. */
+ * (:274-277); fixed summation order.  Lists longer than RISP_MAX_LIST go through risp_list_norm_eps_part in pieces: first = 0
+ * continues from the sum of squares the previous piece left in out[0]; last = 0 leaves the running sum of squares there instead of
+ * finishing (risp_list_norm_eps = one piece with first = last = 1). */
 int risp_list_norm_eps(const risp_list_desc *d, float *out, void *stream);
+int risp_list_norm_eps_part(const risp_list_desc *d, float *out, int first, int last, void *stream);
 /* a[t] += (factor * scalar[0]) * c[t] (c NULL: untouched): the +eps, -2 eps, +eps shifts of the parameters (:299-312) with
  * eps on the device. */
 int risp_list_axpy_scalar(const risp_list_desc *d, const float *scalar, float factor, void *stream);
 /* The optimizers of the search (darts_model.py:78-81) over the table, in place, as torch.optim writes them (no weight decay,
  * dampening, nesterov, amsgrad): SGD with momentum - e = momentum buffers: e = first ? c : e * momentum + c; a -= lr * e - and
- * Adam - b = exp_avg, e = exp_avg_sq (both updated), lr_step = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t).  Rows whose
- * gradient c is NULL are left alone. */
+ * Adam - b = exp_avg, e = exp_avg_sq (both updated), lr_step = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t),
+ * one_minus_beta = (float)(1 - beta) formed in double like torch's lerp_ / addcmul_ weights.  The denominator is
+ * sqrt(exp_avg_sq) / bias2_sqrt + eps with a true division (torch's list-wide CUDA form; its CPU form multiplies by the
+ * reciprocal: 1 ulp apart).  Rows whose gradient c is NULL are left alone. */
 int risp_sgd_momentum_step(const risp_list_desc *d, float lr, float momentum, int first, void *stream);
-int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float bias2_sqrt, float eps, void *stream);
+int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
+                   float bias2_sqrt, float eps, void *stream);
 /* architecture gradient, :254-265 with :313-323: a = b - lr_meta * ((c - e) / 2 * eps[0]); zeros where b, c or e is NULL or
  * the finite-difference term holds a NaN (nan_flags[t] = 1 there; may be NULL).  numel <= 256. */
 int risp_darts_alpha_grad(const risp_list_desc *d, const float *eps, float lr_meta, int *nan_flags, void *stream);
@@ -505,6 +511,8 @@ typedef struct risp_train_desc {
     int N, H, W;                                  /* H, W even */
     float lr_step;                                /* lr / (1 - beta1^t), t = this step's number (1-based) */
     float beta1, beta2;
+    float one_minus_beta1, one_minus_beta2;       /* (float)(1 - beta): formed in double and rounded once, as torch forms the
+                                                     weights of lerp_ / addcmul_ (1.f - 0.999f is 1.3e-5 off float(0.001)) */
     float bias2_sqrt;                             /* sqrt(1 - beta2^t) */
     float eps;
     float *loss;                                  /* 1 float: the mean loss of this step */

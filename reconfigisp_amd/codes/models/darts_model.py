@@ -34,7 +34,9 @@ logger = logging.getLogger('base')
 
 class PixelLoss(nn.Module):
     """nn.MSELoss ('l2') / nn.L1Loss ('l1') of the reference (:58-63) - loss and gradient in one pass on the device
-    (functional.pixel_loss); tensors the kernel does not take (numel % 4 != 0, unaligned views, other dtypes) go to torch."""
+    (functional.pixel_loss); tensors the kernel does not take (numel % 4 != 0, unaligned views, other dtypes) and a target that
+    itself needs a gradient (the kernel returns none for it) go to torch.  CPU tensors raise, like every other operator of this
+    build (no CPU fallback); a second-order pass through the loss raises as well (the gradient is formed once, as a constant)."""
 
     def __init__(self, kind):
         super().__init__()
@@ -42,7 +44,7 @@ class PixelLoss(nn.Module):
 
     def forward(self, out, gt):
         if (out.dtype == torch.float32 and gt.dtype == torch.float32 and out.shape == gt.shape and out.numel() % 4 == 0
-                and out.is_contiguous() and gt.is_contiguous() and (out.data_ptr() | gt.data_ptr()) % 16 == 0):
+                and not gt.requires_grad and out.is_contiguous() and gt.is_contiguous() and (out.data_ptr() | gt.data_ptr()) % 16 == 0):
             return F.pixel_loss(out, gt, self.kind)
         return nn.functional.mse_loss(out, gt) if self.kind == 'l2' else nn.functional.l1_loss(out, gt)
 
@@ -227,14 +229,20 @@ class DartsModel(BaseModel):
         self._allreduce_mean([p.grad for p in self.netG_attr.trainable_parameters])
         self.optimizer_G.step()
         self.log_dict['loss'] = l_pix.item()
-        flags, self._nan_flags = getattr(self, '_nan_flags', None), None
-        if flags is not None:                       # (the queue is drained by the read-out above anyway)
-            for idx, bad in enumerate(flags.tolist()):
-                if bad:
-                    print('Warning: NaN in hessian, for the {}-th alpha'.format(idx + 1))
+        self._report_nan_flags()                    # (the queue is drained by the read-out above anyway)
         if self.is_latency:
             self.log_dict['latency'] = self.latency.item()
             self.log_dict['latency_term'] = self.latency_term.item()
+
+    def _report_nan_flags(self):
+        """The reference prints its NaN warning inside optimize_alphas() (:258-261); here the flags of an architecture step are read
+        where the iteration next synchronises - the loss read-out of optimize_parameters(), or the start of the next
+        optimize_alphas() when no weight step came in between - so no warning is lost or overwritten."""
+        flags, self._nan_flags = getattr(self, '_nan_flags', None), None
+        if flags is not None:
+            for idx, bad in enumerate(flags.tolist()):
+                if bad:
+                    print('Warning: NaN in hessian, for the {}-th alpha'.format(idx + 1))
 
     # ------------------------------------------------------------------ architecture step
     def virtual_step(self):
@@ -276,6 +284,7 @@ class DartsModel(BaseModel):
                 self.netG_attr.end_reuse()
 
     def _optimize_alphas(self):
+        self._report_nan_flags()                    # a previous architecture step that no weight step followed
         self.optimizer_alpha.zero_grad()
         self.virtual_step()
         loss = self._loss(self.netV, self.val_img, self.val_gt, self.val_glb_flag, self.cri_pix_v)[0]

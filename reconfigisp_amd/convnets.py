@@ -197,6 +197,14 @@ if CONV_ARITH not in ('f16x2', 'f32'):
     raise ValueError("RISP_CONV_ARITH must be 'f16x2' or 'f32', got %r" % CONV_ARITH)
 
 
+def f16x2_addressable(cin, cout, h, w):
+    """``risp_conv2d_f16x2`` addresses an image through buffer resources of 2^31 - 1 bytes whose range check covers the per-lane
+    offset: pixel + up to 16 input planes on the way in, pixel + the cout plane on the way out (residual / mask rows alike).  Every
+    such offset stays below 2^31 iff max(cin, cout) * H * W * 4 < 2^31 (the entry point checks the same bound); larger images -
+    an untiled 3000 x 4000 frame through a 64-channel layer - take the fp32 kernels with their 64-bit addresses."""
+    return max(cin, cout) * h * w * 4 < (1 << 31)
+
+
 def _wino5_pack(w, transpose):
     return wino5_weights(w, transpose, L.load().risp_conv_wino5_chunk())
 
@@ -476,7 +484,7 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     wpack = wino if use_wino else (pc.bwd if transpose else pc.fwd)
     h2 = getattr(pc, 'f16x2_bwd' if transpose else 'f16x2_fwd', None)
     if (CONV_ARITH == 'f16x2' and h2 is not None and plain16 and (add is None or add_c == cout)
-            and max(cin, cout) * h * w < (1 << 30)):
+            and f16x2_addressable(cin, cout, h, w)):
         # wide 3x3 / 5x5 layer: split precision on the f16 matrix pipe (same tensors, same epilogue flags, its own pack)
         wpack, entry, use_wino = h2, 'risp_conv2d_f16x2', True
     if (K3 and getattr(pc, 'k3', None) is not None and not transpose and w % 4 == 0 and h >= pc.k - 1 and w >= pc.k - 1

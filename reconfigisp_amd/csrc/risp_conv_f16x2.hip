@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(const risp_conv_desc
         const int c = cc < P ? cc : H2_TW + cc;
         dstc[k] = id < IH * 2 * P * 8 ? (((cp >> 2) * IH + ir) * RS + (c & 3) * S + (c >> 2)) * 16 + (cp & 3) * 4 : -1;
     }
-    const unsigned hw4 = (unsigned)hw * 4u;                                 // bytes of a plane (max(cin, cout) * H * W < 2^30: checked by the entry point)
+    // bytes of a plane.  max(cin, cout) * H * W * 4 < 2^31 (checked by the entry point): every lane offset below - pixel + up to 16
+    // planes on the way in, pixel + cout plane on the way out - stays inside the 2^31 - 1 bytes that h2_rsrc's range check covers
+    const unsigned hw4 = (unsigned)hw * 4u;
     // the tile being staged: image / member, cout block, corner; its tensors as the launch's group layout has them
     struct TileRef {
         int n, cb, x0, y0;
@@ -598,10 +600,10 @@ int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_f16x2: null tensor");
     RISP_CHECK_GROUP(d, "risp_conv2d_f16x2");
     RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cin % H2_CK == 0 && (d.cout == 32 || d.cout == 64) &&
-                       (d.ksize == 3 || d.ksize == 5) && (unsigned long long)(d.cout > d.cin ? d.cout : d.cin) * d.H * d.W < (1ull << 30) &&
+                       (d.ksize == 3 || d.ksize == 5) && (unsigned long long)(d.cout > d.cin ? d.cout : d.cin) * d.H * d.W * 4ull < (1ull << 31) &&
                        (!(d.epilogue & RISP_EPI_ADD) || d.add_c == d.cout),
-                   "risp_conv2d_f16x2: needs a 3x3 or 5x5 layer, cin %% 16 == 0, cout 32 or 64 (= add_c), W %% 4 == 0, fewer than 2^30 "
-                   "elements per image (N=%d H=%d W=%d cin=%d cout=%d k=%d)",
+                   "risp_conv2d_f16x2: needs a 3x3 or 5x5 layer, cin %% 16 == 0, cout 32 or 64 (= add_c), W %% 4 == 0, fewer than 2^31 "
+                   "bytes per image on either side (N=%d H=%d W=%d cin=%d cout=%d k=%d)",
                    d.N, d.H, d.W, d.cin, d.cout, d.ksize);
     RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_f16x2: only plain loads");
     RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(64) void virtual_step_kernel(const risp_list_desc d
 }
 
 // norm = || concatenation of c[t] ||_2 (one workgroup, index order), eps = norm < 1e-6 ? 0 : 0.01 / norm  (:276-277)
-__global__ __launch_bounds__(256) void norm_eps_kernel(const risp_list_desc d, float *__restrict__ out) {
+// first = 0: continue from the sum of squares a previous piece left in out[0]; last = 0: leave the running sum of squares there
+__global__ __launch_bounds__(256) void norm_eps_kernel(const risp_list_desc d, float *__restrict__ out, int first, int last) {
     __shared__ float red[4];
     float s = 0.f;
     for (int t = 0; t < d.n; ++t) {
@@ -73,7 +74,13 @@ __global__ __launch_bounds__(256) void norm_eps_kernel(const risp_list_desc d, f
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        float sq = (red[0] + red[1]) + (red[2] + red[3]);
+        if (!first) sq = out[0] + sq;
+        if (!last) {
+            out[0] = sq;
+            return;
+        }
+        const float norm = sqrtf(sq);
         out[0] = norm;
         out[1] = norm < 1e-6f ? 0.f : 0.01f / norm;
     }
@@ -130,8 +137,10 @@ __global__ __launch_bounds__(64) void sgd_momentum_kernel(const risp_list_desc d
 // torch.optim.Adam (no weight decay / amsgrad), one wave per tensor, as torch writes it:
 //   exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
 //   denom = exp_avg_sq.sqrt() / sqrt(1 - beta2^t) + eps; param.addcdiv_(exp_avg, denom, value = -lr / (1 - beta1^t))
-// a = p, c = g, b = exp_avg, e = exp_avg_sq (b and e updated in place)
-__global__ __launch_bounds__(64) void adam_kernel(const risp_list_desc d, float lr_step, float beta1, float beta2, float bias2_sqrt, float eps) {
+// a = p, c = g, b = exp_avg, e = exp_avg_sq (b and e updated in place); w1 = (float)(1 - beta1), w2 = (float)(1 - beta2) formed in
+// double by the caller, as torch forms them (within an ulp of torch.optim.Adam per step, not bit-equal: torch's CPU form multiplies
+// by the reciprocal of sqrt(1 - beta2^t) where this divides, and its fused multiply-adds are the compiler's choice)
+__global__ __launch_bounds__(64) void adam_kernel(const risp_list_desc d, float lr_step, float w1, float beta2, float w2, float bias2_sqrt, float eps) {
     const int t = blockIdx.x;
     float *p = d.a[t], *ea = const_cast<float *>(d.b[t]), *es = const_cast<float *>(d.e[t]);
     const float *g = d.c[t];
@@ -139,8 +148,8 @@ __global__ __launch_bounds__(64) void adam_kernel(const risp_list_desc d, float 
     for (int i = threadIdx.x; i < d.numel[t]; i += 64) {
         const float grad = g[i];
         float m = ea[i], v = es[i];
-        m = __builtin_fmaf(1.f - beta1, grad - m, m);
-        v = __builtin_fmaf((1.f - beta2) * grad, grad, v * beta2);
+        m = __builtin_fmaf(w1, grad - m, m);
+        v = __builtin_fmaf(w2 * grad, grad, v * beta2);
         const float denom = __builtin_sqrtf(v) / bias2_sqrt + eps;
         ea[i] = m;
         es[i] = v;
@@ -189,12 +198,14 @@ int risp_darts_virtual_step(const risp_list_desc *d, float momentum, float lr_me
     return 0;
 }
 
-int risp_list_norm_eps(const risp_list_desc *d, float *out, void *stream) {
+int risp_list_norm_eps_part(const risp_list_desc *d, float *out, int first, int last, void *stream) {
     RISP_CHECK_ARG(d && out && d->n >= 0 && d->n <= RISP_MAX_LIST, "risp_list_norm_eps: 0..%d tensors, an output of 2 floats", RISP_MAX_LIST);
-    hipLaunchKernelGGL(norm_eps_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d, out);
+    hipLaunchKernelGGL(norm_eps_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d, out, first, last);
     RISP_LAUNCH_CHECK("risp_list_norm_eps");
     return 0;
 }
+
+int risp_list_norm_eps(const risp_list_desc *d, float *out, void *stream) { return risp_list_norm_eps_part(d, out, 1, 1, stream); }
 
 int risp_list_axpy_scalar(const risp_list_desc *d, const float *scalar, float factor, void *stream) {
     if (int st = check_list(d, "risp_list_axpy_scalar", 1 << 20)) return st;
@@ -214,11 +225,13 @@ int risp_sgd_momentum_step(const risp_list_desc *d, float lr, float momentum, in
     return 0;
 }
 
-int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float bias2_sqrt, float eps, void *stream) {
+int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
+                   float bias2_sqrt, float eps, void *stream) {
+    (void)beta1;
     if (int st = check_list(d, "risp_adam_step", 1 << 20)) return st;
     for (int t = 0; t < d->n; ++t) RISP_CHECK_ARG(d->b[t] && d->e[t], "risp_adam_step: tensor %d has no moment buffers", t);
     if (d->n == 0) return 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, lr_step, beta1, beta2, bias2_sqrt, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(d->n), dim3(64), 0, (hipStream_t)stream, *d, lr_step, one_minus_beta1, beta2, one_minus_beta2, bias2_sqrt, eps);
     RISP_LAUNCH_CHECK("risp_adam_step");
     return 0;
 }

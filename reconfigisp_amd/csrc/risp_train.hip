@@ -220,8 +220,8 @@ __global__ __launch_bounds__(64) void train_finish_kernel(const risp_train_desc 
     //   exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
     //   denom = exp_avg_sq.sqrt() / sqrt(1 - beta2^t) + eps; param.addcdiv_(exp_avg, denom, value = -lr / (1 - beta1^t))
     float m = a.exp_avg[k][j], v = a.exp_avg_sq[k][j];
-    m = __builtin_fmaf(1.f - a.beta1, grad - m, m);
-    v = __builtin_fmaf((1.f - a.beta2) * grad, grad, v * a.beta2);
+    m = __builtin_fmaf(a.one_minus_beta1, grad - m, m);
+    v = __builtin_fmaf(a.one_minus_beta2 * grad, grad, v * a.beta2);
     const float denom = __builtin_sqrtf(v) / a.bias2_sqrt + a.eps;
     raw = raw - a.lr_step * (m / denom);
     if (lane == 0) {

@@ -550,6 +550,7 @@ class _PixelLoss(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, gl):
         g, = ctx.saved_tensors
         return (g * gl if g is not None else None), None, None
@@ -601,10 +602,13 @@ class _HipImpl:
     @staticmethod
     def list_norm_eps(tensors):
         """(2,) device tensor: the 2-norm of the concatenated tensors (None skipped) and eps = 0 if norm < 1e-6 else 0.01 / norm"""
-        live = [t for t in tensors if t is not None]
-        out = torch.empty(2, device=live[0].device, dtype=torch.float32)
-        d, _keep = _tensor_table([(t, None, t, None) for t in live], 0)
-        L.call('risp_list_norm_eps', C.byref(d), _p(out), _stream())
+        live = [t for t in tensors if t is not None and t.numel()]
+        dev = next(t.device for t in tensors if t is not None)
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        pieces = [live[at: at + L.LIST_MAX] for at in range(0, len(live), L.LIST_MAX)] or [[]]
+        for k, piece in enumerate(pieces):          # any number of tensors (torch.cat(...).norm() has no limit): pieces of LIST_MAX
+            d, _keep = _tensor_table([(t, None, t, None) for t in piece], 0)
+            L.call('risp_list_norm_eps_part', C.byref(d), _p(out), int(k == 0), int(k == len(pieces) - 1), _stream())
         return out
 
     @staticmethod
@@ -620,8 +624,9 @@ class _HipImpl:
         """rows of (out, dalpha or None, pos or None, neg or None) -> out = dalpha - lr_meta * (pos - neg) / 2 * eps, zeros where an
         input is missing or the finite-difference term holds a NaN; returns the (len(rows),) int32 NaN flags (on the device)"""
         flags = torch.zeros(len(rows), device=rows[0][0].device, dtype=torch.int32)
-        d, _keep = _tensor_table(rows, 0)
-        L.call('risp_darts_alpha_grad', C.byref(d), _p(eps), float(lr_meta), C.c_void_p(flags.data_ptr()), _stream())
+        for at in range(0, len(rows), L.LIST_MAX):
+            d, _keep = _tensor_table(rows[at: at + L.LIST_MAX], 0)
+            L.call('risp_darts_alpha_grad', C.byref(d), _p(eps), float(lr_meta), C.c_void_p(flags.data_ptr() + 4 * at), _stream())
         _written([r[0] for r in rows])
         return flags
 

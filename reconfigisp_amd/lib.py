@@ -47,7 +47,7 @@ class TrainDesc(C.Structure):
                 ('blocks', _f * TRAIN_MAX), ('raw', _f * TRAIN_MAX), ('grad', _f * TRAIN_MAX),
                 ('exp_avg', _f * TRAIN_MAX), ('exp_avg_sq', _f * TRAIN_MAX), ('loss_kind', _i),
                 ('N', _i), ('H', _i), ('W', _i), ('lr_step', _fl), ('beta1', _fl), ('beta2', _fl),
-                ('bias2_sqrt', _fl), ('eps', _fl), ('loss', _f), ('scratch', _f)]
+                ('one_minus_beta1', _fl), ('one_minus_beta2', _fl), ('bias2_sqrt', _fl), ('eps', _fl), ('loss', _f), ('scratch', _f)]
 
 
 PARAM_OPS_MAX = 16
@@ -177,10 +177,11 @@ SIGNATURES = {
     'risp_pixel_loss': (_i, [_f, _f, _f, _f, _f, _z, _i, _s]),
     'risp_darts_virtual_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _s]),
     'risp_list_norm_eps': (_i, [C.POINTER(ListDesc), _f, _s]),
+    'risp_list_norm_eps_part': (_i, [C.POINTER(ListDesc), _f, _i, _i, _s]),
     'risp_list_axpy_scalar': (_i, [C.POINTER(ListDesc), _f, _fl, _s]),
     'risp_darts_alpha_grad': (_i, [C.POINTER(ListDesc), _f, _fl, _f, _s]),
     'risp_sgd_momentum_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _i, _s]),
-    'risp_adam_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _fl, _fl, _fl, _s]),
+    'risp_adam_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _fl, _fl, _fl, _fl, _fl, _s]),
     'risp_train_scratch_floats': (_z, [_i]),
     'risp_chain_train_step': (_i, [C.POINTER(TrainDesc), _s]),
 }

@@ -154,6 +154,7 @@ class FusedIspStep:
         d.N, d.H, d.W = n, h, w
         d.lr_step = lr / (1.0 - beta1 ** step)
         d.beta1, d.beta2, d.bias2_sqrt, d.eps = beta1, beta2, math.sqrt(1.0 - beta2 ** step), eps
+        d.one_minus_beta1, d.one_minus_beta2 = 1.0 - beta1, 1.0 - beta2            # in double, rounded once (torch's lerp_ / addcmul_ weights)
         d.loss, d.scratch = F._p(loss), F._p(plan['scratch'])
         L.call('risp_chain_train_step', C.byref(d), F._stream())
         for st in states:

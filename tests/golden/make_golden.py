@@ -642,8 +642,35 @@ def gold_losses():
     npz('losses', **out)
 
 
+# ---------------------------------------------------------------- 12. the option surface (options/options.py:8-62)
+def gold_options():
+    """The reference's ``options.parse`` on its nine shipped YAMLs (train/* with is_train=True, test/* with False): the DERIVED
+    fields (phase / data_type / mode after '_mc' stripping per dataset, meta_device, every path.* with the install root folded,
+    the debug overrides) and a hash of the whole parsed tree - tests/golden/option_canon.py.  No YAML text is stored."""
+    import glob
+    import json
+    import contextlib
+    import io
+    import options.options as RO
+    sys.path.insert(0, HERE)
+    from option_canon import canonical
+    out = {}
+    saved = os.environ.get('CUDA_VISIBLE_DEVICES')
+    for f in sorted(glob.glob(os.path.join(REF, 'options', '*', '*.yml'))):
+        rel = os.path.relpath(f, os.path.join(REF, 'options'))
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = RO.parse(f, is_train=rel.startswith('train'))
+        out[rel] = canonical(opt)
+    if saved is None:
+        os.environ.pop('CUDA_VISIBLE_DEVICES', None)
+    else:
+        os.environ['CUDA_VISIBLE_DEVICES'] = saved
+    assert len(out) == 9, sorted(out)
+    npz('options', table=np.array(json.dumps(out, sort_keys=True)))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls',
-                             'f64', 'losses']
+                             'f64', 'losses', 'options']
     for w in which:
         globals()['gold_' + w]()

@@ -394,3 +394,23 @@ def test_first_layer_window_pack_reproduces_the_convolution(co, ci):
                         acc += a_j @ window
                 out[:, y, 8 * b + j] = acc[:co]
     assert (out - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+
+
+def test_f16x2_buffer_offsets_stay_inside_the_resource():
+    """risp_conv2d_f16x2 range-checks per-lane byte offsets against 2^31 - 1 (risp_f16x2.h::h2_rsrc): the largest offset a lane forms
+    - the last pixel of the last input plane a staging task reads, or of the last cout plane the epilogue stores / reads the residual
+    and mask rows at - must stay below 2^31 for everything convnets.f16x2_addressable() lets through, and an untiled 3000 x 4000
+    frame through a 64-channel layer (cout planes past 2 GiB: their stores would be dropped silently) must be refused."""
+    def largest_offset(cin, cout, h, w):
+        hw4 = 4 * h * w
+        stage = 14 * hw4 + hw4 + (hw4 - 16)          # channel pair 7 of a chunk (2 cp planes), + 1 plane, + the pixel
+        store = (cout - 1) * hw4 + (hw4 - 16)
+        return max(stage, store)
+
+    for cin, cout, h, w in ((64, 64, 256, 256), (64, 64, 1448, 1448), (64, 32, 2048, 2044), (16, 64, 2896, 2892), (64, 64, 2048, 4092)):
+        ok = CN.f16x2_addressable(cin, cout, h, w)
+        assert ok == (largest_offset(cin, cout, h, w) < (1 << 31) and max(cin, cout) * h * w * 4 < (1 << 31)), (cin, cout, h, w)
+    assert CN.f16x2_addressable(64, 64, 2048, 4092)                   # 2^31 - 2^21 bytes: the largest tile class that fits
+    assert not CN.f16x2_addressable(64, 64, 2048, 4096)               # exactly 2^31
+    assert not CN.f16x2_addressable(64, 64, 3000, 4000)               # the frame of test_split.py, untiled
+    assert not CN.f16x2_addressable(64, 32, 3000, 4000)
