@@ -312,6 +312,11 @@ int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
  * launches (group_n, strides in floats).  A tile's result does not depend on the batch it travels in. */
 size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
+/* Diagnostics (A/B timing in one process, tests): which kernel serves risp_conv2d_f16x2 - 1 (default) = the wave-specialised
+ * form of round 5 (one 8-wave workgroup per CU: four waves stage tiles and weights a chunk ahead, four issue the matrix
+ * instructions), 0 = the round-4 form (two 4-wave workgroups per CU, every wave does both).  Same arithmetic in the same
+ * order: the two give identical bits.  Returns the previous setting; any other argument only queries. */
+int risp_conv_f16x2_variant(int v);
 
 /* The same arithmetic for layers with at most 4 output channels and a 5- or 9-tap filter row (round 4; SRCNNRes conv 5x5 32 -> 3,
  * srcnn_res_arch.py:22; backward-data of its 9x9 first layer restricted to the 3 image channels, :18; backward-data of

@@ -53,23 +53,6 @@ struct H2 {
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
-__device__ __forceinline__ float comp(const float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
-
-// hi / lo halves of 8 scaled values -> two 16-byte slots
-__device__ __forceinline__ void split8(const float (&a)[8], float s, uint4 &hi, uint4 &lo) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float a0 = a[2 * e] * s, a1 = a[2 * e + 1] * s;
-        const h2 hh = {(_Float16)a0, (_Float16)a1};
-        const h2 ll = {(_Float16)(a0 - (float)hh[0]), (_Float16)(a1 - (float)hh[1])};
-        h[e] = __builtin_bit_cast(unsigned, hh);
-        l[e] = __builtin_bit_cast(unsigned, ll);
-    }
-    hi = make_uint4(h[0], h[1], h[2], h[3]);
-    lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
 #ifdef RISP_H2_STAMPS
 #define H2STAMP(v) do { __builtin_amdgcn_s_waitcnt(0xC07F); v = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -575,9 +558,18 @@ int launch_f16x2_epi(const risp_conv_desc &d, void *stream) {
     return a ? (m ? launch_f16x2<KS, NT, true, true>(d, stream) : launch_f16x2<KS, NT, true, false>(d, stream))
              : (m ? launch_f16x2<KS, NT, false, true>(d, stream) : launch_f16x2<KS, NT, false, false>(d, stream));
 }
+int g_h2_variant = 1;                                  // risp_conv_f16x2_variant()
 }  // namespace
 
+int risp_launch_f16x2_ws(const risp_conv_desc &d, void *stream);      // risp_conv_f16x2_ws.hip
+
 extern "C" {
+
+int risp_conv_f16x2_variant(int v) {
+    const int old = g_h2_variant;
+    if (v == 0 || v == 1) g_h2_variant = v;
+    return old;
+}
 
 #ifdef RISP_H2_STAMPS
 int risp_conv_f16x2_occupancy(void) {                 // diagnostic builds only: resident workgroups per CU
@@ -614,6 +606,7 @@ int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
                      reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_f16x2: tensors must be 16-byte aligned");
+    if (g_h2_variant == 1) return risp_launch_f16x2_ws(d, stream);      // the wave-specialised form (same bits)
     if (d.ksize == 5) return launch_f16x2_epi<5, 1>(d, stream);         // one cout block per tile: 64 couts = two tiles per pixel tile
     return d.cout == 64 ? launch_f16x2_epi<3, 2>(d, stream) : launch_f16x2_epi<3, 1>(d, stream);
 }

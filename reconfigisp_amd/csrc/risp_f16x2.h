@@ -49,6 +49,23 @@ __device__ __forceinline__ float amax4(float m, const float4 &v) {
     return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
 }
 
+__device__ __forceinline__ float comp(const float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+// hi / lo halves of 8 scaled values -> two 16-byte slots
+__device__ __forceinline__ void split8(const float (&a)[8], float s, uint4 &hi, uint4 &lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a0 = a[2 * e] * s, a1 = a[2 * e + 1] * s;
+        const h2 hh = {(_Float16)a0, (_Float16)a1};
+        const h2 ll = {(_Float16)(a0 - (float)hh[0]), (_Float16)(a1 - (float)hh[1])};
+        h[e] = __builtin_bit_cast(unsigned, hh);
+        l[e] = __builtin_bit_cast(unsigned, ll);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 #define H2_WAIT_VM(keep) __builtin_amdgcn_s_waitcnt(0x0F70 | ((keep) & 15) | (((keep) >> 4) << 14))      /* s_waitcnt vmcnt(keep) */
 
 inline int h2_cu_count() {

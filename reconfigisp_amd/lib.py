@@ -142,6 +142,7 @@ SIGNATURES = {
     'risp_conv_wino45_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino45': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_f16x2_wpack_bytes': (_z, [_i, _i, _i]),
+    'risp_conv_f16x2_variant': (_i, [_i]),
     'risp_conv2d_f16x2': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_toep_wpack_bytes': (_z, [_i, _i, _i]),
     'risp_conv2d_toep': (_i, [C.POINTER(ConvDesc), _s]),
