@@ -81,8 +81,10 @@ class ErrorBudget:
     and the fixed summation order of the reductions.  Checks are collected; ``finish()`` fails with the full list
     (RISP_BUDGET_REPORT=1 prints every measured pair with its ratio)."""
 
-    def __init__(self, factor=2.0, atol=4e-6, bar=1e-4, outliers=1):
-        self.factor, self.atol, self.bar, self.outliers, self.rows = factor, atol, bar, outliers, []
+    def __init__(self, factor=2.0, atol=4e-6, bar=1e-4, outliers=1, members=4):
+        # ``members``: how many tensors ONE outlier event may hold (a flipped mask bit reaches the architecture gradient of its own slot
+        # and of the slots upstream: at most n_step + 2 = 4 .. 5 vectors, usually fewer) - a regression that is broad still fails
+        self.factor, self.atol, self.bar, self.outliers, self.members, self.rows = factor, atol, bar, outliers, members, []
 
     def __call__(self, got, ref32, ref64, what='', family=None, event=None):
         """``event``: members that one cause perturbs together count as ONE outlier (a ReLU mask flipped in one operator of a
@@ -116,6 +118,10 @@ class ErrorBudget:
                 bad.append('%s: |hip - fp64| = %.3e of the tensor\'s magnitude; reference fp32: %.3e (family %s: %.3e)' % (
                     what, e_got, e_ref, family, fam[family]))
         for family, events in over.items():
+            for event, names in events.items():
+                if len(names) > self.members:
+                    bad.append('family %s, %s: %d tensors cost more than %.1f x their own reference error (one event may hold %d): %s' % (
+                        family, event, len(names), self.factor, self.members, ', '.join(names)))
             if len(events) > self.outliers:
                 bad.append('family %s: %d events cost more than %.1f x their own reference error (at most %d may): %s' % (
                     family, len(events), self.factor, self.outliers, '; '.join(', '.join(m) for m in events.values())))

@@ -343,6 +343,136 @@ def gold_darts():
     npz('darts_step', **out)
 
 
+# ---------------------------------------------------------------- 6b. DARTS scenarios chosen for what they can pin (round 5)
+def _darts_opt(n_step):
+    from collections import OrderedDict
+    return OrderedDict(model='darts', gpu_ids=None, dist=False, is_train=True,
+                       network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=n_step, n_modules=15, prune_threshold=0.2),
+                       path=dict(pretrain_model_G=None, strict_load=True),
+                       train=dict(lr_G=1e-2, momentum_G=0.9, lr_meta=1e-2, beta1=0.9, beta2=0.99, pixel_criterion='l2',
+                                  lr_scheme='MultiStepLR', lr_steps=[1000], restarts=None, restart_weights=None, lr_gamma=0.5,
+                                  clear_state=False))
+
+
+def _darts_scenario(n_step, batch, size, seed, double=False, iters=2, margins=None):
+    """Two iterations (optimize_alphas + optimize_parameters, models/darts_model.py:159-324) of the imported reference on seeded data
+    (inputs / targets from seeds seed .. seed + 3, proxies as in gold_darts).  ``double``: the same graph in float64 (gold_f64's shims).
+    ``margins``: a list that receives, per ReLU call, min |pre-activation| / max |pre-activation|."""
+    import models.darts_model as DM
+    old_float = torch.Tensor.float
+    if double:
+        torch.Tensor.float = lambda self, *a, **k: self
+    try:
+        model = DM.DartsModel(_darts_opt(n_step))
+        for net in (model.netG, model.netV):
+            seed_supernet(net, 1000)
+            with torch.no_grad():
+                net.alpha_demosaic[3] = -20.0
+            if double:
+                _to_double(net)
+        if margins is not None:
+            def pre(_m, inp):
+                x = inp[0].detach().abs()
+                margins.append((x.min() / x.max()).item())
+            for net in (model.netG, model.netV):
+                for mods in net.all_modules:
+                    for m in mods:
+                        for r in m.modules():
+                            if isinstance(r, nn.ReLU):
+                                r.register_forward_pre_hook(pre)
+        data = [rnd(batch, 1, size, size, seed=seed), rnd(batch, 3, size, size, seed=seed + 1),
+                rnd(batch, 1, size, size, seed=seed + 2), rnd(batch, 3, size, size, seed=seed + 3)]
+        out = dict(zip(('img', 'gt', 'val_img', 'val_gt'), data))
+        if double:
+            data = [t.double() for t in data]
+        for it in range(iters):
+            model.feed_data(tuple(data))
+            model.update_learning_rate(it, warmup_iter=-1)
+            model.optimize_alphas()
+            out['it%d_val_loss' % it] = model.val_loss.detach().clone()
+            for k, a in enumerate(model.netG.alphas):
+                out['it%d_alpha_grad%d' % (it, k)] = a.grad.clone()
+            model.optimize_parameters()
+            out['it%d_loss' % it] = np.array(model.log_dict['loss'], np.float64 if double else np.float32)
+            for k, v in model.netG.named_parameters():              # what the weight step's backward() left in .grad (:173)
+                if k.startswith('param_') and v.grad is not None:
+                    out['it%d_pgrad_%s' % (it, k)] = v.grad.detach().clone()
+            for k, v in model.netG.state_dict().items():
+                out['it%d_%s' % (it, k)] = v.detach().clone()
+        return out
+    finally:
+        torch.Tensor.float = old_float
+
+
+def _scenario_distance(a, b):
+    """largest deviation between two runs of a scenario over every recorded quantity, relative to the tensor's largest magnitude
+    (the -20 logit of DemosaicNet excluded: Adam turns its 1e-8 gradient into a step of arbitrary sign)"""
+    worst, where = 0.0, ''
+    for k in a:
+        if not k.startswith('it'):
+            continue
+        x, y = torch.as_tensor(a[k]).double(), torch.as_tensor(b[k]).double()
+        if k.endswith('alpha_demosaic'):
+            x, y = x[:3], y[:3]
+        if x.numel():
+            dv = ((x - y).abs().max() / (y.abs().max() + 1e-30)).item()
+            if dv > worst:
+                worst, where = dv, k
+    return worst, where
+
+
+def gold_darts_kf():
+    """``darts_step_kf`` (+ ``_f64``): gold_darts' scenario (n_step 2, batch 2, 16 x 16) on the first data seed for which the reference
+    ITSELF is insensitive to its arithmetic - fp32 with oneDNN convolutions, fp32 with torch's native convolutions, fp32 on one thread
+    (different summation splits) and float64 all agree to 1e-5 of every recorded tensor's magnitude over both iterations.  Why: a ReLU
+    whose pre-activation sits within rounding of zero hands its mask bit to whichever arithmetic evaluates it, and one such bit moves an
+    architecture gradient by 1e-4 .. 1e-3 here (gold_darts' seed 40 has one at 3.6e-9 of its layer: the reference's own fp32 and
+    float64 runs are 3.7e-4 apart on it).  A scenario on which four arithmetics of the reference agree pins the STEP LOGIC at the 1e-4
+    bar without pinning one implementation's coin tosses; the criterion never looks at this build.  (A margin on every pre-activation,
+    as for the CNN fixtures, is not available: 1.8e7 of them per scenario put the smallest at ~1e-8 of its layer for every seed.)"""
+    for seed in range(100, 400, 4):
+        margins = []
+        base = _darts_scenario(2, 2, 16, seed, margins=margins)
+        d64 = _darts_scenario(2, 2, 16, seed, double=True)
+        worst = [_scenario_distance(base, d64)]
+        if worst[0][0] <= 1e-5:
+            with torch.backends.mkldnn.flags(enabled=False):
+                worst.append(_scenario_distance(_darts_scenario(2, 2, 16, seed), base))
+            torch.set_num_threads(1)
+            worst.append(_scenario_distance(_darts_scenario(2, 2, 16, seed), base))
+            torch.set_num_threads(4)
+        print('  seed %d: %s' % (seed, ', '.join('%.1e (%s)' % w for w in worst)))
+        if len(worst) == 3 and max(w[0] for w in worst) <= 1e-5:
+            break
+    else:
+        raise RuntimeError('no arithmetic-insensitive DARTS scenario found')
+    extra = dict(data_seed=np.array(seed), arithmetic_spread=np.array([w[0] for w in worst]),
+                 smallest_relu_margin=np.array(min(margins)), relu_calls=np.array(len(margins)))
+    npz('darts_step_kf', **base, **extra)
+    npz('darts_step_kf_f64', **{k: v for k, v in d64.items() if k.startswith('it')})
+
+
+def gold_darts_n3():
+    """``darts_step_n3`` (+ ``_f64``): the reference's SHIPPED search geometry - options/train/SID_search.yml:16-17,31-32 and
+    S7ISP_search.yml:16-17,27-28: n_step 3 (5 slots), batch_size 4, data_size 48, prune_threshold 0.2 - two iterations of
+    models/darts_model.py:159-324.  At this size (5e8 ReLU pre-activations per scenario) no seed is free of consequential ties: over
+    seeds 300 .. 324 the reference's fp32 run is 0.9e-4 .. 1.8e-3 from its own float64 run.  The fixture is the seed where that
+    distance is smallest (RISP_GOLD_N3_SEED: skip the search), stored with its float64 twin so that tests judge
+    |hip - fp64| against |reference fp32 - fp64| (tests/test_gpu_error_budget.py) rather than against a bar the reference misses."""
+    forced = os.environ.get('RISP_GOLD_N3_SEED')
+    best = None
+    for seed in ([int(forced)] if forced else range(300, 328, 4)):
+        base = _darts_scenario(3, 4, 48, seed)
+        d64 = _darts_scenario(3, 4, 48, seed, double=True)
+        dist = _scenario_distance(base, d64)
+        print('  seed %d: fp32 vs float64 %.2e (%s)' % (seed, dist[0], dist[1]))
+        if best is None or dist[0] < best[0][0]:
+            best = (dist, seed, base, d64)
+    dist, seed, base, d64 = best
+    npz('darts_step_n3', **base, data_seed=np.array(seed), fp32_vs_f64=np.array(dist[0]))
+    npz('darts_step_n3_f64', **{k: v for k, v in d64.items() if k.startswith('it')})
+
+
 # ---------------------------------------------------------------- 7. tiling + metrics
 def gold_tiling():
     img = rnd(50, 77, 3, seed=50).numpy()
@@ -671,6 +801,6 @@ def gold_options():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls',
-                             'f64', 'losses', 'options']
+                             'f64', 'losses', 'options', 'darts_kf', 'darts_n3']
     for w in which:
         globals()['gold_' + w]()

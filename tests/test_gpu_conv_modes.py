@@ -283,7 +283,32 @@ def test_srcnn_res_folded_equals_unfolded(P, hw):
         y = fn.apply(x, pv, packs)
         y.backward(gy)
         res.append((y.detach(), x.grad, pv.grad))
+    # The two paths are two fp32 arithmetics of the same layers (the folded first layer even decides its ReLU ties exactly, convnets.
+    # TOEP_FIRST): a pre-activation within rounding of zero may be clipped by one and passed by the other, and the input gradient then
+    # differs by O(1) over that activation's footprint (9 x 9 for the first layer, 13 x 13 through it for the second).  Ties are
+    # located with a float64 evaluation; the comparison holds everywhere outside their footprints (typically everywhere).
+    with torch.no_grad():
+        xd = x0.double()
+        feat = torch.cat([xd.amin(dim=(2, 3)), xd.mean(dim=3).mean(dim=2), xd.amax(dim=(2, 3)), pv0.double()], dim=1)
+        pre1 = TF.conv2d(torch.cat([xd, feat[:, :, None, None].expand(-1, -1, h, w)], dim=1), seq[0].weight.double(), seq[0].bias.double(), padding=4)
+        pre2 = TF.conv2d(torch.relu(pre1), seq[2].weight.double(), seq[2].bias.double(), padding=2)
+        tie = lambda pre: (pre.abs() < 2e-6 * pre.abs().max()).any(dim=1, keepdim=True).float()      # ~10 x the kernels' rounding
+        near = (TF.max_pool2d(tie(pre1), 9, 1, 4) + TF.max_pool2d(tie(pre2), 13, 1, 6)) > 0            # (n, 1, h, w)
+        # ... and the pixels that hold a channel's minimum / maximum: the gradient of the min / max planes (srcnn_res_arch.py:36-40) lands
+        # there, and a flipped activation changes it by that activation's whole contribution
+        flat = x0.flatten(2)
+        for i in range(n):
+            if near[i].any():
+                for pos in torch.cat([flat[i].argmin(dim=1), flat[i].argmax(dim=1)]).tolist():
+                    near[i, 0, pos // w, pos % w] = True
+    assert h * w < 1000 or near.float().mean().item() < 0.25           # (a tie's footprint covers most of a tiny image)
     for a, b, what in zip(res[0], res[1], ('output', 'input grad', 'param grad')):
+        if what == 'input grad':
+            a, b = torch.where(near, torch.zeros_like(a), a), torch.where(near, torch.zeros_like(b), b)
+        if what == 'param grad':                       # a sum over the image: an image with a tie carries that activation's whole share
+            tied = torch.tensor([bool(near[i].any()) for i in range(n)], device=a.device)
+            assert_close(a[tied], b[tied], what=what + ' (images with a ReLU tie)', rtol=2e-2, floor=1.0)
+            a, b = a[~tied], b[~tied]
         assert_close(a, b, what=what, rtol=2e-4, floor=1.0)
 
 

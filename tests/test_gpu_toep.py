@@ -334,16 +334,21 @@ def test_first_layer_dispatch(monkeypatch):
     x = rnd(n, 3, h, w, seed=150)
     pc9, pc3 = CN.PackedConv(rnd(64, 3, 9, 9, seed=151) * 0.1, rnd(64, seed=152)), CN.PackedConv(rnd(64, 3, 3, 3, seed=153) * 0.1, rnd(64, seed=154))
     monkeypatch.setattr(CN.L, 'call', spy)
+    assert CN.TOEP_FIRST == 'train'                                # the default: one first-layer kernel for inference and training
     y = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU, infer=True)
     assert calls[-1] == 'risp_conv2d_toep_first'
-    CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)                     # training forward: the fp32 kernel unless asked for (convnets.TOEP_FIRST)
-    assert calls[-1] == 'risp_conv2d_k3'
-    monkeypatch.setattr(CN, 'TOEP_FIRST', 'train')                 # ... then with exact recomputation of the ReLU ties
-    yt = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)
+    yt = CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)                # training forward: the same kernel + exact recomputation of the ReLU ties
     assert calls[-1] == 'risp_conv2d_toep_first_exact' and (yt - y).abs().max().item() <= 1e-6 * y.abs().max().item()
+    assert ((yt > 0) != (y > 0)).float().mean().item() < 1e-4     # ... which can only move outputs that sit on the kink
+    monkeypatch.setattr(CN, 'TOEP_FIRST', 'infer')                 # round 4's default: training forwards on the fp32 kernel
+    CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)
+    assert calls[-1] == 'risp_conv2d_k3'
     monkeypatch.setattr(CN, 'TOEP_FIRST', 'plain')
     assert torch.equal(y, CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU)) and calls[-1] == 'risp_conv2d_toep_first'
-    monkeypatch.setattr(CN, 'TOEP_FIRST', 'infer')
+    monkeypatch.setattr(CN, 'TOEP_FIRST', '0')
+    CN.conv(x, pc9, n, h, w, epi=CN.EPI_RELU, infer=True)
+    assert calls[-1] == 'risp_conv2d_k3'
+    monkeypatch.setattr(CN, 'TOEP_FIRST', 'train')
     CN.conv(x, pc3, n, h, w, epi=CN.EPI_RELU, infer=True)
     assert calls[-1] == 'risp_conv2d_k3'
     monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')

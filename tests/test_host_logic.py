@@ -136,10 +136,10 @@ def test_registry_errors():
         ['path_bayer', 'laplacian', 'gamma', 'wbquadratic', 'wbmanual']
 
 
-def darts_opt(dev):
+def darts_opt(dev, n_step=2):
     from collections import OrderedDict
     return OrderedDict(model='darts', gpu_ids=[0] if dev.type == 'cuda' else None, dist=False, is_train=True,
-                       network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=2, n_modules=15,
+                       network_G=dict(which_model_G='SuperPruneFifteenDemosFourBayerTwo', n_step=n_step, n_modules=15,
                                       prune_threshold=0.2, module_path=None),
                        path=dict(pretrain_model_G=None, strict_load=True),
                        train=dict(lr_G=1e-2, momentum_G=0.9, lr_meta=1e-2, beta1=0.9, beta2=0.99,
@@ -156,11 +156,29 @@ def seed_darts(model):
             net.alpha_demosaic[3] = -20.0
 
 
+# The DARTS fixtures (tests/golden/make_golden.py): 'darts_step_kf' - the 4-slot scenario on a data seed where four arithmetics of the
+# reference itself (oneDNN / native / one-thread fp32, float64) agree to 1e-5, so the 1e-4 bar judges the step logic and not a ReLU
+# coin toss; 'darts_step_n3' - the reference's shipped search geometry (SID_search.yml:16-17,31-32: n_step 3, batch 4, 48 x 48, prune
+# 0.2), where the reference's own fp32 run is 0.9e-4 from its float64 run (no tie-free seed exists at that size: ref_rtol adds the
+# golden's own distance); 'darts_step' - the round-1 scenario, which holds one first-layer pre-activation at 3.6e-9 of its layer: kept
+# as the regression of the fp32 first-layer route (RISP_CONV_TOEP_FIRST=0), whose rounding happens to take the reference's side of it.
+DARTS_FIXTURES = [('darts_step_kf', 2, None), ('darts_step_n3', 3, None), ('darts_step', 2, '0')]
+
+
 @pytest.mark.filterwarnings('ignore:Detected call of')
-def test_darts_search_step_matches_reference(dev):
+@pytest.mark.parametrize('fixture,n_step,toep_first', DARTS_FIXTURES, ids=[f[0] for f in DARTS_FIXTURES])
+def test_darts_search_step_matches_reference(dev, fixture, n_step, toep_first, monkeypatch):
     from reconfigisp_amd.codes.models import create_model
-    g, g64 = load_golden('darts_step'), load_golden('darts_step_f64')
-    model = create_model(darts_opt(dev))
+    from reconfigisp_amd import convnets as CN
+    if toep_first is not None:
+        monkeypatch.setattr(CN, 'TOEP_FIRST', toep_first)
+    g, g64 = load_golden(fixture), load_golden(fixture + '_f64')
+    if dev.type == 'cuda' and float(g.get('fp32_vs_f64', 0.0)) > 2e-5:
+        # a scenario on which the reference's fp32 run is ~1e-4 from its own float64 run cannot hold a tensor-by-tensor fp32-vs-fp32 bar
+        # for ANY second implementation; the kernels are judged on it against float64 (tests/test_gpu_error_budget.py), the step logic
+        # here on the seam, where the oracle's arithmetic is torch's own
+        pytest.skip('judged against the float64 run in test_gpu_error_budget.py::test_darts_iterations_within_budget')
+    model = create_model(darts_opt(dev, n_step))
     seed_darts(model)
     data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
     for it in range(2):
