@@ -332,6 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
     for (int i = 0; i < 2 * NH; ++i) WS_BARRIER_LDS();                 // chunks -2 and -1: the producers fill the pipeline
     WS_LAP(c_bar);
     int g = 0;
+    int want_next = ws_want(red);                                      // chunk 0's exponent; later ones are read a phase ahead (below)
     for (int k = 0; k < my_tiles; ++k) {
         WsTile cur;
         locate(wg + k * nwg, cur);
@@ -344,7 +345,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
                 for (int e = 0; e < 16; ++e) acc[t][b][e] = 0.f;
         int se = 0;                                                    // running exponent: the accumulators hold sum * 2^se * s_w
         for (int ch = 0; ch < nchunks; ++ch, ++g) {
-            const int want = ws_want(red + 4 * (g & 3));
+            const int want = want_next;
+            // the next chunk's maxima were published a phase ago (visible since the barrier that opened this phase): read them now, off
+            // the critical path of the next phase's head (after the walk's last chunk: a stale row, unused)
+            want_next = ws_want(red + 4 * ((g + 1) & 3));
             if (ch == 0) {
                 se = want;
             } else if (want < se) {                                    // larger values than before: rescale the running sums (exact)
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
             }
         }
         // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias), as in conv_f16x2_kernel: one 16-byte store per cout and lane, 16 lanes =
-        // 256 contiguous bytes of a cout row; residual / mask rows in few large batches, each in front of its own stores
+        // 256 contiguous bytes of a cout row
         {
             const int oy = cur.y0 + wave + 4 * (l31 >> 4), ox = cur.x0 + 4 * (l31 & 15);
             const int na = (d.group_flags & RISP_GROUP_SHARED_ADD) ? cur.n - cur.g * d.group_n : cur.n;
@@ -439,16 +443,24 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
             const __amdgpu_buffer_rsrc_t ra = h2_rsrc(HAS_ADD ? d.add + (size_t)na * d.add_c * hw : d.x);
             const __amdgpu_buffer_rsrc_t rm = h2_rsrc(HAS_MASK ? d.mask + (size_t)cur.n * d.cout * hw : d.x);
             const float *bias_row = lbias + (k & 1) * 64 + 4 * hl;
-            constexpr int EB = (HAS_ADD && HAS_MASK) ? 8 : 16, NB = 16 * NT / EB;
-            float4 av[HAS_ADD ? EB : 1], mv[HAS_MASK ? EB : 1];
-#pragma unroll
-            for (int g2 = 0; g2 < NB; ++g2) {
+            // gfx9 counts loads and stores in ONE in-order counter: a load issued behind a store returns only when that store has
+            // completed.  The residual / mask rows therefore come in batches through two register sets, the loads of batch k + 1 issued
+            // IN FRONT of the stores of batch k: they queue behind the stores of batch k - 1 only, and that round trip passes while batch
+            // k is formed and stored (the round-4 epilogue loaded a batch behind the previous batch's stores and waited it out).
+            constexpr int EB = (HAS_ADD && HAS_MASK) ? 4 : 8, NB = 16 * NT / EB;
+            float4 av[2][HAS_ADD ? EB : 1], mv[2][HAS_MASK ? EB : 1];
+            auto fetch_rows = [&](int g2, int buf) {
 #pragma unroll
                 for (int kk = 0; kk < EB; ++kk) {
                     const int c = g2 * EB + kk, cu = (c >> 4) * 32 + 8 * ((c >> 2) & 3) + (c & 3);
-                    if (HAS_ADD) av[kk] = h2_load16(ra, loff, (unsigned)cu * hw4e);
-                    if (HAS_MASK) mv[kk] = h2_load16(rm, loff, (unsigned)cu * hw4e);
+                    if (HAS_ADD) av[buf][kk] = h2_load16(ra, loff, (unsigned)cu * hw4e);
+                    if (HAS_MASK) mv[buf][kk] = h2_load16(rm, loff, (unsigned)cu * hw4e);
                 }
+            };
+            if (HAS_ADD || HAS_MASK) fetch_rows(0, 0);
+#pragma unroll
+            for (int g2 = 0; g2 < NB; ++g2) {
+                if ((HAS_ADD || HAS_MASK) && g2 + 1 < NB) fetch_rows(g2 + 1, (g2 + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < EB; ++kk) {
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
                     const float bb = bias_row[cu];
                     float4 o = make_float4(acc[0][b][e] * fin + bb, acc[1][b][e] * fin + bb, acc[2][b][e] * fin + bb, acc[3][b][e] * fin + bb);
                     if (HAS_ADD) {
-                        const float4 a4 = av[kk];
+                        const float4 a4 = av[g2 & 1][kk];
                         o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
                     }
                     o.x = o.x < floor_ ? floor_ : o.x;                  // ReLU, or nothing (floor = -inf); a NaN stays a NaN (torch.relu)
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
                     o.z = o.z < floor_ ? floor_ : o.z;
                     o.w = o.w < floor_ ? floor_ : o.w;
                     if (HAS_MASK) {
-                        const float4 mk = mv[kk];
+                        const float4 mk = mv[g2 & 1][kk];
                         o.x = mk.x > 0.f ? o.x : 0.f;
                         o.y = mk.y > 0.f ? o.y : 0.f;
                         o.z = mk.z > 0.f ? o.z : 0.f;
