@@ -155,15 +155,22 @@ def kernel_time_ms(net, batches, reps, device, isp):
     return e0.elapsed_time(e1) / reps
 
 
+def launched_kernel():
+    """the instance of the fused kernel a bench step launches, as rocprofv3 names it (asked of the library, not assumed)"""
+    from reconfigisp_amd import lib as L
+    return L.load().risp_bilateral_chain_kernel(1, 3, 0).decode()
+
+
 def measured_traffic(algorithmic_bytes):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only when
-    they were taken on this very workload; otherwise null."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, regenerated each round by
+    tools/collect_r05.py from that round's counter passes) - only when they were taken on THIS kernel instance and this very
+    workload; otherwise null (a stale file must not be reported as a measurement)."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             t = json.load(f)
-        if t.get('algorithmic_bytes_per_launch') == algorithmic_bytes:
+        if t.get('kernel') == launched_kernel() and t.get('algorithmic_bytes_per_launch') == algorithmic_bytes:
             return t['traffic_bytes_per_launch']
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, RuntimeError, AttributeError):
         pass
     return None
 
@@ -192,6 +199,36 @@ def host_cpu():
         pass
     logical = os.cpu_count() or 1
     return model, (len(cores) or logical), logical
+
+
+ARCH_CONFIG1 = 'Demosaic_01_sRGB_11_01'                    # BASELINE configs[0]: demosaic -> WB -> gamma
+
+
+def cpu_baseline_config1(size, seconds=4.0):
+    """BASELINE.json configs[0]: test.py on ONE 256 x 256 synthetic Bayer patch through the 3-stage
+    fixed pipeline demosaic -> WbManual -> Gamma, the oracle (torch CPU fp32) on the host cores.  One patch is 65 k pixels of
+    element-wise work: threads beyond a few only add overhead, so 1, 4 and 8 threads are tried for `seconds` / 3 each."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import isp_oracle as O
+    from reconfigisp_amd.codes.data.synthetic_raw import make_batch
+    bay, _ = make_batch(1, size, size, seed=10)
+    names = O.parse_architecture(ARCH_CONFIG1)
+    raw = [torch.tensor(O.PARAM_INIT[k]) for k in names]
+    best = None
+    with torch.no_grad():
+        for th in (1, 4, 8):
+            torch.set_num_threads(th)
+            O.fixed_pipeline(bay, names, raw, [None] * len(names), origin=True)
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds / 3:
+                O.fixed_pipeline(bay, names, raw, [None] * len(names), origin=True)
+                reps += 1
+            rate = size * size * reps / (time.perf_counter() - t0) / 1e6
+            if best is None or rate > best[0]:
+                best = (rate, th, reps)
+    return {'value': round(best[0], 2), 'unit': 'MPix/s', 'cores': best[1], 'kind': 'port',
+            'sample': 'one %dx%d patch x %d repetitions of %s through oracle/isp_oracle.py (torch CPU fp32) at %d thread(s), the '
+                      'best of 1 / 4 / 8' % (size, size, best[2], ARCH_CONFIG1, best[1])}
 
 
 def cpu_baseline(bay, arch, point_s=3.0, min_iters=10):
@@ -590,8 +627,8 @@ def main():
                        'global_batch': args.batch * world, 'parallelism': 'batch-sharded x%d, no collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': measured_traffic(BYTES_PER_PIX_ISP * pix_per_step),
-                         'kernel': 'bilateral_chain_kernel<true,1> (risp_bilateral_chain_fwd): one launch per step, '
-                                   '%d B/pix algorithmic' % BYTES_PER_PIX_ISP},
+                         'kernel': '%s (risp_bilateral_chain_fwd): one launch per step, %d B/pix algorithmic'
+                                   % (launched_kernel(), BYTES_PER_PIX_ISP)},
             'extra': extra,
         }
         if proof is not None:
@@ -600,6 +637,7 @@ def main():
             line['dry_run_all_ranks_on_one_device'] = True
         if not args.no_cpu and world == 1:
             line['cpu_baseline'] = cpu_baseline(bay_cpu, ARCH_DENOISE)
+            line['cpu_baseline_config1'] = cpu_baseline_config1(args.size)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -247,31 +247,16 @@ int risp_conv2d_small(const risp_conv_desc *d, void *stream);
 int risp_conv_small_groups(const risp_conv_desc *d);
 int risp_conv2d_small_split(const risp_conv_desc *d, float *scratch, int groups, void *stream);
 
-/* The same operator for 3x3 layers with a one-dimensional Winograd transform F(2,3) along x (2/3 of the matrix-core
- * work of risp_conv2d; Path-Restore's 64->64 layers, path_14l_bayer_arch.py:6-21).  wpack: [chunk of risp_conv_wino3_chunk()
- * cin][ky][t][ci][cout padded to 32 or 64] with U_0 = g0, U_1 = (g0+g1+g2)/2, U_2 = (g0-g1+g2)/2, U_3 = g2 of filter row
- * ky (g = w[co][ci][ky][0..2]; backward-data: the forward weight with roles swapped and taps rotated by 180
- * degrees).  load_mode PLAIN, W % 4 == 0, 16-byte aligned tensors; epilogue RELU | ADD | MASK | NOBIAS. */
-int risp_conv_wino3_chunk(void);
-size_t risp_conv_wino3_wpack_floats(int cin, int cout);
-int risp_conv2d_wino3(const risp_conv_desc *d, void *stream);
-
-/* 3x3 layers with F(4,3) along x (half the matrix-core work of risp_conv2d): wpack [cout block of 32][chunk of
- * risp_conv_wino43_chunk() cin][ky][t][ci][32], U_t = (G g)_t, G rows (1/4,0,0) (1/6,1/6,1/6) (1/6,-1/6,1/6)
- * (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1).  Same restrictions as risp_conv2d_wino3.  Layers with 33..64 couts and
- * cin % 4 == 0 run both cout blocks in one wave (same results bit for bit); the environment variable RISP_W43_B2=0, read
- * once per process, keeps them on the one-block kernel (A/B diagnostics - the only environment the library reads). */
+/* The same operator for 3x3 layers with a one-dimensional Winograd transform F(4,3) along x, fp32 throughout (half the
+ * matrix-core work of risp_conv2d; Path-Restore's 64->64 layers, path_14l_bayer_arch.py:6-21, when RISP_CONV_ARITH=f32):
+ * wpack [cout block of 32][chunk of risp_conv_wino43_chunk() cin][ky][t][ci][32], U_t = (G g)_t, G rows (1/4,0,0)
+ * (1/6,1/6,1/6) (1/6,-1/6,1/6) (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1) applied to filter row g = w[co][ci][ky][0..2]
+ * (backward-data: the forward weight with roles swapped and taps rotated by 180 degrees).  load_mode PLAIN, W % 4 == 0,
+ * 16-byte aligned tensors, cout <= 64; epilogue RELU | ADD | MASK | NOBIAS; no grouped launches.  Layers with 33..64 couts
+ * and cin % 4 == 0 run both cout blocks in one wave (same results bit for bit).  The library reads no environment. */
 int risp_conv_wino43_chunk(void);
 size_t risp_conv_wino43_wpack_floats(int cin, int cout);
 int risp_conv2d_wino43(const risp_conv_desc *d, void *stream);
-
-/* 5x5 layers with F(2,5) along x (0.6 of the matrix-core work; SRCNNRes' 64->32 layer and its backward,
- * srcnn_res_arch.py:20).  wpack: [cout block of 32][chunk of risp_conv_wino5_chunk() cin][ky][t][ci][32] with
- * U_t = (G g)_t / (4,6,6,24,24,1), G rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16) (1,-2,4,-8,16) (0,0,0,0,1)
- * applied to filter row g = w[co][ci][ky][0..4].  Same restrictions as risp_conv2d_wino3. */
-int risp_conv_wino5_chunk(void);
-size_t risp_conv_wino5_wpack_floats(int cin, int cout);
-int risp_conv2d_wino5(const risp_conv_desc *d, void *stream);
 
 /* The same operator for the FIRST layers of the proxies - few input channels, the whole weight matrix staged once per
  * workgroup - with a LINEAR reduction index k = (ci * ksize + ky) * ksize + kx, so that the matrix instruction's two k-slots
@@ -286,12 +271,13 @@ int risp_conv_k3_cout_block(int cin, int ksize);
 size_t risp_conv_k3_wpack_floats(int cin, int cout, int ksize);
 int risp_conv2d_k3(const risp_conv_desc *d, void *stream);
 
-/* 5x5 layers with F(4,5) along x (0.4 of the matrix-core work of risp_conv2d, 2/3 of risp_conv2d_wino5): U_t = (G g)_t / s_t,
+/* 5x5 layers with F(4,5) along x (0.4 of the matrix-core work of risp_conv2d; SRCNNRes' 64->32 layer and its backward,
+ * srcnn_res_arch.py:20, when RISP_CONV_ARITH=f32, and the 5x5 backward passes with 3 or 12 input channels): U_t = (G g)_t / s_t,
  * G rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16) (1,-2,4,-8,16) (1,1/2,1/4,1/8,1/16) (1,-1/2,1/4,-1/8,1/16)
- * (0,0,0,0,1), s = (1, -18, -18, 360, 360, 45/16, 45/16, 1), applied to filter row g = w[co][ci][ky][0..4].  wpack, as
- * risp_conv_wino45_layout() says: 0 = [cout block of 32][chunk of 4 cin][ky][t][ci][32]; 1 = [cout block of 32][chunk of 4 cin]
- * [ky][point group 2][cout block of 16: 2][ci 4][cout 16][4 points] (the kernel with two output rows per wave).  cin % 4 == 0 or
- * cin < 4; otherwise the restrictions of risp_conv2d_wino3. */
+ * (0,0,0,0,1), s = (1, -18, -18, 360, 360, 45/16, 45/16, 1), applied to filter row g = w[co][ci][ky][0..4].  wpack (layout 1,
+ * what risp_conv_wino45_layout() returns): [cout block of 32][chunk of 4 cin][ky][point group 2][cout block of 16: 2][ci 4]
+ * [cout 16][4 points] (two output rows per wave).  cin % 4 == 0 or cin < 4; otherwise the restrictions of risp_conv2d_wino43;
+ * grouped launches. */
 int risp_conv_wino45_chunk(void);
 int risp_conv_wino45_layout(void);
 size_t risp_conv_wino45_wpack_floats(int cin, int cout);
@@ -394,8 +380,9 @@ int risp_group_sum(const float *stack, float *out, int G, int N, int C, int HW, 
 
 /* Backward-weight of the same layer: dw (cout,cin,k,k) = sum_{n,y,x} gy[n,co,y,x] * load(x)[n,ci,y+ky-p,x+kx-p]
  * (fully written).  Uses d->x, load_mode (PLAIN / CONSTCH), cin_img, cvals, N, H, W, cin, cout, ksize; gy is
- * (N,cout,H,W).  scratch: risp_conv_wgrad_scratch_floats(ksize) floats.  Only the proxy fine-tuning path
- * (darts_ft_model.py:206-246) needs weight gradients.  Float atomics: the last bits vary run to run. */
+ * (N,cout,H,W).  scratch: risp_conv_wgrad_scratch_floats(ksize) floats (per-workgroup partial sums: 768 slices of the pixel
+ * tiles, dealt over the 32 x 32 blocks of (cout, cin), added in index order by a finishing launch - no atomics, the same bits on every run).
+ * Only the proxy fine-tuning path (darts_ft_model.py:206-246) needs weight gradients. */
 size_t risp_conv_wgrad_scratch_floats(int ksize);
 int risp_conv2d_wgrad(const risp_conv_desc *d, const float *gy, float *dw, float *scratch, void *stream);
 
@@ -595,9 +582,15 @@ int risp_gt_crop(const uint8_t *frames, float *out, const int32_t *sel, int N, i
 int risp_resize_rggb(const uint16_t *src, uint16_t *dst, int H0, int W0, int H, int W, int resized_h, int pad_top,
                      void *stream);
 
-/* tensor2bgr + psnr on device (utils/util.py:118-154): truncating uint8 conversion of
- * both images, squared error accumulated in fp64 into sse[0] (zeroed by the call). */
+/* tensor2bgr + psnr on device (utils/util.py:118-154): truncating uint8 conversion of both images, squared error accumulated
+ * in fp64 into sse[0].  sse: risp_sse_uint8_doubles() doubles - sse[1 ..] receive the workgroups' partial sums, added in index
+ * order by a finishing launch (no atomics: the same bits on every run). */
+size_t risp_sse_uint8_doubles(void);
 int risp_sse_uint8(const float *a, const float *b, double *sse, size_t numel, void *stream);
+
+/* Diagnostics: the kernel instance risp_bilateral_chain_fwd launches for these arguments, named as rocprofv3 prints it
+ * (bench.py binds the committed counter readings of profiles/traffic.json to the kernel it actually launches). */
+const char *risp_bilateral_chain_kernel(int from_bayer, int max_window, int with_wb_quadratic);
 
 #ifdef __cplusplus
 }

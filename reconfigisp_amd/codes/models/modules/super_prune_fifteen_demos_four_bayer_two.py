@@ -26,8 +26,8 @@ FUSE_SLOT = os.environ.get('RISP_FUSE_SLOT', '1') != '0'     # element-wise oper
 _POINTWISE = {T.Skip: 'skip', T.WbManual: 'wb_manual', T.Gamma: 'gamma', T.GtmManual: 'gtm_manual', T.WbQuadratic: 'wb_quadratic',
               T.Grayworld: 'grayworld'}
 SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '2'))
-SLOT_STREAMS_MAX_PIXELS = int(os.environ.get('RISP_SLOT_STREAMS_MAX_PIXELS', str(1 << 40)))
-SLOT_STREAMS_MIN_JOBS = int(os.environ.get('RISP_SLOT_STREAMS_MIN_JOBS', '3'))      # jobs of a slot from which the streams are used
+SLOT_STREAMS_MAX_PIXELS = 1 << 40
+SLOT_STREAMS_MIN_JOBS = 3                   # jobs of a slot from which the streams are used
 
 
 class SuperPruneFifteenDemosFourBayerTwo(nn.Module):

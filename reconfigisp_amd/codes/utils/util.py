@@ -115,7 +115,7 @@ def psnr_tensors(a, b):
     a, b = F._dev(a), F._dev(b)
     if a.shape != b.shape:
         raise ValueError('shape mismatch %s vs %s' % (tuple(a.shape), tuple(b.shape)))
-    sse = torch.empty(1, device=a.device, dtype=torch.float64)
+    sse = torch.empty(L.load().risp_sse_uint8_doubles(), device=a.device, dtype=torch.float64)
     L.call('risp_sse_uint8', F._p(a), F._p(b), C.c_void_p(sse.data_ptr()), a.numel(), F._stream())
-    mse = sse.item() / a.numel()
+    mse = sse[0].item() / a.numel()
     return float('inf') if mse == 0 else 10 * math.log10(1. / mse)     # identical images: inf, like numpy's 1./0.

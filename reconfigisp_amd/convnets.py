@@ -22,31 +22,7 @@ LOAD_PLAIN, LOAD_UNSHUFFLE2, LOAD_CONSTCH = 0, 1, 2
 EPI_RELU, EPI_ADD, EPI_MASK, EPI_SHUFFLE2, EPI_NOBIAS, EPI_CASEBIAS = 1, 2, 4, 8, 16, 32
 
 
-# 3x3 layers run on the Winograd-x kernel (risp_conv2d_wino3) unless RISP_WINOGRAD=0 (A/B switch)
-WINOGRAD = os.environ.get('RISP_WINOGRAD', '1') != '0'
-WINO_F43 = os.environ.get('RISP_WINO_F43', '1') != '0'       # 3x3: F(4,3) (default) or F(2,3)
 _WINO_EPI = EPI_RELU | EPI_ADD | EPI_MASK | EPI_NOBIAS
-F43_TRAIN = os.environ.get('RISP_F43_TRAIN', '1') == '1'       # F(4,3) also for training forwards (0: F(2,3) there, as in round 1)
-F43_MIN_GRID = int(os.environ.get('RISP_F43_MIN_GRID', '0'))      # workgroups below which backward-data passes take F(2,3) (see conv())
-
-
-def wino3_weights(w, transpose, ck):
-    """[chunk of ``ck`` cin][ky][t][ci][cout pad] Winograd F(2,3)-along-x weights of a 3x3 layer (include/risp.h).
-    Pure tensor algebra on whatever device ``w`` lives on (tests/test_pack_algebra_cpu.py exercises it on the CPU)."""
-    if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
-        w = w.flip(2, 3).transpose(0, 1)
-    g0, g1, g2 = w[..., 0], w[..., 1], w[..., 2]    # (co, ci, ky)
-    u = torch.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], dim=-1)      # (co, ci, ky, t)
-    co, ci = u.shape[0], u.shape[1]
-    cp, nch = (64 if co > 32 else 32), (ci + ck - 1) // ck
-    p = torch.zeros((nch * ck, 3, 4, cp), device=w.device, dtype=w.dtype)
-    p[:ci, :, :, :co] = u.permute(1, 2, 3, 0)
-    return p.view(nch, ck, 3, 4, cp).permute(0, 2, 3, 1, 4).contiguous()
-
-
-def _wino3_pack(w, transpose):
-    return wino3_weights(w, transpose, L.load().risp_conv_wino3_chunk())
-
 
 _W43_G = ((1 / 4, 0, 0), (1 / 6, 1 / 6, 1 / 6), (1 / 6, -1 / 6, 1 / 6), (1 / 24, 1 / 12, 1 / 6), (1 / 24, -1 / 12, 1 / 6), (0, 0, 1))
 
@@ -69,37 +45,21 @@ def wino43_weights(w, transpose, ck):
     return _wino_blocked_pack(torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype), ck)
 
 
-_W5_G = ((1, 0, 0, 0, 0), (1, 1, 1, 1, 1), (1, -1, 1, -1, 1), (1, 2, 4, 8, 16), (1, -2, 4, -8, 16), (0, 0, 0, 0, 1))
-_W5_S = (4., 6., 6., 24., 24., 1.)
-
-
-def wino5_weights(w, transpose, ck):
-    """[cout block of 32][chunk of ``ck`` cin][ky][t][ci][32] Winograd F(2,5)-along-x weights of a 5x5 layer
-    (include/risp.h).  Pure tensor algebra (computed in fp64, stored in the dtype of ``w``)."""
-    if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
-        w = w.flip(2, 3).transpose(0, 1)
-    g = torch.tensor(_W5_G, dtype=torch.float64, device=w.device) / torch.tensor(_W5_S, dtype=torch.float64,
-                                                                                 device=w.device)[:, None]
-    return _wino_blocked_pack(torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype), ck)
-
-
 _W45_G = ((1, 0, 0, 0, 0), (1, 1, 1, 1, 1), (1, -1, 1, -1, 1), (1, 2, 4, 8, 16), (1, -2, 4, -8, 16),
           (1, 1 / 2, 1 / 4, 1 / 8, 1 / 16), (1, -1 / 2, 1 / 4, -1 / 8, 1 / 16), (0, 0, 0, 0, 1))
 _W45_S = (1., -18., -18., 360., 360., 45. / 16., 45. / 16., 1.)
 
 
-def wino45_weights(w, transpose, ck=4, layout=None):
+def wino45_weights(w, transpose, ck=4, layout=1):
     """Winograd F(4,5)-along-x weights of a 5x5 layer (include/risp.h: risp_conv2d_wino45), pure tensor algebra computed in
-    fp64 and stored in the dtype of ``w``.  ``layout`` (default: what the library's kernel reads, ``risp_conv_wino45_layout``):
-    0 = [cout block of 32][chunk of 4 cin][ky][t][ci][32]; 1 = [cout block of 32][chunk of 4 cin][ky][point group 2]
-    [cout block of 16: 2][ci 4][cout 16][4 points] (the two-rows-per-wave kernel: one ds_read_b128 = the A operands of four points)."""
+    fp64 and stored in the dtype of ``w``: [cout block of 32][chunk of 4 cin][ky][point group 2][cout block of 16: 2][ci 4][cout 16]
+    [4 points] (one ds_read_b128 = the A operands of four points).  ``layout`` 0 = the plain blocked form [cout block of 32][chunk of
+    4 cin][ky][t][ci][32] (tests/test_pack_algebra_cpu.py checks the algebra on it)."""
     if transpose:                                   # backward-data: roles swapped, taps rotated by 180 degrees
         w = w.flip(2, 3).transpose(0, 1)
     g = torch.tensor(_W45_G, dtype=torch.float64, device=w.device) / torch.tensor(_W45_S, dtype=torch.float64,
                                                                                   device=w.device)[:, None]
     u = torch.einsum('tk,oiyk->oiyt', g, w.double()).to(w.dtype)              # (co, ci, ky, t)
-    if layout is None:
-        layout = L.load().risp_conv_wino45_layout()
     if layout == 0:
         return _wino_blocked_pack(u, ck)
     assert ck == 4
@@ -188,7 +148,6 @@ def toep_first_weights(w):
     return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
 
 
-WINO_F45 = os.environ.get('RISP_WINO_F45', '1') != '0'       # 5x5: F(4,5) where cin % 4 == 0 (default), else F(2,5)
 # Arithmetic of the wide hidden layers (3x3, cin % 16 == 0, cout 32 / 64): 'f16x2' (default) = split precision on the f16 matrix
 # pipe - each fp32 operand as two f16 halves, three products, fp32 accumulation (risp_conv2d_f16x2: fp32 tensors in and out,
 # error against float64 no larger than the fp32 kernels'); 'f32' = the fp32 matrix-core kernels (Winograd F(4,3) / F(2,3)).
@@ -203,10 +162,6 @@ def f16x2_addressable(cin, cout, h, w):
     such offset stays below 2^31 iff max(cin, cout) * H * W * 4 < 2^31 (the entry point checks the same bound); larger images -
     an untiled 3000 x 4000 frame through a 64-channel layer - take the fp32 kernels with their 64-bit addresses."""
     return max(cin, cout) * h * w * 4 < (1 << 31)
-
-
-def _wino5_pack(w, transpose):
-    return wino5_weights(w, transpose, L.load().risp_conv_wino5_chunk())
 
 
 def small_weights(w, transpose=False, keep=None):
@@ -241,9 +196,6 @@ def k3_weights(w):
     return p.view(rows, ncb, cp).permute(1, 0, 2).contiguous()
 
 
-K3 = os.environ.get('RISP_CONV_K3', '1') != '0'      # A/B switch: 0 = the 9x9 3 -> 64 layer on the general kernel
-
-
 def srcnn_fold_tables(w1):
     """(rcase (9+P, cout*k*k), wconst (cout*k*k, 9+P)) of SRCNNRes' first layer w1 (cout, 12+P, k, k): see SrcnnResFold."""
     k, p = w1.shape[2], w1.shape[2] // 2
@@ -261,6 +213,29 @@ def srcnn_fold_tables(w1):
     return rcase, wconst
 
 
+def pack_kinds(k, cin, cout, transpose=False):
+    """Which packs a (cout, cin, k, k) layer holds for its forward (``transpose`` False) or backward-data direction - what
+    ``PackedConv`` builds and ``route`` may choose from (the general pack of risp_conv2d always exists)"""
+    c_in, c_out = (cout, cin) if transpose else (cin, cout)
+    have = []
+    if k == 3:
+        have.append('wino43')
+    if k == 5 and (c_in % 4 == 0 or c_in < 4):
+        have.append('wino45')
+    if k in (3, 5) and c_in % 16 == 0 and c_out in (32, 64):
+        have.append('f16x2')
+    if k in (3, 9) and cin in (3, 4) and cout <= 64:           # first layers (forward geometry; route() uses them forward only)
+        have.append('k3')
+    if k == 9 and cin in (3, 4):
+        have.append('toep_first')
+    return have
+
+
+def small_has_toep(k, cout):
+    """does a small-cout layer (``SmallConv``) hold a Toeplitz-band pack for risp_conv2d_toep"""
+    return (k == 9 and cout <= 4) or (k == 5 and cout <= 12)
+
+
 class PackedConv:
     """Device-side packed weights of one layer, forward and backward-data."""
 
@@ -273,30 +248,21 @@ class PackedConv:
         self.bwd = torch.empty(lib.risp_conv_wpack_floats(self.cout, self.cin, self.k), device=w.device)
         L.call('risp_conv_pack_weights', _p(w), self.cin, self.cout, self.k, 0, _p(self.fwd), _stream())
         L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
-        self.wino_fwd = self.wino_bwd = None
-        self.wino_entry = self.wino43_fwd = self.wino43_bwd = None
-        self.wino45_fwd = self.wino45_bwd = None
-        self.f16x2_fwd = self.f16x2_bwd = None
-        if self.k in (3, 5):                            # split-precision packs (see CONV_ARITH); either direction on its own
-            ok = lambda ci, co: ci % 16 == 0 and co in (32, 64)
-            self.f16x2_fwd = f16x2_weights(w, False) if ok(self.cin, self.cout) else None
-            self.f16x2_bwd = f16x2_weights(w, True) if ok(self.cout, self.cin) else None
+        kf, kb = pack_kinds(self.k, self.cin, self.cout, False), pack_kinds(self.k, self.cin, self.cout, True)
+        ck43 = L.load().risp_conv_wino43_chunk()
+        # fp32 Winograd packs: RISP_CONV_ARITH=f32, and the layers the split-precision kernels do not take
+        self.wino43_fwd = wino43_weights(w, False, ck43) if 'wino43' in kf else None
+        self.wino43_bwd = wino43_weights(w, True, ck43) if 'wino43' in kb else None
+        self.wino45_fwd = wino45_weights(w, False) if 'wino45' in kf else None
+        self.wino45_bwd = wino45_weights(w, True) if 'wino45' in kb else None
+        # split-precision packs (see CONV_ARITH); either direction on its own
+        self.f16x2_fwd = f16x2_weights(w, False) if 'f16x2' in kf else None
+        self.f16x2_bwd = f16x2_weights(w, True) if 'f16x2' in kb else None
         # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
-        self.k3 = k3_weights(w) if (self.k in (3, 9) and self.cin in (3, 4) and self.cout <= 64) else None
-        # ... and the 9x9 ones on the f16 matrix pipe in split precision (see CONV_ARITH), risp_conv_toep_first.hip
-        self.toep_first = toep_first_weights(w) if (self.k == 9 and self.cin in (3, 4)) else None
+        self.k3 = k3_weights(w) if 'k3' in kf else None
+        # ... and the 9x9 ones on the f16 matrix pipe in split precision, risp_conv_toep_first.hip
+        self.toep_first = toep_first_weights(w) if 'toep_first' in kf else None
         self.w32 = w.float().contiguous() if self.toep_first is not None else None      # for the exact recomputation of ReLU ties
-        if self.k == 3 and WINOGRAD:
-            self.wino_fwd, self.wino_bwd, self.wino_entry = _wino3_pack(w, False), _wino3_pack(w, True), 'risp_conv2d_wino3'
-            if WINO_F43:                              # inference forward and every backward-data pass (see conv())
-                ck43 = L.load().risp_conv_wino43_chunk()
-                self.wino43_fwd, self.wino43_bwd = wino43_weights(w, False, ck43), wino43_weights(w, True, ck43)
-        elif self.k == 5 and WINOGRAD:
-            self.wino_fwd, self.wino_bwd, self.wino_entry = _wino5_pack(w, False), _wino5_pack(w, True), 'risp_conv2d_wino5'
-            if WINO_F45:                              # launches with cin % 4 == 0 take F(4,5) (see conv())
-                ok45 = lambda c: c % 4 == 0 or c < 4        # the launch's input channels: whole chunks of 4, or one partial chunk
-                self.wino45_fwd = wino45_weights(w, False) if ok45(self.cin) else None
-                self.wino45_bwd = wino45_weights(w, True) if ok45(self.cout) else None
 
 
 class SmallConv:
@@ -309,7 +275,7 @@ class SmallConv:
         self.wpack, self.cout = small_weights(w, transpose, keep)
         self.cin, self.k = self.wpack.shape[0], self.wpack.shape[2]
         # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts
-        self.toep = toep_weights(w, transpose, keep) if (self.k == 9 and self.cout <= 4) or (self.k == 5 and self.cout <= 12) else None
+        self.toep = toep_weights(w, transpose, keep) if small_has_toep(self.k, self.cout) else None
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 
@@ -338,11 +304,9 @@ def toep_grid_ok(images, h, w):
 def _toep_ok(sc, h, w):
     # (any width: planes of at most 128 pixels run with two rows folded into the 32 columns of the matrix instruction; the 12-cout
     # form cannot fold and is ~20 % slower than the vector kernel there, but a layer keeps ONE arithmetic whatever the crop it sees)
-    return TOEP and CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
+    return CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
 
 
-# A/B switches of the two Toeplitz-band kernels (default on; RISP_CONV_ARITH=f32 switches both off as well)
-TOEP = os.environ.get('RISP_CONV_TOEP', '1') != '0'              # risp_conv2d_toep: 5- / 9-tap layers with at most 4 couts
 # risp_conv2d_toep_first (9x9 first layers on the f16 matrix pipe): 'train' (default) = inference AND training forwards, the latter with
 # EXACT ReLU decisions (risp_conv2d_toep_first_exact: outputs whose pre-activation is within the arithmetic's own error of zero are
 # recomputed in double) - one first-layer kernel for model.test() and the training forward; 'infer' = inference launches only, training
@@ -369,16 +333,28 @@ def _tie_list(device):
     return t
 
 
-TOEP_MIN_TILES = int(os.environ.get('RISP_TOEP_MIN_TILES', '256'))
+TOEP_MIN_TILES = 256                        # training launches: tiles below which the vector-FMA kernel with its channel split serves
+
+
+def route_small(k, cin, cout, h, w, images, infer=False, has_mask=False, has_toep=True, split=None):
+    """The dispatch of ``conv_small`` (layers with at most 12 output channels): 5- and 9-tap layers that hold a Toeplitz-band pack
+    (at most 4 couts, or 5 .. 12 with 5 taps) run on risp_conv2d_toep (f16 matrix pipe, split precision) under RISP_CONV_ARITH=f16x2
+    when W % 4 == 0 and the launch has no mask - ALWAYS for inference (a tile's result must not depend on the batch it travels in),
+    for training when the grid holds at least TOEP_MIN_TILES tiles (or the caller forces ``split`` = 0: the per-member form of a
+    grouped launch follows the grouped grid); everything else on risp_conv2d_small (vector FMAs; small training grids split their
+    input channels over several workgroups per tile: risp_conv2d_small_split, never for inference)."""
+    toep = CONV_ARITH == 'f16x2' and has_toep and w % 4 == 0 and cin * h * w < (1 << 30) and not has_mask
+    if toep and (infer or (split == 0 if split is not None else toep_grid_ok(images, h, w))):
+        return 'risp_conv2d_toep'
+    return 'risp_conv2d_small'
 
 
 def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False, out=None, group=None, split=None, tile_sums=None):
-    """One ``risp_conv2d_small`` launch (direct vector-FMA convolution, cout <= 12).  ``infer``: never split the input
-    channels over workgroups - the split depends on the grid, and an inference result must not depend on the batch a
-    tile travels in (test_split.py batches tiles).  ``group``: see ``_group_fields``; ``split``: force the channel split
-    (the per-member form of a grouped launch uses the split the grouped grid would take; 0 = the Toeplitz-band kernel).
-    5- and 9-tap layers with at most 4 couts run on ``risp_conv2d_toep`` (f16 matrix pipe, split precision) when the grid is
-    large enough - always for inference, so that a tile's result does not depend on the batch - unless RISP_CONV_ARITH=f32."""
+    """One launch of a layer with at most 12 output channels (``route_small``).  ``infer``: never split the input channels over
+    workgroups - the split depends on the grid, and an inference result must not depend on the batch a tile travels in
+    (test_split.py batches tiles).  ``group``: see ``_group_fields``; ``split``: force the channel split (the per-member form of a
+    grouped launch uses the split the grouped grid would take; 0 = the Toeplitz-band kernel).  ``tile_sums``: a list that receives
+    the per-tile sums of the input planes when the Toeplitz-band kernel serves the launch (see ``rect_sums``)."""
     if sc.bias is None:
         epi |= EPI_NOBIAS
     nn_ = n * (group[0] if group else 1)
@@ -389,11 +365,11 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
     toep = getattr(sc, 'toep', None)
-    if _toep_ok(sc, h, w) and mask is None and (infer or (split == 0 if split is not None else toep_grid_ok(nn_, h, w))):
+    if route_small(sc.k, sc.cin, sc.cout, h, w, nn_, infer, mask is not None, toep is not None, split) == 'risp_conv2d_toep':
         # the f16 matrix pipe (Toeplitz bands of the filter rows as the A operand): 2.5-3 x the vector-FMA kernel on full grids
         d.wpack = _p(toep)
         _group_fields(d, n, group, toep, sc.bias)
-        if tile_sums is not None:                      # a list: receives the per-tile sums of the input planes (see rect_sums)
+        if tile_sums is not None:
             ps = torch.empty((nn_, L.load().risp_conv_toep_tiles(h, w), sc.cin), device=x.device, dtype=torch.float32)
             L.call('risp_conv2d_toep_sums', C.byref(d), _p(ps), _stream())
             tile_sums.append(ps)
@@ -425,7 +401,7 @@ def rect_sums(g1, rs, images, planes, h, w, k, tile_sums):
 
 # bench.py sets this to [0.0] to count the FLOPs the launches ISSUE on the matrix cores (diagnostic; None = off)
 MFMA_ISSUED = None
-_TAPS = {'risp_conv2d_wino3': (12, 2), 'risp_conv2d_wino43': (18, 4), 'risp_conv2d_wino5': (30, 2), 'risp_conv2d_wino45': (40, 4)}
+_TAPS = {'risp_conv2d_wino43': (18, 4), 'risp_conv2d_wino45': (40, 4)}
 # ... and, separately, the FLOPs the split-precision launches issue on the f16 matrix pipe (3 products per tap) and the time-free
 # count of such launches: bench.py prices the two pipes against their own peaks
 MFMA_ISSUED_F16 = None
@@ -433,7 +409,7 @@ MFMA_ISSUED_F16 = None
 
 def _issued_flops(entry, cin, cout, k, pixels):
     """2 x MACs of the MFMA instructions one launch executes, tile-edge padding not counted: the direct kernel
-    multiplies k*k taps per pixel, the Winograd-x kernels 12 / 18 / 30 transformed taps per 2 / 4 / 2 pixels; output
+    multiplies k*k taps per pixel, the Winograd-x kernels 18 / 40 transformed taps per 4 pixels; output
     channels are padded to a multiple of 32 (the MFMA tile), input channels to the kernel's pair granularity."""
     if entry == 'risp_conv2d_k3':
         return 2.0 * (2 * ((cin * k * k + 1) // 2)) * ((cout + 31) // 32 * 32) * pixels
@@ -441,82 +417,110 @@ def _issued_flops(entry, cin, cout, k, pixels):
     return 2.0 * taps * (cin + cin % 2) * ((cout + 31) // 32 * 32) * pixels / per
 
 
+def route(k, cin, cout, h, w, transpose=False, load=LOAD_PLAIN, epi=0, add_c=0, infer=False, aligned=True, have=()):
+    """THE dispatch table of ``conv``: which entry point of the library serves one launch of a layer.  Pure function of the launch's
+    geometry (``cin`` / ``cout`` as the launch sees them: swapped for a backward-data pass), its load mode and epilogue flags, whether
+    every tensor is 16-byte aligned, whether it is an inference launch, and which packs the layer holds (``have``: a subset of
+    'wino43', 'wino45', 'f16x2', 'k3', 'toep_first').  Rules, first match wins (tests/test_gpu_conv_modes.py::test_route_table pins the
+    result for every layer of the four proxy families):
+
+      1. first layers (3 plain / 4 space-to-depth input channels, 3x3 or 9x9, forward only, epilogue RELU | NOBIAS | CASEBIAS):
+         9x9 under RISP_CONV_ARITH=f16x2 -> risp_conv2d_toep_first (inference; TOEP_FIRST 'train' / 'plain' also training, 'train'
+         through risp_conv2d_toep_first_exact), otherwise -> risp_conv2d_k3 (fp32, linear reduction index);
+      2. wide 3x3 / 5x5 layers (cin % 16 == 0, cout 32 or 64, plain load, epilogue within RELU | ADD | MASK | NOBIAS with a full-width
+         residual, addressable through 2^31-byte buffers) under f16x2 -> risp_conv2d_f16x2 (split precision, f16 matrix pipe);
+      3. 3x3 with the plain-16 conditions -> risp_conv2d_wino43 (fp32 F(4,3)); 5x5 with cin % 4 == 0 or cin < 4 -> risp_conv2d_wino45;
+      4. everything else -> risp_conv2d (fp32 matrix cores, direct).
+    (Layers with at most 12 output channels never come here: ``conv_small`` / ``route_small``.)"""
+    plain16 = load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and aligned
+    if ('k3' in have and not transpose and w % 4 == 0 and h >= k - 1 and w >= k - 1 and aligned
+            and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
+            and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS))):
+        if ('toep_first' in have and CONV_ARITH == 'f16x2' and cin * h * w < (1 << 30)
+                and (TOEP_FIRST in ('train', 'plain') or (TOEP_FIRST == 'infer' and infer))):
+            return 'risp_conv2d_toep_first_exact' if (TOEP_FIRST == 'train' and not infer) else 'risp_conv2d_toep_first'
+        return 'risp_conv2d_k3'
+    if (CONV_ARITH == 'f16x2' and 'f16x2' in have and plain16 and (not (epi & EPI_ADD) or add_c == cout)
+            and f16x2_addressable(cin, cout, h, w)):
+        return 'risp_conv2d_f16x2'
+    if k == 3 and 'wino43' in have and plain16:
+        return 'risp_conv2d_wino43'
+    if k == 5 and 'wino45' in have and plain16:
+        return 'risp_conv2d_wino45'
+    return 'risp_conv2d'
+
+
+def _have(pc, transpose):
+    """the packs of a layer that ``route`` may pick from, for this direction"""
+    sfx = '_bwd' if transpose else '_fwd'
+    have = [name for name in ('wino43', 'wino45', 'f16x2') if getattr(pc, name + sfx, None) is not None]
+    have += [name for name in ('k3', 'toep_first') if getattr(pc, name, None) is not None]
+    return have
+
+
 def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None, epi=0, add=None, add_c=0,
          mask=None, out=None, infer=False, group=None):
-    """One fused convolution launch at resolution (h,w); returns the output tensor.  ``infer``: no backward pass
-    will read this layer's activations (selects the F(4,3) form of a 3x3 layer).  ``group`` = (G, flags): ``pc`` holds the
-    packs of G same-geometry layers stacked along dimension 0 and the launch covers G * n images (``_group_fields``)."""
+    """One fused convolution launch at resolution (h,w); returns the output tensor.  ``infer``: no backward pass will read this
+    layer's activations (an inference launch: its result must not depend on the batch a tile travels in).  ``group`` = (G, flags):
+    ``pc`` holds the packs of G same-geometry layers stacked along dimension 0 and the launch covers G * n images
+    (``_group_fields``).  The kernel is chosen by ``route``."""
     cin, cout = (pc.cout, pc.cin) if transpose else (pc.cin, pc.cout)
     if transpose:
         epi |= EPI_NOBIAS
     if group is not None and pc.k == 3:
-        raise ValueError('grouped launches are not available for 3x3 layers (the Winograd F(4,3) / F(2,3) kernels)')
+        raise ValueError('grouped launches are not available for 3x3 layers')
     nn_ = n * (group[0] if group else 1)
     if out is None:
         shape = (nn_, cout // 4, 2 * h, 2 * w) if epi & EPI_SHUFFLE2 else (nn_, cout, h, w)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
-    wino, entry = (pc.wino_bwd if transpose else pc.wino_fwd), pc.wino_entry
-    # F(4,3) has about twice the rounding error of F(2,3) (still ~2e-7 of max|y|).  Round 1 kept training FORWARD passes on
-    # F(2,3) because a coarser forward flips more ReLU masks whose pre-activation sits within an ulp of zero, and
-    # gradients are discontinuous there.  Round 2 measures that instead of avoiding it: with the float64 yardstick
-    # (tests/test_gpu_error_budget.py) the architecture gradients under F(4,3) forwards stay within the reference's own
-    # fp32 error family (7.1e-5 of their magnitude, the reference: 7.1e-5), every golden still holds, and the search
-    # step is 7 % faster (0.912 -> 0.848 s) - so F(4,3) now serves training forwards too (RISP_F43_TRAIN=0 restores
-    # F(2,3)).  Backward-data passes take their masks from the saved forward activations: their own rounding only
-    # perturbs the gradient smoothly.
-    # Small grids (the per-GPU batch of the 8-GPU search is 4 images): F(4,3)'s 128-pixel-wide tiles then give the chip only
-    # one or two lockstep rounds of workgroups and a lone launch is slower than F(2,3) (4 x 64 x 256 x 256: 110 us
-    # against 97 us) - but with the ops of a slot on two streams (section 5.1 of DESIGN.md) launches overlap and F(4,3)
-    # wins again (DARTS iteration at batch 4: 0.090 s against 0.094 s), so the switch F43_MIN_GRID defaults to off.
-    big_grid = n * ((h + 3) // 4) * ((w + 127) // 128) * ((cout + 31) // 32) >= F43_MIN_GRID
-    if transpose and pc.wino43_bwd is not None and big_grid:
-        wino, entry = pc.wino43_bwd, 'risp_conv2d_wino43'
-    elif pc.wino43_fwd is not None and not transpose and (infer or F43_TRAIN):
-        # (inference: always F(4,3), so that a tile's result never depends on the batch it travels in)
-        wino, entry = pc.wino43_fwd, 'risp_conv2d_wino43'
-    w45 = getattr(pc, 'wino45_bwd' if transpose else 'wino45_fwd', None)
-    if w45 is not None and WINO_F45:                  # 5x5 layers whose launch has cin % 4 == 0: F(4,5), 2/3 of F(2,5)'s matrix work
-        wino, entry = w45, 'risp_conv2d_wino45'
-    plain16 = (load == LOAD_PLAIN and w % 4 == 0 and not (epi & ~_WINO_EPI) and
-               (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
-                (mask.data_ptr() if mask is not None else 0)) % 16 == 0)
-    use_wino = wino is not None and plain16
-    wpack = wino if use_wino else (pc.bwd if transpose else pc.fwd)
-    h2 = getattr(pc, 'f16x2_bwd' if transpose else 'f16x2_fwd', None)
-    if (CONV_ARITH == 'f16x2' and h2 is not None and plain16 and (add is None or add_c == cout)
-            and f16x2_addressable(cin, cout, h, w)):
-        # wide 3x3 / 5x5 layer: split precision on the f16 matrix pipe (same tensors, same epilogue flags, its own pack)
-        wpack, entry, use_wino = h2, 'risp_conv2d_f16x2', True
-    if (K3 and getattr(pc, 'k3', None) is not None and not transpose and w % 4 == 0 and h >= pc.k - 1 and w >= pc.k - 1
-            and ((load == LOAD_PLAIN and cin == 3) or (load == LOAD_UNSHUFFLE2 and cin == 4))
-            and not (epi & ~(EPI_RELU | EPI_NOBIAS | EPI_CASEBIAS)) and (x.data_ptr() | out.data_ptr()) % 16 == 0):
-        wpack, entry, use_wino = pc.k3, 'risp_conv2d_k3', True      # first layers: the linear-k kernel (risp_conv_k3.hip)
-        if ((TOEP_FIRST in ('train', 'plain') or (TOEP_FIRST == 'infer' and infer)) and CONV_ARITH == 'f16x2' and getattr(pc, 'toep_first', None) is not None
-                and cin * h * w < (1 << 30)):
-            wpack, entry = pc.toep_first, 'risp_conv2d_toep_first'  # 9x9: windows of the filter rows on the f16 matrix pipe
+    aligned = (x.data_ptr() | out.data_ptr() | (add.data_ptr() if add is not None else 0) |
+               (mask.data_ptr() if mask is not None else 0)) % 16 == 0
+    have = _have(pc, transpose)
+    if add is not None:
+        epi_r = epi | EPI_ADD
+    else:
+        epi_r = epi
+    entry = route(pc.k, cin, cout, h, w, transpose, load, epi_r, add_c, infer, aligned, have)
+    if entry == 'risp_conv2d_toep_first_exact' and nn_ * cout * h * w >= (1 << 32):
+        entry = 'risp_conv2d_toep_first'
+    sfx = '_bwd' if transpose else '_fwd'
+    wpack = {'risp_conv2d_k3': lambda: pc.k3, 'risp_conv2d_toep_first': lambda: pc.toep_first,
+             'risp_conv2d_toep_first_exact': lambda: pc.toep_first, 'risp_conv2d_f16x2': lambda: getattr(pc, 'f16x2' + sfx),
+             'risp_conv2d_wino43': lambda: getattr(pc, 'wino43' + sfx), 'risp_conv2d_wino45': lambda: getattr(pc, 'wino45' + sfx),
+             'risp_conv2d': lambda: pc.bwd if transpose else pc.fwd}[entry]()
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
                    epilogue=epi, add_c=add_c, x=_p(x), wpack=_p(wpack),
                    bias=_p(pc.bias), cvals=_p(cvals), add=_p(add), mask=_p(mask), y=_p(out))
     _group_fields(d, n, group, wpack, None if transpose else pc.bias)
-    if entry == 'risp_conv2d_toep_first' and use_wino and not infer and TOEP_FIRST == 'train' and nn_ * cout * h * w < (1 << 32):
-        w32 = pc.w32                                    # training forward: exact ReLU decisions (see TOEP_FIRST)
-        L.call('risp_conv2d_toep_first_exact', C.byref(d), _p(w32), w32.stride(0) if group else 0, _p(_tie_list(x.device)), TIES_MAX, _stream())
+    if entry == 'risp_conv2d_toep_first_exact':
+        w32 = pc.w32                                    # exact ReLU decisions (see TOEP_FIRST)
+        L.call(entry, C.byref(d), _p(w32), w32.stride(0) if group else 0, _p(_tie_list(x.device)), TIES_MAX, _stream())
     else:
-        L.call(entry if use_wino else 'risp_conv2d', C.byref(d), _stream())
+        L.call(entry, C.byref(d), _stream())
     if entry == 'risp_conv2d_f16x2':
         if MFMA_ISSUED_F16 is not None:
             MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * pc.k * cin * cout * nn_ * h * w
-    elif entry == 'risp_conv2d_toep_first':
+    elif entry.startswith('risp_conv2d_toep_first'):
         if MFMA_ISSUED_F16 is not None:                # 16 window slots per filter row (9 carry a tap), cout padded to 32
             MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * 16 * cin * ((cout + 31) // 32 * 32) * nn_ * h * w
     elif MFMA_ISSUED is not None:
-        MFMA_ISSUED[0] += _issued_flops(entry if use_wino else 'risp_conv2d', cin, cout, pc.k, nn_ * h * w)
+        MFMA_ISSUED[0] += _issued_flops(entry, cin, cout, pc.k, nn_ * h * w)
     return out
 
 
 def conv_wgrad(x, gy, cin, cout, k, n, h, w, load=LOAD_PLAIN, cin_img=0, cvals=None):
-    """(dW (cout,cin,k,k), db (cout,)) of one layer from its input x and the gradient gy at its output."""
+    """(dW (cout,cin,k,k), db (cout,)) of one layer from its input x and the gradient gy at its output (risp_conv2d_wgrad: per-workgroup
+    partial sums added in index order - the same bits on every run).  ``load`` LOAD_CONSTCH (SRCNNRes' first layer, srcnn_res_arch.py:
+    41-46: ``cin_img`` image channels followed by planes that hold the per-image constants ``cvals``): the gradient of a constant plane's
+    taps is cvals^T @ (rectangle sums of gy) - risp_rect_sums, the sums its backward-data pass needs anyway - and only the image channels
+    go through the matrix kernel (cin_img * k <= 32: one chain per filter ROW with (channel, column) pairs as the matrix columns)."""
     gy = _dev(gy, 'grad')
+    if load == LOAD_CONSTCH and cin_img * k <= 32 and cvals is not None and h >= k // 2 and w >= k // 2:
+        dw_img, db = conv_wgrad(x, gy, cin_img, cout, k, n, h, w)
+        rs = torch.empty((n, cout * k * k), device=gy.device, dtype=torch.float32)
+        L.call('risp_rect_sums', _p(gy), _p(rs), n * cout, h, w, k, _stream())
+        dw_c = (cvals.t() @ rs).view(cin - cin_img, cout, k, k).transpose(0, 1)
+        return torch.cat([dw_img, dw_c], dim=1).contiguous(), db
     dw = torch.empty((cout, cin, k, k), device=gy.device, dtype=torch.float32)
     ws = torch.empty(L.load().risp_conv_wgrad_scratch_floats(k), device=gy.device, dtype=torch.float32)
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=load, cin_img=cin_img, epilogue=0, add_c=0,
@@ -859,8 +863,8 @@ class _Stacked:
 
 
 def stack_packed(pcs):
-    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'wino_fwd', 'wino_bwd', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd', 'toep_first', 'w32'),
-                    ('cin', 'cout', 'k', 'wino_entry'))
+    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd', 'toep_first', 'w32'),
+                    ('cin', 'cout', 'k'))
 
 
 def stack_small(scs):

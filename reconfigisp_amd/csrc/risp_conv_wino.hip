@@ -1,23 +1,10 @@
-// 3x3 convolution layers on the fp32 matrix cores with a one-dimensional Winograd transform F(2,3) along x:
-// two horizontally adjacent outputs of a filter row cost 4 multiplications instead of 6, so the layer issues
-// 12 "taps" (3 filter rows x 4 transform points) per output PAIR where the direct kernel (risp_conv.hip) issues
-// 9 per output pixel - 2/3 of the MFMA work.  The 64 -> 64 3x3 layers of Path-Restore
-// (path_14l_bayer_arch.py:6-21, path_14l_bgr_arch.py:6-21) are 40 % of a search step and 85 % of tiled
-// full-frame inference.
-//
-//     y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3,   m_t = sum_{ky,ci} U[ky][t][co][ci] * V_t(row + ky, ci)
-//     U_0 = g0, U_1 = (g0 + g1 + g2) / 2, U_2 = (g0 - g1 + g2) / 2, U_3 = g2           (packed on the host)
-//     V_0 = d0 - d2, V_1 = d1 + d2, V_2 = d2 - d1, V_3 = d1 - d3,  d_j = x[2p - 1 + j]  (formed on the fly)
-// All arithmetic stays fp32; the transform constants are 1 and 1/2, so the result differs from the direct
-// convolution by a few ulp of the accumulated magnitude (tests: 1e-4 relative like every CNN stage).
-//
-// Per workgroup (4 waves): 4 output rows x 64 pixels x all couts.  Wave w owns row w; its MFMA column index
-// (lane & 31) is the pixel PAIR, so one v_mfma_f32_32x32x2_f32 covers 64 pixels of a row.  Accumulators
-// [4 transform points][CB cout blocks] = 128 VGPRs at 64 couts, the same budget as the direct kernel.
-// Per chunk of CK input channels the raw zero-padded halo tile (CK x 6 x 72) and the weight slab
-// [12][CK][cout] are staged in ping-pong LDS buffers; the global loads of the next chunk are issued from inside
-// the MFMA stream.  The B operands of the four transform points come from ONE pair of LDS reads (d0..d3) and
-// four vector subtractions/additions.
+// 3x3 and 5x5 convolution layers on the fp32 matrix cores with a one-dimensional Winograd transform along x: F(4,3) - four adjacent
+// outputs of a filter row from 6 multiplications, half the matrix work of the direct kernel (risp_conv.hip) - and F(4,5) - four outputs
+// of a 5-tap row from 8, 0.4 of it.  All arithmetic stays fp32; the row scalings of the transforms sit in the packed weights.
+// These kernels serve RISP_CONV_ARITH=f32 (bench.py's cnn_f32_* leg, the yardstick the split-precision kernels are measured against)
+// and the layers the split-precision kernels do not take (cin % 16 != 0: 5x5 backward passes with 3 or 12 input channels).
+// Round 5 removed the F(2,3) / F(2,5) kernels and the one-row F(4,5) form that no default route had reached since round 3 (their
+// measurements: NOTES.md).
 #include <cstdlib>
 #include "risp_common.h"
 
@@ -42,508 +29,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #else
 #define WSTAMP(var) do { } while (0)
 #endif
-constexpr int WTW = 64, WTH = 4;               // output tile: 64 pixels (32 pairs) x 4 rows
-constexpr int WIH = WTH + 2, WIWP = WTW + 8;    // staged rows / row stride: column c <-> image x0 - 4 + c
-constexpr int WTAPS = 12;                       // 3 filter rows x 4 transform points
+constexpr int WTH = 4;                         // output rows of a tile
+constexpr int WIH = WTH + 2;                    // staged rows
 
-
-// ---- store one 32-cout block of a wave's output row (64 pixels) from its private LDS transposition tile
-// [32 couts][64 pixels]: lane -> 4 consecutive pixels of cout rows (lane >> 4) + 4 i, i = 0..7.  Bias, residual and
-// mask values of four rows are loaded unconditionally (clamped addresses) inside wave-uniform branches, one batch
-// ahead of the arithmetic; per-element "if (epi & ADD) load" code makes hipcc wait vmcnt(0) after every load and
-// behind every earlier store (8 x 3 dependent round trips per block).
-__device__ __forceinline__ void store_block32(const risp_conv_desc &d, const float *tile, int lane, int n, int cbase, int oy,
-                                              int x0) {
-    const int q4 = 4 * (lane & 15);                    // this lane's 4 pixels inside the row
-    if (!(oy < d.H && x0 + q4 < d.W)) return;
-    const int epi = d.epilogue;
-    const size_t hw = (size_t)d.H * d.W, pix = (size_t)oy * d.W + x0 + q4;
-    const bool has_add = (epi & RISP_EPI_ADD) != 0, has_mask = (epi & RISP_EPI_MASK) != 0, has_bias = !(epi & RISP_EPI_NOBIAS);
-    float bias[2][4];
-    float4 av[2][4], mv[2][4];
-    auto load_batch = [&](int b, int slot) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = cbase + (lane >> 4) + 4 * (4 * b + i);
-            const int cc = co < d.cout ? co : d.cout - 1;                     // clamped: always a valid address
-            bias[slot][i] = has_bias ? d.bias[cc] : 0.f;
-            if (has_mask) mv[slot][i] = *reinterpret_cast<const float4 *>(d.mask + ((size_t)n * d.cout + cc) * hw + pix);
-            if (has_add) {
-                const int ca = co < d.add_c ? co : d.add_c - 1;
-                av[slot][i] = *reinterpret_cast<const float4 *>(d.add + ((size_t)n * d.add_c + ca) * hw + pix);
-            }
-        }
-    };
-    load_batch(0, 0);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        if (b == 0) load_batch(1, 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = (lane >> 4) + 4 * (4 * b + i), co = cbase + col;
-            float4 o = *reinterpret_cast<const float4 *>(tile + col * WTW + q4);
-            const float bb = bias[b][i];
-            o.x += bb; o.y += bb; o.z += bb; o.w += bb;
-            if (has_add && co < d.add_c) {
-                const float4 a = av[b][i];
-                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-            }
-            if (epi & RISP_EPI_RELU) {
-                o.x = o.x > 0.f ? o.x : 0.f;
-                o.y = o.y > 0.f ? o.y : 0.f;
-                o.z = o.z > 0.f ? o.z : 0.f;
-                o.w = o.w > 0.f ? o.w : 0.f;
-            }
-            if (has_mask) {
-                const float4 m = mv[b][i];
-                o.x = m.x > 0.f ? o.x : 0.f;
-                o.y = m.y > 0.f ? o.y : 0.f;
-                o.z = m.z > 0.f ? o.z : 0.f;
-                o.w = m.w > 0.f ? o.w : 0.f;
-            }
-            if (co < d.cout) *reinterpret_cast<float4 *>(d.y + ((size_t)n * d.cout + co) * hw + pix) = o;
-        }
-    }
-}
-
-template <int CK, int CB>
-__global__ __launch_bounds__(256, 2) void conv_wino3_kernel(const risp_conv_desc d) {
-    constexpr int CP = 32 * CB;
-    constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * CP;
-    constexpr int NXV = (XN / 4 + 255) / 256, NWV = (WN / 4 + 255) / 256;
-    constexpr int NF = NXV + NWV;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sx = smem;                                  // [2][CK][WIH][WIWP]
-    float *sw = smem + 2 * XN;                         // [2][WTAPS][CK][CP]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z;
-    const int nchunks = (d.cin + CK - 1) / CK;
-    unsigned long long t_k0 = 0, rt_k0 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, s_bar = 0, s_cmp = 0, s_pub = 0, t_begin = 0, t_loop_end = 0;
-    (void)t_k0; (void)rt_k0; (void)t0; (void)t1; (void)t2; (void)t3; (void)s_bar; (void)s_cmp; (void)s_pub; (void)t_begin; (void)t_loop_end;
-    WSTAMP(t_k0);
-#ifdef RISP_CONV_STAMPS
-    rt_k0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-    f32x16 acc[4][CB];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int c = 0; c < CB; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
-
-    const size_t hw = (size_t)d.H * d.W;
-    const float *xn = d.x + (size_t)n * d.cin * hw;
-    int xoff[NXV], xcl[NXV];
-    float4 xr[NXV], wr[NWV];
-#pragma unroll
-    for (int i = 0; i < NXV; ++i) {
-        const int v = tid + 256 * i;
-        const int cl = v / (WIH * (WIWP / 4)), rem = v - cl * (WIH * (WIWP / 4));
-        const int iy = rem / (WIWP / 4), q = rem - iy * (WIWP / 4);
-        const int gy = y0 + iy - 1, gx = x0 - 4 + 4 * q;
-        const bool ok = v < XN / 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-        xcl[i] = ok ? cl : -1;                         // -1: outside the image -> zeros
-        xoff[i] = (cl * d.H + gy) * d.W + gx;
-    }
-    auto fetch_one = [&](int ch, int j) {              // j is a compile-time constant at every call site
-        if (j < NXV) {
-            const int ci = ch * CK + xcl[j];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xcl[j] >= 0 && ci < d.cin) v = *reinterpret_cast<const float4 *>(xn + (size_t)ch * CK * hw + xoff[j]);
-            xr[j] = v;
-        } else if (j < NF) {
-            const int v = tid + 256 * (j - NXV);
-            wr[j - NXV] = (v < WN / 4) ? reinterpret_cast<const float4 *>(d.wpack + (size_t)ch * WN)[v]
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto publish = [&](int buf) {
-        float *sxb = sx + buf * XN, *swb = sw + buf * WN;
-#pragma unroll
-        for (int i = 0; i < NXV; ++i) {
-            const int v = tid + 256 * i;
-            if (256 * (i + 1) <= XN / 4 || v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];   // full rounds: no branch
-        }
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int v = tid + 256 * i;
-            if (256 * (i + 1) <= WN / 4 || v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
-        }
-    };
-
-    WSTAMP(t_begin);
-#pragma unroll
-    for (int j = 0; j < NF; ++j) fetch_one(0, j);
-    publish(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        WSTAMP(t0);
-        __syncthreads();                               // tile ch published, tile ch-1 no longer read
-        WSTAMP(t1);
-        const bool more = ch + 1 < nchunks;
-        if (more) {                                    // next chunk's global loads: in flight during this chunk's MFMAs
-#pragma unroll
-            for (int j = 0; j < NF; ++j) fetch_one(ch + 1, j);
-        }
-        // d0 of pair p sits at staged column 2p + 3 (image x0 + 2p - 1)
-        const float *bx = sx + buf * XN + (half * WIH + wave) * WIWP + 3 + 2 * l31;
-        const float *aw = sw + buf * WN + half * CP + l31;
-        // Register double-buffering of the LDS operands: group g+1 = (filter row, channel pair) is read before the
-        // 8 MFMAs of group g are issued, so LDS latency hides behind 512 cycles of matrix work.
-        constexpr int NG = 3 * (CK / 2);
-        float opa[2][4][CB], opd[2][4];
-        auto load_group = [&](int g, int slot) {
-            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
-            const float *dp = bx + (2 * cp * WIH + ky) * WIWP;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) opd[slot][j] = dp[j];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int c = 0; c < CB; ++c) opa[slot][t][c] = aw[((ky * 4 + t) * CK + 2 * cp) * CP + c * 32];
-        };
-        load_group(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int slot = g & 1;
-            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
-            __builtin_amdgcn_sched_barrier(0);         // keep the reads above this group's MFMAs (the scheduler sinks them)
-            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3];
-            const float bv[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int c = 0; c < CB; ++c)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t][c], bv[t], acc[t][c], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        WSTAMP(t2);
-        if (more) publish(buf ^ 1);
-        WSTAMP(t3);
-#ifdef RISP_CONV_STAMPS
-        s_bar += t1 - t0;
-        s_cmp += t2 - t1;
-        s_pub += t3 - t2;
-#endif
-    }
-    WSTAMP(t_loop_end);
-
-    // ---- epilogue.  Lane holds m_t[cout = cb*32 + (e&3) + 8*(e>>2) + 4*half][pair = l31]; the output row of the
-    // wave (CP couts x 64 pixels) is transposed through LDS one cout block at a time so that each lane owns 4
-    // consecutive pixels of one cout plane: residual / mask loads and the stores are 16 bytes per lane.
-    const int oy = y0 + wave;
-    __syncthreads();                                   // every wave is done with the staging tiles
-    float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
-#pragma unroll
-    for (int c = 0; c < CB; ++c) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int col = (e & 3) + 8 * (e >> 2) + 4 * half;
-            const float m0 = acc[0][c][e], m1 = acc[1][c][e], m2 = acc[2][c][e], m3 = acc[3][c][e];
-            float2 y2;
-            y2.x = m0 + m1 + m2;
-            y2.y = m1 - m2 - m3;
-            *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
-        }
-        __builtin_amdgcn_wave_barrier();               // private tile, in-order LDS: keep the compiler from reordering
-        store_block32(d, tile, lane, n, c * 32, oy, x0);
-        __builtin_amdgcn_wave_barrier();               // the tile is rewritten by the next cout block
-    }
-#ifdef RISP_CONV_STAMPS
-    if (lane == 0 && d.mask && !(d.epilogue & RISP_EPI_MASK)) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(d.mask)) +
-                                8 * ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave);
-        unsigned long long t_end;
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        WSTAMP(t_end);
-        o[0] = s_bar; o[1] = s_cmp; o[2] = s_pub;
-        o[3] = t_begin - t_k0;
-        o[4] = t_loop_end - t_begin;
-        o[5] = t_end - t_loop_end;
-        o[6] = rt_k0;
-        o[7] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------
-// 5x5 layers: F(2,5) along x - 6 multiplications per output pair and filter row instead of 10 (0.6 of the MFMA
-// work of risp_conv2d).  SRCNNRes' 64 -> 32 layer and its backward (srcnn_res_arch.py:20) are 39 % of a search
-// step.  Interpolation points 0, +-1, +-2, inf with the row scalings moved into the weights, so the on-the-fly
-// input transform has small integer coefficients:
-//     V0 = 4 d0 - 5 d2 + d4        V1 =  4 (d1 + d2) - (d3 + d4)     V2 = -4 (d1 - d2) + (d3 - d4)
-//     V3 = -2 (d1 - d3) - (d2 - d4) V4 =  2 (d1 - d3) - (d2 - d4)     V5 = 4 d1 - 5 d3 + d5,   d_j = x[2p - 2 + j]
-//     U_t = (G g)_t / (4, 6, 6, 24, 24, 1),  G = rows (1,0,0,0,0) (1,1,1,1,1) (1,-1,1,-1,1) (1,2,4,8,16) (1,-2,4,-8,16) (0,0,0,0,1)
-//     y0 = m0 + m1 + m2 + m3 + m4,   y1 = m1 - m2 + 2 m3 - 2 m4 + m5
-// fp32 emulation of a 64 -> 32 layer: rms / max error 3.7e-7 / 6.5e-7 of max|y| against 3.9e-7 / 6.0e-7 for the
-// direct fp32 convolution.  One cout block of 32 per workgroup (6 accumulator tiles = 96 VGPRs); layers with 64
-// couts put the cout block in the grid.  4 input channels per LDS stage (2 x 24.6 KB).
-constexpr int W5IH = WTH + 4, W5TAPS = 30;
-
-#ifndef RISP_W5_WAVES
-#define RISP_W5_WAVES 2
-#endif
-template <int CK>
-__global__ __launch_bounds__(256, RISP_W5_WAVES) void conv_wino5_kernel(const risp_conv_desc d_in, int ncb) {
-    constexpr int CP = 32;
-    constexpr int XN = CK * W5IH * WIWP, WN = W5TAPS * CK * CP;
-    constexpr int NXV = (XN / 4 + 255) / 256, NWV = (WN / 4 + 255) / 256;
-    constexpr int NF = NXV + NWV;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sx = smem;                                  // [2][CK][W5IH][WIWP]
-    float *sw = smem + 2 * XN;                         // [2][W5TAPS][CK][CP]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
-    const risp_conv_desc d = risp_conv_group_view(d_in, n);
-    const int nchunks = (d.cin + CK - 1) / CK;
-    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
-
-    f32x16 acc[6];
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    const size_t hw = (size_t)d.H * d.W;
-    const float *xn = d.x + (size_t)n * d.cin * hw;
-    int xoff[NXV], xcl[NXV];
-    float4 xr[NXV], wr[NWV];
-#pragma unroll
-    for (int i = 0; i < NXV; ++i) {
-        const int v = tid + 256 * i;
-        const int cl = v / (W5IH * (WIWP / 4)), rem = v - cl * (W5IH * (WIWP / 4));
-        const int iy = rem / (WIWP / 4), q = rem - iy * (WIWP / 4);
-        const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * q;
-        const bool ok = v < XN / 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-        xcl[i] = ok ? cl : -1;                         // -1: outside the image -> zeros
-        xoff[i] = (cl * d.H + gy) * d.W + gx;
-    }
-    auto fetch_one = [&](int ch, int j) {              // j is a compile-time constant at every call site
-        if (j < NXV) {
-            const int ci = ch * CK + xcl[j];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xcl[j] >= 0 && ci < d.cin) v = *reinterpret_cast<const float4 *>(xn + (size_t)ch * CK * hw + xoff[j]);
-            xr[j] = v;
-        } else if (j < NF) {
-            const int v = tid + 256 * (j - NXV);
-            wr[j - NXV] = (v < WN / 4) ? reinterpret_cast<const float4 *>(wpack + (size_t)ch * WN)[v]
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto publish = [&](int buf) {
-        float *sxb = sx + buf * XN, *swb = sw + buf * WN;
-#pragma unroll
-        for (int i = 0; i < NXV; ++i) {
-            const int v = tid + 256 * i;
-            if (256 * (i + 1) <= XN / 4 || v < XN / 4) reinterpret_cast<float4 *>(sxb)[v] = xr[i];   // full rounds: no branch
-        }
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int v = tid + 256 * i;
-            if (256 * (i + 1) <= WN / 4 || v < WN / 4) reinterpret_cast<float4 *>(swb)[v] = wr[i];
-        }
-    };
-
-#pragma unroll
-    for (int j = 0; j < NF; ++j) fetch_one(0, j);
-    publish(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        __syncthreads();                               // tile ch published, tile ch-1 no longer read
-        const bool more = ch + 1 < nchunks;
-        if (more) {                                    // next chunk's global loads: in flight during this chunk's MFMAs
-#pragma unroll
-            for (int j = 0; j < NF; ++j) fetch_one(ch + 1, j);
-        }
-        // d0 of pair p sits at staged column 2p + 2 (image x0 + 2p - 2): 8-byte aligned
-        const float *bx = sx + buf * XN + (half * W5IH + wave) * WIWP + 2 + 2 * l31;
-        const float *aw = sw + buf * WN + half * CP + l31;
-        constexpr int NG = 5 * (CK / 2);
-        float opa[2][6], opd[2][6];
-        auto load_group = [&](int g, int slot) {
-            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
-            const float *dp = bx + (2 * cp * W5IH + ky) * WIWP;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) opd[slot][j] = dp[j];
-#pragma unroll
-            for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
-        };
-        load_group(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int slot = g & 1;
-            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
-            __builtin_amdgcn_sched_barrier(0);         // keep the reads above this group's MFMAs
-            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3], d4 = opd[slot][4],
-                        d5 = opd[slot][5];
-            const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
-            // fused multiply-adds (exact products, one rounding each): 14 vector instructions instead of 22
-            const float bv[6] = {__builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4)), __builtin_fmaf(4.f, s12, -s34),
-                                 __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
-                                 __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) publish(buf ^ 1);
-    }
-
-    // ---- epilogue (as conv_wino3_kernel, one cout block)
-    const int oy = y0 + wave;
-    __syncthreads();                                   // every wave is done with the staging tiles
-    float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int col = (e & 3) + 8 * (e >> 2) + 4 * half;
-        const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
-        float2 y2;
-        y2.x = m0 + m1 + m2 + m3 + m4;
-        y2.y = m1 - m2 + 2.f * m3 - 2.f * m4 + m5;
-        *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
-    }
-    __builtin_amdgcn_wave_barrier();
-    store_block32(d, tile, lane, n, cb * 32, oy, x0);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// F(2,5) with LDS-DMA staging: conv_wino5_kernel's tile, operand reads, MFMA stream and epilogue with the staging of
-// conv_wino43_glds_kernel (see there).  The raw tile (4 x 8 x 72 floats = 9 wave-instructions of 64 x 16 bytes) and
-// the weight slab (30 x 4 x 32 floats = 15) make exactly 24 = 6 per wave; 2 LDS stages of 24 KB, 3 workgroups per CU.
-template <int WGS>
-__global__ __launch_bounds__(256, WGS) void conv_wino5_glds_kernel(const risp_conv_desc d_in, int ncb) {
-    constexpr int CK = 4, CP = 32;
-    constexpr int XN = CK * W5IH * WIWP, WN = W5TAPS * CK * CP;          // floats: 2304, 3840
-    constexpr int XI = XN / 256, WI = WN / 256, PER_WAVE = (XI + WI) / 4;
-    constexpr int STAGE = XN + WN;
-    static_assert(XN % 256 == 0 && WN % 256 == 0 && (XI + WI) % 4 == 0, "staging layout");
-    extern __shared__ __attribute__((aligned(16))) float smem[];         // [2][STAGE]; the epilogue reuses it
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
-    const risp_conv_desc d = risp_conv_group_view(d_in, n);
-    const int nchunks = d.cin / CK;
-    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
-    const size_t hw = (size_t)d.H * d.W;
-    const float *xn = d.x + (size_t)n * d.cin * hw;
-
-    f32x16 acc[6];
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    for (int v = tid; v < 2 * STAGE / 4; v += 256) reinterpret_cast<float4 *>(smem)[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const float *src0[PER_WAVE];
-    unsigned long long mask[PER_WAVE];
-    int step[PER_WAVE];
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-        const int id = wave + 4 * j;
-        bool ok;
-        if (id < XI) {
-            const int v = id * 64 + lane;
-            const int cl = v / (W5IH * (WIWP / 4)), rem = v - cl * (W5IH * (WIWP / 4));
-            const int iy = rem / (WIWP / 4), q = rem - iy * (WIWP / 4);
-            const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * q;
-            ok = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-            src0[j] = xn + ((size_t)cl * d.H + gy) * d.W + gx;
-            step[j] = CK * (int)hw;
-        } else {
-            ok = true;
-            src0[j] = wpack + 4 * ((id - XI) * 64 + lane);
-            step[j] = WN;
-        }
-        mask[j] = __builtin_amdgcn_ballot_w64(ok);
-    }
-    auto issue = [&](int ch, int buf) {
-        float *stage = smem + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const int id = wave + 4 * j;
-            lds_dma16(src0[j] + (size_t)ch * step[j], stage + id * 256, mask[j]);      // ids 0..8 tile, 9..23 slab: contiguous
-        }
-    };
-
-    __syncthreads();                                   // zeros in place before the first DMA lands
-    issue(0, 0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's part of chunk ch has landed
-        __builtin_amdgcn_s_barrier();                  // ... every wave's; the other buffer is free
-        if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
-        const float *sx = smem + buf * STAGE, *sw = sx + XN;
-        // d0 of pair p sits at staged column 2p + 2 (image x0 + 2p - 2): 8-byte aligned
-#ifndef RISP_W5_FUSED_READS
-        // three separate 8-byte reads (the second and third base made opaque): from one base + constant offsets hipcc
-        // fuses them into ds_read2_b64, 8 LDS cycles where two ds_read_b64 take 2 + 2 (1075 -> 1060 us on 64 -> 32, 32 x 256 x 256)
-        typedef __attribute__((address_space(3))) const f32x2 lds_pair;
-        const unsigned b0 = (unsigned)(size_t)(lds_pair *)(sx + (half * W5IH + wave) * WIWP + 2 + 2 * l31);
-        unsigned b1 = b0 + 8, b2 = b0 + 16;
-        asm volatile("" : "+v"(b1), "+v"(b2));
-#else
-        const float *bx = sx + (half * W5IH + wave) * WIWP + 2 + 2 * l31;
-#endif
-        const float *aw = sw + half * CP + l31;
-        constexpr int NG = 5 * (CK / 2);
-        float opa[2][6], opd[2][6];
-        auto load_group = [&](int g, int slot) {
-            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
-#ifndef RISP_W5_FUSED_READS
-            const unsigned go = (2 * cp * W5IH + ky) * WIWP * 4;
-            const f32x2 p0 = *(lds_pair *)(size_t)(b0 + go), p1 = *(lds_pair *)(size_t)(b1 + go), p2 = *(lds_pair *)(size_t)(b2 + go);
-            opd[slot][0] = p0.x; opd[slot][1] = p0.y; opd[slot][2] = p1.x; opd[slot][3] = p1.y; opd[slot][4] = p2.x; opd[slot][5] = p2.y;
-#else
-            const float *dp = bx + (2 * cp * W5IH + ky) * WIWP;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) opd[slot][j] = dp[j];
-#endif
-#pragma unroll
-            for (int t = 0; t < 6; ++t) opa[slot][t] = aw[((ky * 6 + t) * CK + 2 * cp) * CP];
-        };
-        load_group(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int slot = g & 1;
-            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const float d0 = opd[slot][0], d1 = opd[slot][1], d2 = opd[slot][2], d3 = opd[slot][3], d4 = opd[slot][4],
-                        d5 = opd[slot][5];
-            const float s12 = d1 + d2, s34 = d3 + d4, m12 = d1 - d2, m34 = d3 - d4, m13 = d1 - d3, m24 = d2 - d4;
-            const float bv[6] = {__builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4)), __builtin_fmaf(4.f, s12, -s34),
-                                 __builtin_fmaf(-4.f, m12, m34), __builtin_fmaf(-2.f, m13, -m24), __builtin_fmaf(2.f, m13, -m24),
-                                 __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5))};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---- epilogue (as conv_wino5_kernel)
-    const int oy = y0 + wave;
-    __syncthreads();                                   // every wave is done with the staging tiles
-    float *tile = smem + wave * (32 * WTW);            // [32 couts][64 pixels], private to the wave
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int col = (e & 3) + 8 * (e >> 2) + 4 * half;
-        const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
-        float2 y2;
-        y2.x = m0 + m1 + m2 + m3 + m4;
-        y2.y = m1 - m2 + 2.f * m3 - 2.f * m4 + m5;
-        *reinterpret_cast<float2 *>(tile + col * WTW + 2 * l31) = y2;
-    }
-    __builtin_amdgcn_wave_barrier();
-    store_block32(d, tile, lane, n, cb * 32, oy, x0);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // 3x3 layers, F(4,3) along x: FOUR adjacent outputs of a filter row from 6 multiplications - 18 "taps" per output
@@ -1184,111 +672,6 @@ __device__ __forceinline__ void w45_epilogue(const risp_conv_desc &d, const f32x
     }
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wino45_glds_kernel(const risp_conv_desc d_in, int ncb) {
-    constexpr int CK = 4, CP = 32, STAGES = 2;
-    constexpr int XN = CK * W45IH * W43WP, WN = W45TAPS * CK * CP;      // floats: 4352, 5120
-    constexpr int XI = XN / 256, WI = WN / 256, PIECES = XI + WI, PER_WAVE = (PIECES + 3) / 4;     // 17 + 20 wave-instructions per chunk
-    constexpr int STAGE = PIECES * 256;
-    static_assert(XN % 256 == 0 && WN % 256 == 0, "staging layout");
-    extern __shared__ __attribute__((aligned(16))) float smem[];        // [STAGES][STAGE]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int x0 = blockIdx.x * W43TW, y0 = blockIdx.y * WTH, n = blockIdx.z / ncb, cb = blockIdx.z - n * ncb;
-    const risp_conv_desc d = risp_conv_group_view(d_in, n);
-    const int nchunks = (d.cin + CK - 1) / CK;         // cin % 4 != 0 only with a single chunk (cin < 4): see the masks below
-    const float *__restrict__ wpack = d.wpack + (size_t)cb * nchunks * WN;
-    const size_t hw = (size_t)d.H * d.W;
-    const float *xn = d.x + (size_t)n * d.cin * hw;
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    // zero the whole staging area once (lanes outside the image are masked out of every transfer and keep their zeros)
-    for (int v = tid; v < STAGES * STAGE / 4; v += 256) reinterpret_cast<float4 *>(smem)[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // this wave's DMA slots: id = wave + 4 j; ids 0..16 input tile, 17..36 weight slab
-    const float *src0[PER_WAVE];
-    unsigned long long mask[PER_WAVE];
-    int step[PER_WAVE];
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-        const int id = wave + 4 * j;
-        bool ok = false;
-        src0[j] = xn;
-        step[j] = 0;
-        if (id < XI) {
-            const int v = id * 64 + lane;
-            const int cl = v / (W45IH * (W43WP / 4)), rem = v - cl * (W45IH * (W43WP / 4));
-            const int iy = rem / (W43WP / 4), q = rem - iy * (W43WP / 4);
-            const int gy = y0 + iy - 2, gx = x0 - 4 + 4 * q;
-            // (the masks are the same in every chunk; a channel beyond cin exists only when the layer is ONE chunk)
-            ok = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cl < d.cin;
-            src0[j] = xn + ((size_t)(cl < d.cin ? cl : 0) * d.H + gy) * d.W + gx;
-            step[j] = CK * (int)hw;
-        } else if (id < PIECES) {
-            ok = true;
-            src0[j] = wpack + 4 * ((id - XI) * 64 + lane);
-            step[j] = WN;
-        }
-        mask[j] = __builtin_amdgcn_ballot_w64(ok);
-    }
-    auto issue = [&](int ch, int buf) {
-        float *stage = smem + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const int id = wave + 4 * j;
-            if (id < PIECES) lds_dma16(src0[j] + (size_t)ch * step[j], stage + id * 256, mask[j]);     // wave-uniform branch
-        }
-    };
-
-    __syncthreads();                                   // zeros in place before the first DMA lands
-    if (nchunks > 0) issue(0, 0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's transfers of chunk ch have landed
-        __builtin_amdgcn_s_barrier();                  // ... for every wave; the other buffer is free
-        if (ch + 1 < nchunks) issue(ch + 1, buf ^ 1);
-        const float *sx = smem + buf * STAGE, *sw = sx + XN;
-        const f32x4 *bx = reinterpret_cast<const f32x4 *>(sx + (half * W45IH + wave) * W43WP) + l31;
-        const float *aw = sw + half * CP + l31;
-        constexpr int NG = 5 * (CK / 2);
-        float opa[2][8];
-        f32x4 opd[2][3];
-        auto load_group = [&](int g, int slot) {
-            const int ky = g / (CK / 2), cp = g - ky * (CK / 2);
-            const f32x4 *dp = bx + (2 * cp * W45IH + ky) * (W43WP / 4);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) opd[slot][j] = dp[j];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) opa[slot][t] = aw[((ky * 8 + t) * CK + 2 * cp) * CP];
-        };
-        load_group(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int slot = g & 1;
-            if (g + 1 < NG) load_group(g + 1, slot ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+v"(opd[slot][0]), "+v"(opd[slot][2]));
-            const float d0 = opd[slot][0].z, d1 = opd[slot][0].w, d2 = opd[slot][1].x, d3 = opd[slot][1].y, d4 = opd[slot][1].z,
-                        d5 = opd[slot][1].w, d6 = opd[slot][2].x, d7 = opd[slot][2].y;
-            const float e1 = __builtin_fmaf(4.f, d2 + d6, -17.f * d4), o1 = __builtin_fmaf(4.f, d1 + d5, -17.f * d3);
-            const float e3 = __builtin_fmaf(4.f, d6, __builtin_fmaf(-5.f, d4, d2)), o3 = __builtin_fmaf(4.f, d5, __builtin_fmaf(-5.f, d3, d1));
-            const float e5 = __builtin_fmaf(4.f, d2, __builtin_fmaf(-5.f, d4, d6)), o5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
-            const float bv[8] = {__builtin_fmaf(5.25f, d4 - d2, d0 - d6), e1 + o1, e1 - o1, __builtin_fmaf(2.f, o3, e3),
-                                 __builtin_fmaf(-2.f, o3, e3), __builtin_fmaf(2.f, e5, o5), __builtin_fmaf(2.f, e5, -o5),
-                                 __builtin_fmaf(5.25f, d3 - d5, d7 - d1)};
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[slot][t], bv[t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    w45_epilogue<4>(d, acc, n, cb, y0 + wave, x0 + 4 * l31, half);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // F(4,5) with TWO output rows per wave on 16x16x4 tiles (round 3).  A vector instruction costs its own 4-5 cycles of matrix
 // time (tools/mfma_valu.hip) and F(4,5)'s input transform is 26 of them per staged row: in conv_wino45_glds_kernel a wave
@@ -1512,65 +895,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino45_r2_kernel(const risp_conv_
     w45r2_epilogue<4>(d, acc, n, cb, y0 + 2 * rp, x0 + 4 * (16 * xh + q), kk);
 }
 
-template <int CK, int CB>
-int launch_wino(const risp_conv_desc &d, hipStream_t s) {
-    constexpr int XN = CK * WIH * WIWP, WN = WTAPS * CK * 32 * CB;
-    size_t lds = sizeof(float) * 2 * (XN + WN);
-    const size_t epi = sizeof(float) * 4 * 32 * WTW;   // the epilogue's four private transposition tiles
-    if (lds < epi) lds = epi;
-    dim3 grid((d.W + WTW - 1) / WTW, (d.H + WTH - 1) / WTH, d.N);
-    if (lds > 64 * 1024) {                              // gfx950: 160 KB of LDS per CU, two workgroups share it
-        // set on every launch (idempotent, a host-side table update): the library keeps no mutable state of its own,
-        // as include/risp.h promises
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino3_kernel<CK, CB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            risp_set_error("risp_conv2d_wino3: cannot raise the dynamic LDS limit to %zu bytes", lds);
-            return 2;
-        }
-    }
-    hipLaunchKernelGGL((conv_wino3_kernel<CK, CB>), grid, dim3(256), lds, s, d);
-    RISP_LAUNCH_CHECK("risp_conv2d_wino3");
-    return 0;
-}
-
 }  // namespace
 
 extern "C" {
-
-#ifndef RISP_WINO_CK
-#define RISP_WINO_CK 8
-#endif
-constexpr int WCK = RISP_WINO_CK;                      // input channels per LDS stage (and per weight-pack chunk)
-
-int risp_conv_wino3_chunk(void) { return WCK; }
-
-size_t risp_conv_wino3_wpack_floats(int cin, int cout) {
-    const int cb = cout > 32 ? 2 : 1;
-    return (size_t)((cin + WCK - 1) / WCK) * WTAPS * WCK * 32 * cb;
-}
-
-int risp_conv2d_wino3(const risp_conv_desc *dp, void *stream) {
-    RISP_CHECK_ARG(dp, "risp_conv2d_wino3: null descriptor");
-    const risp_conv_desc &d = *dp;
-    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino3: null tensor");
-    RISP_CHECK_ARG(d.group_n == 0, "risp_conv2d_wino3: grouped launches are not supported by the 3x3 Winograd kernels");
-    RISP_CHECK_ARG(d.N > 0 && d.N <= 65535 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 &&
-                       d.ksize == 3,
-                   "risp_conv2d_wino3: needs a 3x3 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,
-                   d.W, d.cin, d.cout, d.ksize);
-    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_wino3: only plain loads");
-    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
-                   "risp_conv2d_wino3: epilogue %d not supported", d.epilogue);
-    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_wino3: bias missing");
-    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_wino3: add tensor missing");
-    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_wino3: mask tensor missing");
-    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
-                     reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
-                   "risp_conv2d_wino3: tensors must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    if (d.cout > 32) return launch_wino<WCK, 2>(d, s);
-    return launch_wino<WCK, 1>(d, s);
-}
 
 constexpr int W43CK = 4;
 int risp_conv_wino43_chunk(void) { return W43CK; }
@@ -1601,8 +928,7 @@ int risp_conv2d_wino43(const risp_conv_desc *dp, void *stream) {
     constexpr int XN = W43CK * WIH * W43WP, WN = W43TAPS * W43CK * 32;
     dim3 grid((d.W + W43TW - 1) / W43TW, (d.H + WTH - 1) / WTH, d.N * ncb);
 #ifndef RISP_W43_NO_GLDS
-    static const bool b2 = [] { const char *e = getenv("RISP_W43_B2"); return e ? atoi(e) != 0 : RISP_W43_B2 != 0; }();   // A/B switch (tools/ab_env.sh)
-    if (b2 && d.cin % 4 == 0 && ncb == 2) {            // both cout blocks per wave: 12 accumulator tiles, 2 workgroups per CU
+    if (RISP_W43_B2 && d.cin % 4 == 0 && ncb == 2) {            // both cout blocks per wave: 12 accumulator tiles, 2 workgroups per CU
         hipLaunchKernelGGL(conv_wino43_b2_kernel, dim3(grid.x, grid.y, d.N), dim3(256), sizeof(float) * 2 * 31 * 256, (hipStream_t)stream, d);
         RISP_LAUNCH_CHECK("risp_conv2d_wino43");
         return 0;
@@ -1633,55 +959,9 @@ int risp_conv2d_wino43(const risp_conv_desc *dp, void *stream) {
     return 0;
 }
 
-constexpr int W5CK = 4;
-int risp_conv_wino5_chunk(void) { return W5CK; }
-
-size_t risp_conv_wino5_wpack_floats(int cin, int cout) {
-    return (size_t)((cout + 31) / 32) * ((cin + W5CK - 1) / W5CK) * W5TAPS * W5CK * 32;
-}
-
-int risp_conv2d_wino5(const risp_conv_desc *dp, void *stream) {
-    RISP_CHECK_ARG(dp, "risp_conv2d_wino5: null descriptor");
-    const risp_conv_desc &d = *dp;
-    RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_wino5: null tensor");
-    RISP_CHECK_GROUP(d, "risp_conv2d_wino5");
-    RISP_CHECK_ARG(d.N > 0 && d.H > 0 && d.W > 0 && d.W % 4 == 0 && d.cin > 0 && d.cout > 0 && d.cout <= 64 && d.ksize == 5 &&
-                       (size_t)d.N * ((d.cout + 31) / 32) <= 65535,
-                   "risp_conv2d_wino5: needs a 5x5 layer, cout <= 64, W %% 4 == 0 (N=%d H=%d W=%d cin=%d cout=%d k=%d)", d.N, d.H,
-                   d.W, d.cin, d.cout, d.ksize);
-    RISP_CHECK_ARG(d.load_mode == RISP_LOAD_PLAIN, "risp_conv2d_wino5: only plain loads");
-    RISP_CHECK_ARG(!(d.epilogue & ~(RISP_EPI_RELU | RISP_EPI_ADD | RISP_EPI_MASK | RISP_EPI_NOBIAS)),
-                   "risp_conv2d_wino5: epilogue %d not supported", d.epilogue);
-    RISP_CHECK_ARG((d.epilogue & RISP_EPI_NOBIAS) || d.bias, "risp_conv2d_wino5: bias missing");
-    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_ADD) || (d.add && d.add_c > 0), "risp_conv2d_wino5: add tensor missing");
-    RISP_CHECK_ARG(!(d.epilogue & RISP_EPI_MASK) || d.mask, "risp_conv2d_wino5: mask tensor missing");
-    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
-                     reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
-                   "risp_conv2d_wino5: tensors must be 16-byte aligned");
-    const int ncb = (d.cout + 31) / 32;
-    constexpr int XN = W5CK * W5IH * WIWP, WN = W5TAPS * W5CK * 32;
-    size_t lds = sizeof(float) * 2 * (XN + WN);
-    const size_t epi = sizeof(float) * 4 * 32 * WTW;
-    if (lds < epi) lds = epi;
-    dim3 grid((d.W + WTW - 1) / WTW, (d.H + WTH - 1) / WTH, d.N * ncb);
-#ifndef RISP_W5_NO_GLDS
-    if (d.cin % 4 == 0) {                              // LDS-DMA staging, 3 workgroups per CU
-#ifndef RISP_W5_GLDS_WGS
-#define RISP_W5_GLDS_WGS 3
-#endif
-        hipLaunchKernelGGL(conv_wino5_glds_kernel<RISP_W5_GLDS_WGS>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
-        RISP_LAUNCH_CHECK("risp_conv2d_wino5");
-        return 0;
-    }
-#endif
-    hipLaunchKernelGGL(conv_wino5_kernel<W5CK>, grid, dim3(256), lds, (hipStream_t)stream, d, ncb);
-    RISP_LAUNCH_CHECK("risp_conv2d_wino5");
-    return 0;
-}
-
 int risp_conv_wino45_chunk(void) { return 4; }
 
-int risp_conv_wino45_layout(void) { return RISP_W45_R2 ? 1 : 0; }
+int risp_conv_wino45_layout(void) { return 1; }
 
 size_t risp_conv_wino45_wpack_floats(int cin, int cout) {
     return (size_t)((cout + 31) / 32) * ((cin + 3) / 4) * W45TAPS * 4 * 32;
@@ -1707,7 +987,7 @@ int risp_conv2d_wino45(const risp_conv_desc *dp, void *stream) {
                    "risp_conv2d_wino45: tensors must be 16-byte aligned");
     const int ncb = (d.cout + 31) / 32;
     const size_t lds = sizeof(float) * 2 * (4 * W45IH * W43WP + W45TAPS * 4 * 32);
-    const auto kernel = RISP_W45_R2 ? &conv_wino45_r2_kernel : &conv_wino45_glds_kernel;      // the two read different slab layouts
+    const auto kernel = &conv_wino45_r2_kernel;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         risp_set_error("risp_conv2d_wino45: cannot raise the dynamic LDS limit to %zu bytes", lds);
         return 2;

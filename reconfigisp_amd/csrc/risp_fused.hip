@@ -327,4 +327,14 @@ int risp_bilateral_chain_fwd(const float *in, int from_bayer, float *out_demosai
     return 0;
 }
 
+const char *risp_bilateral_chain_kernel(int from_bayer, int max_window, int with_wb_quadratic) {
+    // the instance the dispatch above launches for these arguments, as a profiler prints it (profiles/traffic.json is keyed on it)
+    static const char *names[2][2][2] = {
+        {{"bilateral_chain_kernel<false,0,false>", "bilateral_chain_kernel<false,0,true>"},
+         {"bilateral_chain_kernel<false,1,false>", "bilateral_chain_kernel<false,1,true>"}},
+        {{"bilateral_chain_kernel<true,0,false>", "bilateral_chain_kernel<true,0,true>"},
+         {"bilateral_chain_kernel<true,1,false>", "bilateral_chain_kernel<true,1,true>"}}};
+    return names[from_bayer ? 1 : 0][max_window / 2 == 1 ? 1 : 0][with_wb_quadratic ? 1 : 0];
+}
+
 }  // extern "C"

@@ -323,7 +323,17 @@ __global__ __launch_bounds__(256) void sse_u8_kernel(const float *__restrict__ a
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sse, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) sse[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);      // this workgroup's slot
+}
+
+// sse[0] = the workgroups' partial sums in index order (lane l: l, l + 64, ...; a fixed tree over the lanes): the same bits on every
+// run (round 4 merged them with a double atomicAdd)
+__global__ __launch_bounds__(64) void sse_finish_kernel(double *__restrict__ sse, int n) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) acc += sse[1 + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (threadIdx.x == 0) sse[0] = acc;
 }
 
 }  // namespace
@@ -473,15 +483,14 @@ int risp_plane_sums(const float *x, float *out, int N, int C, int c0, int nc, in
     return 0;
 }
 
+size_t risp_sse_uint8_doubles(void) { return 1 + 1024; }
+
 int risp_sse_uint8(const float *a, const float *b, double *sse, size_t numel, void *stream) {
     RISP_CHECK_ARG(a && b && sse && numel > 0, "risp_sse_uint8: bad arguments");
-    if (hipMemsetAsync(sse, 0, sizeof(double), (hipStream_t)stream) != hipSuccess) {
-        risp_set_error("risp_sse_uint8: memset failed");
-        return 2;
-    }
     size_t b_ = (numel + 256 * 16 - 1) / (256 * 16);
     int grid = (int)(b_ < 1 ? 1 : (b_ > 1024 ? 1024 : b_));
     hipLaunchKernelGGL(sse_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, sse, numel);
+    hipLaunchKernelGGL(sse_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sse, grid);
     RISP_LAUNCH_CHECK("risp_sse_uint8");
     return 0;
 }

@@ -128,15 +128,9 @@ SIGNATURES = {
     'risp_srcnn_case_table_group': (_i, [_f, C.POINTER(SrcnnGroupDesc), _f, _s]),
     'risp_srcnn_const_grad_group': (_i, [_f, C.POINTER(SrcnnGroupDesc), _f, _i, _s]),
     'risp_group_sum': (_i, [_f, _f, _i, _i, _i, _i, _f, _i, _f, _s]),
-    'risp_conv_wino3_chunk': (_i, []),
-    'risp_conv_wino3_wpack_floats': (_z, [_i, _i]),
-    'risp_conv2d_wino3': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wino43_chunk': (_i, []),
     'risp_conv_wino43_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino43': (_i, [C.POINTER(ConvDesc), _s]),
-    'risp_conv_wino5_chunk': (_i, []),
-    'risp_conv_wino5_wpack_floats': (_z, [_i, _i]),
-    'risp_conv2d_wino5': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_wino45_chunk': (_i, []),
     'risp_conv_wino45_layout': (_i, []),
     'risp_conv_wino45_wpack_floats': (_z, [_i, _i]),
@@ -169,6 +163,8 @@ SIGNATURES = {
     'risp_raw_crop': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _fl, _s]),
     'risp_gt_crop': (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _s]),
     'risp_resize_rggb': (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _s]),
+    'risp_bilateral_chain_kernel': (C.c_char_p, [_i, _i, _i]),
+    'risp_sse_uint8_doubles': (_z, []),
     'risp_sse_uint8': (_i, [_f, _f, _f, _z, _s]),
     'risp_prune_softmax_fwd': (_i, [_f, _f, _fl, _i, _f, _f, _f, _s]),
     'risp_prune_softmax_bwd': (_i, [_f, _f, _f, _i, _f, _s]),

@@ -50,13 +50,12 @@ def test_srcnn_demosaic_vs_reference_golden():
     _golden_case('srcnn_demosaic', 'srcnn_demosaic')
 
 
-@pytest.mark.parametrize('f43_train', [True, False])
-def test_path14l_vs_reference_golden(f43_train, monkeypatch):
-    """forward + input gradient of both Path-Restore nets against the reference goldens, with the 3x3 training passes on
-    F(4,3) (the default) and on F(2,3) (RISP_F43_TRAIN=0)"""
+@pytest.mark.parametrize('arith', ['f16x2', 'f32'])
+def test_path14l_vs_reference_golden(arith, monkeypatch):
+    """forward + input gradient of both Path-Restore nets against the reference goldens, with the 3x3 layers in split precision
+    on the f16 matrix pipe (the default) and on the fp32 F(4,3) kernels (RISP_CONV_ARITH=f32)"""
     from reconfigisp_amd import convnets as CN
-    monkeypatch.setattr(CN, 'F43_TRAIN', f43_train)
-    monkeypatch.setattr(CN, 'F43_MIN_GRID', 0 if f43_train else 1 << 30)
+    monkeypatch.setattr(CN, 'CONV_ARITH', arith)
     _golden_case('path14l_bayer', 'path14l_bayer')
     _golden_case('path14l_bayer_40x72', 'path14l_bayer')
     _golden_case('path14l_bgr', 'path14l_bgr')

@@ -90,7 +90,8 @@ def test_const_channel_load():
 
 
 @pytest.mark.parametrize('cin,cout,k,hw', [(32, 3, 5, (16, 16)), (64, 32, 5, (24, 40)), (17, 64, 9, (20, 36)),
-                                           (64, 64, 3, (33, 30)), (3, 64, 3, (8, 8))])
+                                           (64, 64, 3, (33, 30)), (3, 64, 3, (8, 8)), (3, 64, 9, (20, 36)), (6, 40, 5, (17, 19)),
+                                           (40, 6, 5, (19, 35)), (24, 3, 9, (20, 36)), (10, 10, 3, (9, 18)), (5, 5, 1, (8, 8))])
 def test_backward_weight(cin, cout, k, hw):
     from reconfigisp_amd import convnets as CN
     h, w = hw
@@ -103,6 +104,32 @@ def test_backward_weight(cin, cout, k, hw):
     gw, gb = CN.conv_wgrad(x, gy, cin, cout, k, n, h, w)
     assert_close(gw, gw_ref, what='dW')
     assert_close(gb, gb_ref, what='db')
+    gw2, gb2 = CN.conv_wgrad(x, gy, cin, cout, k, n, h, w)               # per-workgroup partial sums added in index order: no atomics
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    big = 40                                                            # more pixel tiles than slices: every workgroup walks several
+    xb, gyb = rnd(big, cin, h, w, seed=25), rnd(big, cout, h, w, seed=26)
+    gwb, _ = CN.conv_wgrad(xb, gyb, cin, cout, k, big, h, w)
+    wd = wt.double().detach().requires_grad_(True)
+    gwb_ref, = torch.autograd.grad(TF.conv2d(xb.double(), wd, None, padding=k // 2), wd, gyb.double())
+    assert_close(gwb, gwb_ref, what='dW, 40 images')
+    assert torch.equal(gwb, CN.conv_wgrad(xb, gyb, cin, cout, k, big, h, w)[0])
+
+
+@pytest.mark.parametrize('P,hw', [(1, (20, 36)), (5, (33, 30))])
+def test_backward_weight_of_the_first_layer_with_constant_planes(P, hw):
+    """SRCNNRes' first layer (srcnn_res_arch.py:41-46): 3 image channels through the matrix kernel, the 9 + P constant planes as
+    cvals^T @ rectangle sums - against autograd on the materialised (N, 12 + P, H, W) input"""
+    from reconfigisp_amd import convnets as CN
+    h, w = hw
+    n, k, cout = 3, 9, 64
+    x, cv, gy = rnd(n, 3, h, w, seed=31), rnd(n, 9 + P, seed=32), rnd(n, cout, h, w, seed=33)
+    wd = torch.zeros(cout, 12 + P, k, k, device='cuda', dtype=torch.float64, requires_grad=True)
+    full = torch.cat([x, cv[:, :, None, None].expand(-1, -1, h, w)], dim=1).double()
+    ref, = torch.autograd.grad(TF.conv2d(full, wd, None, padding=k // 2), wd, gy.double())
+    gw, gb = CN.conv_wgrad(x, gy, 12 + P, cout, k, n, h, w, load=CN.LOAD_CONSTCH, cin_img=3, cvals=cv)
+    assert_close(gw, ref, what='dW of the first layer')
+    assert_close(gb, gy.double().sum(dim=(0, 2, 3)), what='db')
+    assert torch.equal(gw, CN.conv_wgrad(x, gy, 12 + P, cout, k, n, h, w, load=CN.LOAD_CONSTCH, cin_img=3, cvals=cv)[0])
 
 
 def test_srcnn_res_weight_gradients_vs_oracle():
@@ -367,18 +394,17 @@ def test_small_split_pixelshuffle_store(cin, cout, k, groups):
 @pytest.mark.parametrize('cin,cout', [(64, 64), (4, 64), (64, 33), (3, 64), (64, 3)])
 @pytest.mark.parametrize('hw', SIZES + [(12, 128), (6, 260)])
 def test_inference_dispatch_f43(cin, cout, hw, monkeypatch):
-    """3x3 layers whose activations no backward pass reads go through risp_conv2d_wino43 (F(4,3)), the others
-    through F(2,3).  Both against PyTorch, every epilogue the kernels share."""
+    """3x3 layers on the fp32 route go through risp_conv2d_wino43 (F(4,3)), inference and training launches alike: against PyTorch,
+    every epilogue the kernel has."""
     from reconfigisp_amd import convnets as CN
     h, w = hw
     n = 2
     wt, b = rnd(cout, cin, 3, 3, seed=71) * 0.1, rnd(cout, seed=72) * 0.1
     pc = CN.PackedConv(wt, b)
-    assert pc.wino43_fwd is not None and pc.wino_fwd is not None
+    assert pc.wino43_fwd is not None
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
     x, add, mask = rnd(n, cin, h, w, seed=73), rnd(n, cout, h, w, seed=74), rnd(n, cout, h, w, seed=75)
     lin = TF.conv2d(x, wt, b, padding=1)
-    monkeypatch.setattr(CN, 'F43_MIN_GRID', 0)
-    monkeypatch.setattr(CN, 'F43_TRAIN', False)         # infer=False -> F(2,3) (the RISP_F43_TRAIN=0 form), infer=True -> F(4,3)
     for infer in (True, False):
         assert_close(CN.conv(x, pc, n, h, w, infer=infer), lin, what='plain infer=%s' % infer)
         assert_close(CN.conv(x, pc, n, h, w, epi=CN.EPI_ADD | CN.EPI_RELU, add=add, add_c=cout, infer=infer),
@@ -423,7 +449,7 @@ def test_f43_both_cout_blocks_in_one_wave_equals_per_block_launches(cout, hw, mo
 
 
 # ---------------------------------------------------------------------------------------------------
-# randomized layer shapes through the dispatching wrappers (direct / F(2,3) / F(4,3) / F(2,5) / small-cout kernels)
+# randomized layer shapes through the dispatching wrappers (direct / F(4,3) / F(4,5) / split-precision / small-cout kernels)
 import os
 _FUZZ = int(os.environ.get('RISP_TEST_SEEDS', '8')) * 6            # soak runs: RISP_TEST_SEEDS=64
 
@@ -431,8 +457,7 @@ _FUZZ = int(os.environ.get('RISP_TEST_SEEDS', '8')) * 6            # soak runs: 
 @pytest.mark.parametrize('seed', range(_FUZZ))
 def test_random_layer_shapes(seed, monkeypatch):
     from reconfigisp_amd import convnets as CN
-    monkeypatch.setattr(CN, 'F43_TRAIN', seed % 2 == 0)             # every other case: F(2,3) for the infer=False passes
-    monkeypatch.setattr(CN, 'F43_MIN_GRID', 0 if seed % 4 < 2 else 1 << 30)   # ... and for the backward-data pass
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f16x2' if seed % 2 == 0 else 'f32')      # every other case on the fp32 routes
     rng = np.random.default_rng(9000 + seed)
     k = int(rng.choice([1, 3, 3, 5, 5, 9]))
     cin, cout = int(rng.integers(1, 65)), int(rng.integers(1, 65))
@@ -490,7 +515,6 @@ def test_linear_k_9x9_over_three_channels(cout, hw, monkeypatch):
     table = rnd(3 * n, cout, 9, 9, seed=51) * 0.1
 
     def launch(pc, xx, tab, epi, group=None):
-        assert CN.K3
         calls = []
         real = L.call
         L.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
@@ -520,11 +544,11 @@ def test_linear_k_9x9_over_three_channels(cout, hw, monkeypatch):
         assert torch.equal(yg[g * n:(g + 1) * n], single)
         assert_close(single, with_table(g), what='k3 member %d' % g)
     # the general kernel on the same layer
-    CN.K3 = False
+    keep, packs[0].k3 = packs[0].k3, None               # (no pack, no route: route() falls through to risp_conv2d)
     try:
         general = CN.conv(x, packs[0], n, h, w)
     finally:
-        CN.K3 = True
+        packs[0].k3 = keep
     assert_close(launch(packs[0], x, None, 0), general, rtol=1e-5, floor=1.0, what='k3 vs general kernel')
 
 
@@ -557,3 +581,42 @@ def test_linear_k_first_layers(k, cin, cout, hw, monkeypatch):
         L.call = real
     assert calls == ['risp_conv2d_k3'], calls
     assert_close(y, torch.relu(TF.conv2d(planes, wt, b, padding=k // 2)), what='linear-k %dx%d %d->%d' % (k, k, cin, cout))
+
+
+@pytest.mark.parametrize('arith', ['f16x2', 'f32'])
+def test_conv_launches_what_route_says(arith, monkeypatch):
+    """``conv`` / ``conv_small`` launch the entry point ``route`` / ``route_small`` name, for the layers of tests/test_route_table_cpu.py
+    (the packs a layer holds are those ``pack_kinds`` lists), and every route meets PyTorch"""
+    from reconfigisp_amd import convnets as CN, lib as L
+    monkeypatch.setattr(CN, 'CONV_ARITH', arith)
+    calls = []
+    real = L.call
+    monkeypatch.setattr(CN.L, 'call', lambda name, *a: (calls.append(name), real(name, *a))[1])
+    n, h, w = 2, 24, 64
+    for k, cin, cout in ((9, 3, 64), (5, 64, 32), (5, 32, 3), (1, 64, 32), (3, 64, 64), (3, 3, 64), (3, 64, 3), (5, 32, 12)):
+        wt, b = rnd(cout, cin, k, k, seed=300 + k + cin) * (0.5 / k), rnd(cout, seed=301) * 0.1
+        pc = CN.PackedConv(wt, b)
+        for transpose in (False, True):
+            assert CN._have(pc, transpose) == CN.pack_kinds(k, cin, cout, transpose)
+            ci, co = (cout, cin) if transpose else (cin, cout)
+            x = rnd(n, ci, h, w, seed=302)
+            for infer in (False, True):
+                if transpose and infer:
+                    continue
+                calls.clear()
+                epi = 0 if transpose else CN.EPI_RELU
+                y = CN.conv(x, pc, n, h, w, transpose=transpose, epi=epi, infer=infer)
+                want = CN.route(k, ci, co, h, w, transpose, CN.LOAD_PLAIN, epi | (CN.EPI_NOBIAS if transpose else 0), 0, infer, True,
+                                CN.pack_kinds(k, cin, cout, transpose))
+                assert calls[-1] == want, (k, cin, cout, transpose, infer, calls, want)
+                ref = TF.conv_transpose2d(x, wt, padding=k // 2) if transpose else torch.relu(TF.conv2d(x, wt, b, padding=k // 2))
+                assert_close(y, ref, what='%s k%d %d->%d T%d' % (want, k, cin, cout, transpose))
+        if cout <= 12:
+            sc = CN.SmallConv(wt, b)
+            x = rnd(n, cin, h, w, seed=303)
+            for infer in (False, True):
+                calls.clear()
+                y = CN.conv_small(x, sc, n, h, w, infer=infer)
+                want = CN.route_small(k, cin, cout, h, w, n, infer, False, CN.small_has_toep(k, cout))
+                assert calls[-1] in (want, want + '_split'), (k, cin, cout, infer, calls, want)
+                assert_close(y, TF.conv2d(x, wt, b, padding=k // 2), what='%s k%d %d->%d' % (want, k, cin, cout))

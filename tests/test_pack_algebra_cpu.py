@@ -1,5 +1,5 @@
 """CPU checks of the weight algebra behind three kernels (pure tensor code in reconfigisp_amd/convnets.py; the
-kernels themselves are tested on the GPU): the Winograd F(2,3) packs, the small-cout packs, and the tables that
+kernels themselves are tested on the GPU): the Winograd F(4,3) / F(4,5) packs, the small-cout packs, and the tables that
 fold SRCNNRes' broadcast planes out of its 9x9 layer.  Each is emulated with plain torch ops in the exact way the
 kernel consumes the pack and compared with torch.nn.functional.conv2d (fp64, so only the algebra is on trial)."""
 import numpy as np
@@ -13,69 +13,6 @@ from reconfigisp_amd import convnets as CN
 def rnd(*shape, seed):
     g = np.random.Generator(np.random.PCG64(seed))
     return torch.from_numpy(g.standard_normal(shape))
-
-
-def wino_emulate(x, pack, ck, cout):
-    """What conv_wino3_kernel computes from its pack: m_t = sum_{ky,ci} U[ky][t][co][ci] V_t(row+ky, ci)."""
-    n, cin, h, w = x.shape
-    xp = TF.pad(x, (1, 3, 1, 1))                               # zero 'same' padding (+2 so that odd tails exist)
-    npairs = (w + 1) // 2
-    d = torch.stack([xp[:, :, :, j:j + 2 * npairs:2] for j in range(4)], dim=-1)      # (n,ci,h+2,pairs,4): d_j = x[2p-1+j]
-    v = torch.stack([d[..., 0] - d[..., 2], d[..., 1] + d[..., 2], d[..., 2] - d[..., 1], d[..., 1] - d[..., 3]], dim=-1)
-    u = pack.permute(0, 3, 1, 2, 4).reshape(-1, 3, 4, pack.shape[-1])[:cin, :, :, :cout]   # (ci, ky, t, co)
-    m = torch.zeros(n, cout, h, npairs, 4, dtype=x.dtype)
-    for ky in range(3):
-        m += torch.einsum('nchpt,cto->nohpt', v[:, :, ky:ky + h], u[:, ky])
-    y = torch.zeros(n, cout, h, 2 * npairs, dtype=x.dtype)
-    y[..., 0::2] = m[..., 0] + m[..., 1] + m[..., 2]
-    y[..., 1::2] = m[..., 1] - m[..., 2] - m[..., 3]
-    return y[..., :w]
-
-
-@pytest.mark.parametrize('cin,cout,ck', [(64, 64, 8), (5, 3, 8), (12, 33, 4)])
-def test_winograd_pack_forward_and_backward_data(cin, cout, ck):
-    wt = rnd(cout, cin, 3, 3, seed=1)
-    x = rnd(2, cin, 6, 10, seed=2).requires_grad_(True)
-    ref = TF.conv2d(x, wt, None, padding=1)
-    got = wino_emulate(x.detach(), CN.wino3_weights(wt, False, ck), ck, cout)
-    assert torch.allclose(got, ref.detach(), rtol=1e-10, atol=1e-10)
-    gy = rnd(2, cout, 6, 10, seed=3)
-    gref, = torch.autograd.grad(ref, x, gy)
-    got = wino_emulate(gy, CN.wino3_weights(wt, True, ck), ck, cin)
-    assert torch.allclose(got, gref, rtol=1e-10, atol=1e-10)
-
-
-def wino5_emulate(x, pack, ck, cout):
-    """What conv_wino5_kernel computes from its pack (scaled F(2,5) input transform, 6 points)."""
-    n, cin, h, w = x.shape
-    xp = TF.pad(x, (2, 5, 2, 2))
-    npairs = (w + 1) // 2
-    d = [xp[:, :, :, j:j + 2 * npairs:2] for j in range(6)]              # d_j = x[2p - 2 + j]
-    s12, s34, m12, m34, m13, m24 = d[1] + d[2], d[3] + d[4], d[1] - d[2], d[3] - d[4], d[1] - d[3], d[2] - d[4]
-    v = torch.stack([4 * d[0] - 5 * d[2] + d[4], 4 * s12 - s34, m34 - 4 * m12, -2 * m13 - m24, 2 * m13 - m24,
-                     4 * d[1] - 5 * d[3] + d[5]], dim=-1)                # (n,ci,h+4,pairs,6)
-    ncb, nch = pack.shape[0], pack.shape[1]
-    u = pack.permute(0, 5, 1, 4, 2, 3).reshape(ncb * 32, nch * ck, 5, 6)[:cout, :cin]     # (co, ci, ky, t)
-    m = torch.zeros(n, cout, h, npairs, 6, dtype=x.dtype)
-    for ky in range(5):
-        m += torch.einsum('nchpt,oct->nohpt', v[:, :, ky:ky + h], u[:, :, ky])
-    y = torch.zeros(n, cout, h, 2 * npairs, dtype=x.dtype)
-    y[..., 0::2] = m[..., 0] + m[..., 1] + m[..., 2] + m[..., 3] + m[..., 4]
-    y[..., 1::2] = m[..., 1] - m[..., 2] + 2 * m[..., 3] - 2 * m[..., 4] + m[..., 5]
-    return y[..., :w]
-
-
-@pytest.mark.parametrize('cin,cout,ck', [(64, 32, 4), (32, 64, 4), (5, 3, 4), (6, 40, 2)])
-def test_winograd5_pack_forward_and_backward_data(cin, cout, ck):
-    wt = rnd(cout, cin, 5, 5, seed=11)
-    x = rnd(2, cin, 6, 10, seed=12).requires_grad_(True)
-    ref = TF.conv2d(x, wt, None, padding=2)
-    got = wino5_emulate(x.detach(), CN.wino5_weights(wt, False, ck), ck, cout)
-    assert torch.allclose(got, ref.detach(), rtol=1e-9, atol=1e-9)
-    gy = rnd(2, cout, 6, 10, seed=13)
-    gref, = torch.autograd.grad(ref, x, gy)
-    got = wino5_emulate(gy, CN.wino5_weights(wt, True, ck), ck, cin)
-    assert torch.allclose(got, gref, rtol=1e-9, atol=1e-9)
 
 
 def wino43_emulate(x, pack, ck, cout):

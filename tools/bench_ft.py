@@ -18,6 +18,8 @@ opt = OrderedDict(model='darts_ft', gpu_ids=[0], dist=False, is_train=True,
                              lr_scheme='MultiStepLR', lr_steps=[100000], restarts=None, restart_weights=None,
                              lr_gamma=0.5, clear_state=False))
 torch.manual_seed(10)
+import random
+random.seed(10)                                  # the replay-memory entries finetune_proxies() draws
 model = create_model(opt)
 a, ga = make_batch(batch, 256, 256, seed=1)
 b, gb = make_batch(batch, 256, 256, seed=2)

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of one convolution layer (GPU box): python tools/conv_bench.py [cin cout k N H W reps]
-Default: the inference dispatch (infer=True: 3x3 -> F(4,3)); RISP_BENCH_GRAD=1 times the training dispatch
-(3x3 -> F(2,3)); RISP_WINOGRAD=0 the direct kernel."""
+The kernel is whatever convnets.route() picks (RISP_CONV_ARITH=f32: the fp32 kernels); RISP_BENCH_GRAD=1 times a training launch."""
 import os
 import sys
 import time
