@@ -135,6 +135,52 @@ inline int risp_bwd_blocks(int N, int HW) {
     return bx < 1 ? 1 : bx;
 }
 
+// ... of the kernels that form WbQuadratic's 30 parameter sums (stand-alone backward and the second launch of the fused slot
+// backward: the same partition, so the same bits).  Their per-workgroup cost is dominated by what does not scale with the pixels -
+// 30 parameter loads, a 30-value block reduction, the partial row - worth ~8 vectors of pixel work: ONE resident round of
+// workgroups (512 = 2 per CU at their 2 waves per SIMD) with as many vectors per thread as that leaves, instead of 4 per thread.
+inline int risp_bwd_blocks_wbq(int N, int HW) {
+    const int hw4 = HW / 4;
+    int bx = (512 + N - 1) / (N > 0 ? N : 1);
+    const int most = (hw4 + 255) / 256;                        // at least one vector per thread
+    if (bx > most) bx = most;
+    if (bx > 64) bx = 64;
+    return bx < 1 ? 1 : bx;
+}
+
+// sum of a wave's values, in every lane's row leader: butterflies inside the rows of 16 by DPP (no LDS round trips), then the four
+// rows by readlane - a fixed order
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));       // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));      // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));      // row_mirror
+    const int x = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48)));
+}
+
+// block_sum with the wave stage on DPP: thread 0 receives the totals in v[] (waves added in index order)
+template <int NV>
+__device__ __forceinline__ void block_sum_dpp(float (&v)[NV], float *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float s = wave_sum_dpp(v[i]);
+        if (lane == 0) lds[i * nw + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += lds[i * nw + w];
+            v[i] = s;
+        }
+    }
+    __syncthreads();
+}
+
 struct f3 {
     float b, g, r;
 };

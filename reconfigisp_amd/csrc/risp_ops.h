@@ -148,7 +148,7 @@ struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR 
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) acc[ch * 10 + j] += g[ch] * f[j];
+            for (int j = 0; j < 10; ++j) acc[ch * 10 + j] = __builtin_fmaf(g[ch], f[j], acc[ch * 10 + j]);      // one instruction per term
             o.b += g[ch] * (2.f * x.b * c[ch][0] + x.g * c[ch][3] + x.r * c[ch][4] + c[ch][6]);
             o.g += g[ch] * (2.f * x.g * c[ch][1] + x.b * c[ch][3] + x.r * c[ch][5] + c[ch][7]);
             o.r += g[ch] * (2.f * x.r * c[ch][2] + x.b * c[ch][4] + x.g * c[ch][5] + c[ch][8]);
@@ -177,7 +177,7 @@ struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR 
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-            for (int j = 0; j < 10; ++j) acc[ch * 10 + j] += g[ch] * f[j];
+            for (int j = 0; j < 10; ++j) acc[ch * 10 + j] = __builtin_fmaf(g[ch], f[j], acc[ch * 10 + j]);
     }
     __device__ static float pscale(int) { return 10.f; }
     __host__ __device__ static int prow(int n) { return n; }

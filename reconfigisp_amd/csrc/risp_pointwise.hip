@@ -35,8 +35,11 @@ __global__ __launch_bounds__(256) void bgr_fwd_kernel(const float *__restrict__ 
     }
 }
 
+#ifndef RISP_WBQ_WAVES
+#define RISP_WBQ_WAVES 2
+#endif
 template <class Ctx>
-__global__ __launch_bounds__(256) void bgr_bwd_kernel(const float *__restrict__ x, const float *__restrict__ p,
+__global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_bwd_kernel(const float *__restrict__ x, const float *__restrict__ p,
                                                       const float *__restrict__ gy, float *__restrict__ gx,
                                                       float *__restrict__ gp, int hw4) {
     __shared__ float red[Ctx::NP * 4];
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void bgr_bwd_kernel(const float *__restrict__ 
         ob[hw4 + i] = make_float4(o0.g, o1.g, o2.g, o3.g);
         ob[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
     }
-    block_sum<Ctx::NP>(acc, red);
+    if (Ctx::NP >= 30) block_sum_dpp<Ctx::NP>(acc, red);
+    else block_sum<Ctx::NP>(acc, red);
     if (threadIdx.x == 0) {      // one partial row per workgroup; param_finish_kernel adds them in index order
 #pragma unroll
         for (int j = 0; j < Ctx::NP; ++j) gp[((size_t)n * gridDim.x + blockIdx.x) * Ctx::NP + j] = acc[j] * Ctx::pscale(j);
@@ -116,7 +120,7 @@ template <class Ctx>
 int launch_bwd(const char *name, const float *x, const float *p, const float *gy, float *gx, float *gp, float *scratch,
                int N, int HW, void *stream) {
     RISP_CHECK_ARG(x && p && gy && gx && gp && scratch && N > 0 && HW > 0 && HW % 4 == 0, "%s: bad arguments", name);
-    const int hw4 = HW / 4, bx = risp_bwd_blocks(N, HW);
+    const int hw4 = HW / 4, bx = Ctx::NP >= 30 ? risp_bwd_blocks_wbq(N, HW) : risp_bwd_blocks(N, HW);
     hipLaunchKernelGGL(bgr_bwd_kernel<Ctx>, dim3(bx, N), dim3(256), 0, (hipStream_t)stream, x, p, gy, gx, scratch, hw4);
     const int rows = N;                                // gp is (N, NP): rows no image maps to (GtmManual: all but row 0) get 0
     hipLaunchKernelGGL(param_finish_kernel<Ctx>, dim3((rows * Ctx::NP + 3) / 4), dim3(256), 0, (hipStream_t)stream, scratch,

@@ -326,8 +326,11 @@ __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_d
 
 // The 30 parameter sums of the slot's quadratic white balance (see slot_mix_bwd_kernel, WBQ = 2): slots SO_WQ .. SO_WQ + 29 of the
 // same partial rows.  The loads of the next vector are issued before the current one is worked on.
-__global__ __launch_bounds__(256) void slot_wbq_params_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy, float *__restrict__ part,
-                                                              int hw4) {
+#ifndef RISP_WBQ_WAVES
+#define RISP_WBQ_WAVES 2
+#endif
+__global__ __launch_bounds__(256, RISP_WBQ_WAVES) void slot_wbq_params_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy, float *__restrict__ part,
+                                                              int hw4, int bx_rows) {
     __shared__ float red[30 * 4];
     const int n = blockIdx.y;
     int at = -1;
@@ -361,11 +364,15 @@ __global__ __launch_bounds__(256) void slot_wbq_params_kernel(const risp_slot_mi
         wq.bwd_gp({b.z, g.z, r.z}, {db.z * w, dg.z * w, dr.z * w}, acc);
         wq.bwd_gp({b.w, g.w, r.w}, {db.w * w, dg.w * w, dr.w * w}, acc);
     }
-    block_sum<30>(acc, red);
+    block_sum_dpp<30>(acc, red);
     if (threadIdx.x == 0) {
-        float *row = part + ((size_t)n * gridDim.x + blockIdx.x) * RISP_SLOT_ROW;
+        // this workgroup's row of the main kernel's bx_rows partial rows per image; the rows beyond this kernel's own (coarser)
+        // grid receive zeros - the finish kernel adds all bx_rows in index order, and adding 0 changes no bit
+        for (int rb = blockIdx.x; rb < bx_rows; rb += gridDim.x) {
+            float *row = part + ((size_t)n * bx_rows + rb) * RISP_SLOT_ROW;
 #pragma unroll
-        for (int j = 0; j < 30; ++j) row[SO_WQ + j] = acc[j] * 10.f;                   // WbqCtx::pscale
+            for (int j = 0; j < 30; ++j) row[SO_WQ + j] = rb == (int)blockIdx.x ? acc[j] * 10.f : 0.f;      // WbqCtx::pscale
+        }
     }
 }
 
@@ -502,7 +509,7 @@ int risp_slot_mix_bwd(const risp_slot_mix_desc *d, const float *gy, float *gx, f
         hipLaunchKernelGGL(slot_mix_bwd_kernel<1>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
     } else if (wbq) {
         hipLaunchKernelGGL(slot_mix_bwd_kernel<2>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
-        hipLaunchKernelGGL(slot_wbq_params_kernel, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, scratch, hw4);
+        hipLaunchKernelGGL(slot_wbq_params_kernel, dim3(risp_bwd_blocks_wbq(d->N, d->HW), d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, scratch, hw4, bx);
     } else {
         hipLaunchKernelGGL(slot_mix_bwd_kernel<0>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);
     }
