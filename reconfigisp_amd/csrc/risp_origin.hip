@@ -148,9 +148,11 @@ __device__ __forceinline__ void stage_tile4(const float *__restrict__ planes, fl
         const int c = rowi / th, ty = rowi - c * th;
         const int gy = reflect101(y0 + ty - R, H), gx = x0 + 4 * v;
         const float *src = planes + ((size_t)c * H + gy) * W;
-        float4 q;
-        if (gx < W) q = *reinterpret_cast<const float4 *>(src + gx);       // W % 4 == 0: entirely inside
-        else q = make_float4(src[reflect101(gx, W)], src[reflect101(gx + 1, W)], src[reflect101(gx + 2, W)], src[reflect101(gx + 3, W)]);
+        // the 16-byte load is issued unconditionally (from column 0 where the vector lies beyond the image): with a branch around it
+        // hipcc waits for every load before it issues the next, and a tile is 4 .. 6 of them per thread - one memory round trip each
+        const bool inside = gx < W;                                       // W % 4 == 0: entirely inside, or entirely outside
+        float4 q = *reinterpret_cast<const float4 *>(src + (inside ? gx : 0));
+        if (!inside) q = make_float4(src[reflect101(gx, W)], src[reflect101(gx + 1, W)], src[reflect101(gx + 2, W)], src[reflect101(gx + 3, W)]);
         *reinterpret_cast<float4 *>(lds + rowi * tw + RP + 4 * v) = make_float4(conv(q.x), conv(q.y), conv(q.z), conv(q.w));
     }
     for (int idx = threadIdx.x; idx < C * th * 2 * R; idx += 256) {

@@ -40,5 +40,7 @@ for tag, counter in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
             acc[r['Kernel_Name']] += float(r['Counter_Value'])
             cnt[r['Kernel_Name']] += 1
     print('== %s per launch (raw counter units = KiB; FETCH_SIZE under-reports wide streaming reads 2x on gfx950)' % counter)
-    for k in sorted(acc, key=lambda k: -acc[k])[:12]:
+    top = sorted(acc, key=lambda k: -acc[k])
+    # the twelve largest, and ALWAYS the two kernels of the bench line (tools/collect_r05.py reads their rows into profiles/traffic.json)
+    for k in top[:12] + [k for k in top[12:] if 'chain_kernel' in k]:
         print('%-72s launches %5d  avg %14.1f KiB' % (short(k), cnt[k], acc[k] / cnt[k]))
