@@ -245,7 +245,16 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
                 se = (chw == 0 || want < se) ? want : se;              // the running exponent of the tile (the consumers keep the same)
                 const float s = __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
                 uint4 *tb = tile + (w & 1) * C::TILE;
+#ifndef RISP_WS_ABL_NO_QUAD
                 put_quad(tb, RW.v1, dst1, 4 * q1 + P, s);
+#endif
+                // The halo travels as channel PAIRS: 4-byte LDS writes, four lanes to a bank - ALL of the kernel's bank conflicts (13 % of
+                // the LDS's active cycles, tools/ws_conflicts.sh: 0 with this block compiled out).  Nobody waits for them: the LDS is a
+                // quarter busy and the producers have a third of every phase to spare.  Whole-slot halo tasks (8 channels per lane, 16-byte
+                // writes: conflict share 0.006) were built and measured - every producer wave then runs the split / write sequence twice
+                // (the second time on 16 lanes), the producers become the critical path (0.66 -> 0.90 of their life) and the launch is
+                // 6-8 % SLOWER (400 -> 434 us): not kept.
+#ifndef RISP_WS_ABL_NO_HALO       /* PMC diagnostics only (wrong results) */
 #pragma unroll
                 for (int k = 0; k < P; ++k) {
                     const int q = (pt + 256 * k) & 15;
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
 #pragma unroll
                 for (int k = 0; k < NC2; ++k)
                     if (dstc[k] >= 0) put_pair(tb, RW.vc[k][0], RW.vc[k][1], s, dstc[k]);
+#endif
                 if (chw == 0 && pt < 32 * NT) {
                     const int co = tw.cb * 32 * NT + pt;
                     lbias[(kw & 1) * 64 + pt] = (d.epilogue & RISP_EPI_NOBIAS) || co >= d.cout ? 0.f : d.bias[(size_t)tw.g * d.bias_gs + co];
