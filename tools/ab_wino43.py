@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: in-process A/B of builds of risp_conv_wino.hip with different -D flags (interleaved rounds) on one
-64 -> 64 3x3 layer through risp_conv2d_wino43 (F(4,3)), or - RISP_AB_ENTRY=wino5 - one 64 -> 32 5x5 layer through
-risp_conv2d_wino5 (F(2,5)), or - RISP_AB_ENTRY=wino45 - through risp_conv2d_wino45 (F(4,5)).  python tools/ab_wino43.py "" "-DRISP_W43_NO_GLDS" ...
+64 -> 64 3x3 layer through risp_conv2d_wino43 (F(4,3)), or - RISP_AB_ENTRY=wino45 - one 64 -> 32 5x5 layer through
+risp_conv2d_wino45 (F(4,5)).  python tools/ab_wino43.py "" "-DRISP_W43_NO_GLDS" ...
 [env RISP_AB_SHAPE="n h w", RISP_AB_EPI=1 for the residual + ReLU epilogue of a Path-Restore block, RISP_AB_CH="cin cout"]"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,9 +25,9 @@ from reconfigisp_amd import lib as L
 from reconfigisp_amd import convnets as CN
 n, h, w = (int(v) for v in os.environ.get('RISP_AB_SHAPE', '64 128 128').split())
 W45 = os.environ.get('RISP_AB_ENTRY') == 'wino45'                 # F(4,5): the pack follows each build's risp_conv_wino45_layout()
-W5 = os.environ.get('RISP_AB_ENTRY') == 'wino5' or W45
+W5 = W45
 K = 5 if W5 else 3
-ENTRY = 'risp_conv2d_wino45' if W45 else ('risp_conv2d_wino5' if W5 else 'risp_conv2d_wino43')
+ENTRY = 'risp_conv2d_wino45' if W45 else 'risp_conv2d_wino43'
 cin, cout = (int(v) for v in os.environ.get('RISP_AB_CH', '64 32' if W5 else '64 64').split())
 torch.manual_seed(0)
 wt = torch.randn(cout, cin, K, K, device='cuda') * (0.05 if K == 3 else 0.02)
