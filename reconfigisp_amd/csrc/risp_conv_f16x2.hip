@@ -606,7 +606,9 @@ int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
                      reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_f16x2: tensors must be 16-byte aligned");
-    if (g_h2_variant == 1) return risp_launch_f16x2_ws(d, stream);      // the wave-specialised form (same bits)
+    // the wave-specialised form (same bits).  Its 64-cout 3x3 kernel spreads a tile's epilogue over the last chunk and the next tile's
+    // first one: a one-chunk layer (16 input channels: none in the proxies) stays on the kernel below
+    if (g_h2_variant == 1 && !(d.ksize == 3 && d.cout == 64 && d.cin < 32)) return risp_launch_f16x2_ws(d, stream);
     if (d.ksize == 5) return launch_f16x2_epi<5, 1>(d, stream);         // one cout block per tile: 64 couts = two tiles per pixel tile
     return d.cout == 64 ? launch_f16x2_epi<3, 2>(d, stream) : launch_f16x2_epi<3, 1>(d, stream);
 }

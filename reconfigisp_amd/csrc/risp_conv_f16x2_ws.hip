@@ -26,6 +26,20 @@
 // round-4 3x3 loop read 12 -, 8 for 5) as one stream over the filter rows of a phase, pixel and weight operands two steps ahead of
 // their first use, across filter rows.  Every accumulator still receives its products in the round-4 order (chunk, filter row, tap;
 // x_lo w_hi, x_hi w_lo, x_hi w_hi): results are bit-identical (tests/test_gpu_f16x2.py).
+//
+// SPLIT epilogue (3x3, 64 couts, with a residual and / or a mask to read: the launches whose epilogue is a quarter to a third of a
+// consumer's life).  The tile's two cout blocks are multiplied one after the other in the tile's first and last chunk (the pixel
+// operands are read once per block there), and the epilogue travels in 32 PIECES (one cout row per lane, one 16-byte store): pieces
+// 0-15 (block 0) ride on the 18 steps of block 1's products in the last chunk, pieces 16-31 (block 1) on block 0's products of the
+// NEXT tile's first chunk, whose sums start from a zero operand instead of zeroed registers.  Residual / mask rows come through a
+// ring of 8 (4 + 4) pieces, requested in front of the store of the piece that frees the slot; a lane outside the image carries an
+// out-of-range buffer offset instead of a branch.  Per accumulator the order of the products is unchanged: same bits.  Measured
+// (tools/ws_stamps.py, tools/ab_ws_build.py, 32 x 256 x 256): consumer cycles per tile 42.5k -> 38.7k (residual + ReLU), 51.5k -> 44.7k
+// (residual + mask), the epilogue's share of their life 0.25 / 0.37 -> 0.01 - but the launch gains 2.5-5.5 % only (460 -> 436 us, 533 ->
+// 509 us): the chip is POWER-limited under this kernel and answers the denser instruction stream with a lower clock (1.58 -> 1.47
+// GHz, 1.73 -> 1.54 GHz).  A launch of 4 images gains 8-9 %.  Without a residual or mask the form LOSES 3 % (the extra operand reads
+// of the two block-wise chunks cost more than the 0.12 of the life they hide): those launches keep the tile's epilogue behind its
+// last chunk.
 #include "risp_f16x2.h"
 
 namespace {
@@ -49,6 +63,9 @@ struct WS {
 #define WS_T() __builtin_amdgcn_s_memtime()
 #else
 #define WS_T() 0ull
+#endif
+#ifndef WS_SPLIT
+#define WS_SPLIT 1                                                  /* 0: diagnostic builds - the 3x3 NT = 2 epilogue behind the tile's last chunk */
 #endif
 #define WS_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define WS_BARRIER_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -338,23 +355,100 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
 #else
 #define WS_LAP(acc) do { } while (0)
 #endif
+    // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias), as in conv_f16x2_kernel, in PIECES: piece p = one cout row per lane (cout
+    // 32 (p >> 4) + 8 ((p >> 2) & 3) + (p & 3) + 4 hl of the tile's block), one 16-byte store of four consecutive pixels, 16 lanes = 256
+    // contiguous bytes.  gfx9 counts loads and stores in ONE in-order counter: a load issued behind a store returns only when that store
+    // has completed.  The residual / mask rows therefore travel through a ring of R pieces, piece p + R requested in front of the store
+    // of piece p.
+    constexpr bool SPLIT = WS_SPLIT && KS == 3 && NT == 2 && (HAS_ADD || HAS_MASK || WS_SPLIT > 1);            // the tile's two cout blocks finish half a chunk apart (header)
+    constexpr int NPIECE = 16 * NT, R = (HAS_ADD && HAS_MASK) ? 4 : 8;
+    unsigned hw4e = hw4;
+    asm volatile("" : "+s"(hw4e));
+    const float floor_ = (d.epilogue & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
+    // the tile the pieces belong to.  A lane outside the image carries an offset beyond the buffer's range (h2_rsrc: 2^31 - 1 bytes):
+    // its loads return zeros and its stores are dropped by the range check - no branch in the instruction stream.  SPLIT: until the
+    // first tile's last chunk "no tile": every lane out of range
+    unsigned e_loff = 0x80000000u, e_hw4 = 0;
+    float e_fin = 0.f;
+    const float *e_bias = lbias + 4 * hl;
+    __amdgpu_buffer_rsrc_t e_ry = h2_rsrc(d.x), e_ra = e_ry, e_rm = e_ry;
+    float4 av[HAS_ADD ? R : 1], mv[HAS_MASK ? R : 1];
+#pragma unroll
+    for (int i = 0; i < (HAS_ADD ? R : 1); ++i) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < (HAS_MASK ? R : 1); ++i) mv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto epi_setup = [&](const WsTile &cur, int k, int se) {
+        const int oy = cur.y0 + wave + 4 * (l31 >> 4), ox = cur.x0 + 4 * (l31 & 15);
+        const int na = (d.group_flags & RISP_GROUP_SHARED_ADD) ? cur.n - cur.g * d.group_n : cur.n;
+        const float inv_sw = *reinterpret_cast<const float *>(d.wpack + (size_t)cur.g * d.wpack_gs);
+        e_fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+        e_hw4 = hw4e;
+        e_loff = oy < d.H && ox < d.W ? 4u * (unsigned)(oy * d.W + ox) + (unsigned)(cur.cb * 32 * NT + 4 * hl) * hw4 : 0x80000000u;
+        e_ry = h2_rsrc(d.y + (size_t)cur.n * d.cout * hw);
+        e_ra = h2_rsrc(HAS_ADD ? d.add + (size_t)na * d.add_c * hw : d.x);
+        e_rm = h2_rsrc(HAS_MASK ? d.mask + (size_t)cur.n * d.cout * hw : d.x);
+        e_bias = lbias + (k & 1) * 64 + 4 * hl;
+    };
+    auto epi_fetch = [&](int p) {
+        unsigned h = e_hw4;
+        asm volatile("" : "+s"(h));                                     // (the offsets of 32 pieces are not worth 32 registers)
+        const unsigned co = (unsigned)((p >> 4) * 32 + 8 * ((p >> 2) & 3) + (p & 3)) * h;
+        if (HAS_ADD) av[p % R] = h2_load16(e_ra, e_loff, co);
+        if (HAS_MASK) mv[p % R] = h2_load16(e_rm, e_loff, co);
+    };
+    // (the bias of piece p is read from LDS two pieces ahead: LDS reads return in order, a piece that waited for its own read would
+    // wait for every operand read in flight)
+    float bq[3];
+    auto epi_bias = [&](int p) { bq[p % 3] = e_bias[(p >> 4) * 32 + 8 * ((p >> 2) & 3) + (p & 3)]; };
+    auto epi_piece = [&](const f32x16 (&acc)[4][NT], int p) {
+        const int b = p >> 4, e = p & 15, cu = b * 32 + 8 * (e >> 2) + (e & 3);
+        const float bb = bq[p % 3];
+        float4 o = make_float4(acc[0][b][e] * e_fin + bb, acc[1][b][e] * e_fin + bb, acc[2][b][e] * e_fin + bb, acc[3][b][e] * e_fin + bb);
+        float4 a4, mk;
+        if (HAS_ADD) a4 = av[p % R];
+        if (HAS_MASK) mk = mv[p % R];
+        if ((HAS_ADD || HAS_MASK) && p + R < NPIECE) epi_fetch(p + R);
+        if (HAS_ADD) {
+            o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+        }
+        o.x = o.x < floor_ ? floor_ : o.x;                              // ReLU, or nothing (floor = -inf); a NaN stays a NaN (torch.relu)
+        o.y = o.y < floor_ ? floor_ : o.y;
+        o.z = o.z < floor_ ? floor_ : o.z;
+        o.w = o.w < floor_ ? floor_ : o.w;
+        if (HAS_MASK) {
+            o.x = mk.x > 0.f ? o.x : 0.f;
+            o.y = mk.y > 0.f ? o.y : 0.f;
+            o.z = mk.z > 0.f ? o.z : 0.f;
+            o.w = mk.w > 0.f ? o.w : 0.f;
+        }
+        // (plane offset in the VECTOR offset: see risp_conv_f16x2.hip - a 16-byte buffer store reads its data registers late)
+        unsigned h = e_hw4;
+        asm volatile("" : "+s"(h));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), e_ry, e_loff + (unsigned)cu * h, 0, 0);
+    };
+
 #pragma unroll
     for (int i = 0; i < 2 * NH; ++i) WS_BARRIER_LDS();                 // chunks -2 and -1: the producers fill the pipeline
     WS_LAP(c_bar);
     int g = 0;
     int want_next = ws_want(red);                                      // chunk 0's exponent; later ones are read a phase ahead (below)
+    f32x16 acc[4][NT];
     for (int k = 0; k < my_tiles; ++k) {
         WsTile cur;
         locate(wg + k * nwg, cur);
-        f32x16 acc[4][NT];
+        if constexpr (!SPLIT) {                                        // (SPLIT: the first product of every sum starts from a zero operand)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
+                for (int b = 0; b < NT; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[t][b][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[t][b][e] = 0.f;
+        }
         int se = 0;                                                    // running exponent: the accumulators hold sum * 2^se * s_w
-        for (int ch = 0; ch < nchunks; ++ch, ++g) {
+        const uint4 *wsb, *tsb;
+        h8 a[KS][NT][2], bv[3][2];
+        // a chunk's head: its exponent (published by the producers a phase ago), the running sums rescaled if it is smaller, its buffers
+        auto head = [&](int ch) {
             const int want = want_next;
             // the next chunk's maxima were published a phase ago (visible since the barrier that opened this phase): read them now, off
             // the critical path of the next phase's head (after the walk's last chunk: a stale row, unused)
@@ -372,135 +466,209 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_ws_kernel(const risp_conv_d
                         for (int e = 0; e < 16; ++e) acc[t][b][e] *= f;
                 se = want;
             }
-            const uint4 *wsb = wl + (KS == 3 ? 3 * (g & 1) * WST : 0) + abase;          // filter row ky of the chunk: slot ky from here
-            const uint4 *tsb = tile + (g & 1) * C::TILE + bbase;
-            h8 a[KS][NT][2], bv[3][2];
-            // filter rows [ky0, ky0 + nky): steps q = NU (ky - ky0) + u; step q multiplies the pixel operand of shift u with the taps
-            // kx = u - t of the pixel tiles t.  Operands are read two steps ahead of their first use: the pixel operand of step q + 2, and
-            // tap kx of filter row ky in front of step NU (ky - ky0) + kx - 2 (a tap's registers are free again after shift kx + 3).
-            auto rows = [&](auto KY0, auto NKY) {
-                constexpr int ky0 = decltype(KY0)::value, nq = decltype(NKY)::value * NU;
-                auto load_a = [&](int ky, int kx) {
+            wsb = wl + (KS == 3 ? 3 * (g & 1) * WST : 0) + abase;      // filter row ky of the chunk: slot ky from here
+            tsb = tile + (g & 1) * C::TILE + bbase;
+        };
+        // filter rows [ky0, ky0 + nky): steps q = NU (ky - ky0) + u; step q multiplies the pixel operand of shift u with the taps
+        // kx = u - t of the pixel tiles t.  Operands are read two steps ahead of their first use: the pixel operand of step q + 2, and
+        // tap kx of filter row ky in front of step NU (ky - ky0) + kx - 2 (a tap's registers are free again after shift kx + 3).
+        // BSEL: both cout blocks (-1) or one; ZERO: the sums start here (a tile's first chunk); EPI: piece EPI - 1 + q of the
+        // epilogue rides on step q (the pieces belong to the OTHER block, or to the previous tile).
+        auto rows = [&](auto KY0, auto NKY, auto BSEL_, auto ZERO_, auto EPI_) {
+            constexpr int ky0 = decltype(KY0)::value, nq = decltype(NKY)::value * NU, BSEL = decltype(BSEL_)::value, EPI = decltype(EPI_)::value;
+            constexpr bool ZERO = decltype(ZERO_)::value;
+            auto load_a = [&](int ky, int kx) {
 #pragma unroll
-                    for (int b = 0; b < NT; ++b)
+                for (int b = 0; b < NT; ++b)
+                    if (BSEL < 0 || b == BSEL)
 #pragma unroll
                         for (int part = 0; part < 2; ++part)
                             a[kx][b][part] = __builtin_bit_cast(h8, wsb[ky * WST + ((kx * 2 + part) * 2) * NT * 32 + b * 32]);
-                };
-                auto load_b = [&](int q) {
-                    const int ky = ky0 + q / NU, u = q % NU, sl = ky * RS + (u & 3) * S + (u >> 2);
-                    bv[q % 3][0] = __builtin_bit_cast(h8, tsb[sl]);
-                    bv[q % 3][1] = __builtin_bit_cast(h8, tsb[C::PART + sl]);
-                };
-                load_a(ky0, 0);
-                load_b(0);
-                load_a(ky0, 1);
-                load_b(1);
-                __builtin_amdgcn_sched_barrier(0);
-                WS_LAP(c_head);
-#pragma unroll
-                for (int q = 0; q < nq; ++q) {
-                    const int u = q % NU;
-                    if (q + 2 < nq) {
-                        load_b(q + 2);
-                        if ((q + 2) % NU < KS) load_a(ky0 + (q + 2) / NU, (q + 2) % NU);
-                    }
-                    // keep the reads of the later steps in front of this step's products (hipcc sinks them to their first use otherwise)
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int kx = u - t;
-                        if (kx >= 0 && kx < KS) {
-#pragma unroll
-                            for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][b][0], bv[q % 3][1], acc[t][b], 0, 0, 0);
-#pragma unroll
-                            for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][b][1], bv[q % 3][0], acc[t][b], 0, 0, 0);
-#pragma unroll
-                            for (int b = 0; b < NT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][b][0], bv[q % 3][0], acc[t][b], 0, 0, 0);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                WS_LAP(c_mat);
             };
-            if constexpr (KS == 3) {
-                rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-            } else {
-                rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-                WS_BARRIER_LDS();                                      // rows 3-4 of this chunk have landed; the producers may refill slots 0-2
-                WS_LAP(c_bar);
-                rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+            auto load_b = [&](int q) {
+                const int ky = ky0 + q / NU, u = q % NU, sl = ky * RS + (u & 3) * S + (u >> 2);
+                bv[q % 3][0] = __builtin_bit_cast(h8, tsb[sl]);
+                bv[q % 3][1] = __builtin_bit_cast(h8, tsb[C::PART + sl]);
+            };
+            load_a(ky0, 0);
+            load_b(0);
+            load_a(ky0, 1);
+            load_b(1);
+            if constexpr (EPI > 0) {
+                epi_bias(EPI - 1);
+                epi_bias(EPI);
             }
-            if (ch + 1 < nchunks) {                                    // (a tile's last chunk: behind the epilogue)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_LAP(c_head);
+#pragma unroll
+            for (int q = 0; q < nq; ++q) {
+                const int u = q % NU;
+                if (q + 2 < nq) {
+                    load_b(q + 2);
+                    if ((q + 2) % NU < KS) load_a(ky0 + (q + 2) / NU, (q + 2) % NU);
+                }
+                if constexpr (EPI > 0)
+                    if (q + 2 < 16) epi_bias(EPI - 1 + q + 2);
+                // keep the reads of the later steps in front of this step's products (hipcc sinks them to their first use otherwise)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kx = u - t;
+                    if (kx >= 0 && kx < KS) {
+                        const bool first = ZERO && q < NU && kx == 0;       // filter row 0, tap 0: the first product of acc[t][.]
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+                            if (BSEL < 0 || b == BSEL) {
+                                f32x16 c0;
+                                if (first) {
+#pragma unroll
+                                    for (int e = 0; e < 16; ++e) c0[e] = 0.f;
+                                } else {
+                                    c0 = acc[t][b];
+                                }
+                                acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][b][0], bv[q % 3][1], c0, 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+                            if (BSEL < 0 || b == BSEL) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][b][1], bv[q % 3][0], acc[t][b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+                            if (BSEL < 0 || b == BSEL) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx][b][0], bv[q % 3][0], acc[t][b], 0, 0, 0);
+                    }
+                }
+                if constexpr (EPI > 0)
+                    if (q < 16) epi_piece(acc, EPI - 1 + q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            WS_LAP(c_mat);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I3 = std::integral_constant<int, 3>;
+        using IALL = std::integral_constant<int, -1>;
+        using NO = std::false_type;
+        if constexpr (SPLIT) {
+            // One cout block after the other in a tile's first and last chunk (the pixel operands are read once per block there): the
+            // epilogue of block 0 rides on block 1's products of the last chunk, that of block 1 on block 0's products of the NEXT
+            // tile's first chunk - the matrix pipe does not wait for the stores.  (nchunks >= 2: the entry point sees to it.)  Straight
+            // code per tile - first chunk, loop over the middle ones, last chunk - so that the accumulators never meet at a join.
+            head(0);
+            rows(I0{}, I3{}, I0{}, std::true_type{}, std::integral_constant<int, 17>{});            // pieces 16 .. 31 of the previous tile
+            rows(I0{}, I3{}, I1{}, std::true_type{}, I0{});
+            ++g;
+            WS_BARRIER_LDS();
+            WS_LAP(c_bar);
+            for (int ch = 1; ch + 1 < nchunks; ++ch, ++g) {
+                head(ch);
+                rows(I0{}, I3{}, IALL{}, NO{}, I0{});
                 WS_BARRIER_LDS();
                 WS_LAP(c_bar);
             }
-        }
-        // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias), as in conv_f16x2_kernel: one 16-byte store per cout and lane, 16 lanes =
-        // 256 contiguous bytes of a cout row
-        {
-            const int oy = cur.y0 + wave + 4 * (l31 >> 4), ox = cur.x0 + 4 * (l31 & 15);
-            const int na = (d.group_flags & RISP_GROUP_SHARED_ADD) ? cur.n - cur.g * d.group_n : cur.n;
-            const float inv_sw = *reinterpret_cast<const float *>(d.wpack + (size_t)cur.g * d.wpack_gs);
-            const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
-            const float floor_ = (d.epilogue & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
-            const bool pixok = oy < d.H && ox < d.W;
-            unsigned hw4e = hw4;
-            asm volatile("" : "+s"(hw4e));
-            const unsigned loff = (pixok ? 4u * (unsigned)(oy * d.W + ox) : 0u) + (unsigned)(cur.cb * 32 * NT + 4 * hl) * hw4;
-            const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)cur.n * d.cout * hw);
-            const __amdgpu_buffer_rsrc_t ra = h2_rsrc(HAS_ADD ? d.add + (size_t)na * d.add_c * hw : d.x);
-            const __amdgpu_buffer_rsrc_t rm = h2_rsrc(HAS_MASK ? d.mask + (size_t)cur.n * d.cout * hw : d.x);
-            const float *bias_row = lbias + (k & 1) * 64 + 4 * hl;
-            // gfx9 counts loads and stores in ONE in-order counter: a load issued behind a store returns only when that store has
-            // completed.  The residual / mask rows therefore come in batches through two register sets, the loads of batch k + 1 issued
-            // IN FRONT of the stores of batch k: they queue behind the stores of batch k - 1 only, and that round trip passes while batch
-            // k is formed and stored (the round-4 epilogue loaded a batch behind the previous batch's stores and waited it out).
-            constexpr int EB = (HAS_ADD && HAS_MASK) ? 4 : 8, NB = 16 * NT / EB;
-            float4 av[2][HAS_ADD ? EB : 1], mv[2][HAS_MASK ? EB : 1];
-            auto fetch_rows = [&](int g2, int buf) {
+            head(nchunks - 1);
+            epi_setup(cur, k, se);
+            if (HAS_ADD || HAS_MASK) {
 #pragma unroll
-                for (int kk = 0; kk < EB; ++kk) {
-                    const int c = g2 * EB + kk, cu = (c >> 4) * 32 + 8 * ((c >> 2) & 3) + (c & 3);
-                    if (HAS_ADD) av[buf][kk] = h2_load16(ra, loff, (unsigned)cu * hw4e);
-                    if (HAS_MASK) mv[buf][kk] = h2_load16(rm, loff, (unsigned)cu * hw4e);
+                for (int p = 0; p < R; ++p) epi_fetch(p);
+            }
+            rows(I0{}, I3{}, I0{}, NO{}, I0{});
+            rows(I0{}, I3{}, I1{}, NO{}, I1{});                                                     // pieces 0 .. 15
+            ++g;
+            WS_BARRIER_LDS();
+            WS_LAP(c_bar);
+        } else {
+            for (int ch = 0; ch < nchunks; ++ch, ++g) {
+                head(ch);
+                if constexpr (KS == 3) {
+                    rows(I0{}, I3{}, IALL{}, NO{}, I0{});
+                } else {
+                    rows(I0{}, I3{}, IALL{}, NO{}, I0{});
+                    WS_BARRIER_LDS();                                  // rows 3-4 of this chunk have landed; the producers may refill slots 0-2
+                    WS_LAP(c_bar);
+                    rows(I3{}, std::integral_constant<int, 2>{}, IALL{}, NO{}, I0{});
                 }
-            };
-            if (HAS_ADD || HAS_MASK) fetch_rows(0, 0);
-#pragma unroll
-            for (int g2 = 0; g2 < NB; ++g2) {
-                if ((HAS_ADD || HAS_MASK) && g2 + 1 < NB) fetch_rows(g2 + 1, (g2 + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < EB; ++kk) {
-                    const int c = g2 * EB + kk, b = c >> 4, j = (c >> 2) & 3, i = c & 3, e = 4 * j + i, cu = b * 32 + 8 * j + i;
-                    const float bb = bias_row[cu];
-                    float4 o = make_float4(acc[0][b][e] * fin + bb, acc[1][b][e] * fin + bb, acc[2][b][e] * fin + bb, acc[3][b][e] * fin + bb);
-                    if (HAS_ADD) {
-                        const float4 a4 = av[g2 & 1][kk];
-                        o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
-                    }
-                    o.x = o.x < floor_ ? floor_ : o.x;                  // ReLU, or nothing (floor = -inf); a NaN stays a NaN (torch.relu)
-                    o.y = o.y < floor_ ? floor_ : o.y;
-                    o.z = o.z < floor_ ? floor_ : o.z;
-                    o.w = o.w < floor_ ? floor_ : o.w;
-                    if (HAS_MASK) {
-                        const float4 mk = mv[g2 & 1][kk];
-                        o.x = mk.x > 0.f ? o.x : 0.f;
-                        o.y = mk.y > 0.f ? o.y : 0.f;
-                        o.z = mk.z > 0.f ? o.z : 0.f;
-                        o.w = mk.w > 0.f ? o.w : 0.f;
-                    }
-                    // (plane offset in the VECTOR offset: see risp_conv_f16x2.hip - a 16-byte buffer store reads its data registers late)
-                    if (pixok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, loff + (unsigned)cu * hw4e, 0, 0);
+                if (ch + 1 < nchunks) {                                // (a tile's last chunk: behind the epilogue)
+                    WS_BARRIER_LDS();
+                    WS_LAP(c_bar);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (!SPLIT) {
+            // ---- epilogue: y = epilogue(acc * 2^-se / s_w + bias), as in conv_f16x2_kernel: one 16-byte store per cout and lane, 16 lanes =
+            // 256 contiguous bytes of a cout row
+            {
+                const int oy = cur.y0 + wave + 4 * (l31 >> 4), ox = cur.x0 + 4 * (l31 & 15);
+                const int na = (d.group_flags & RISP_GROUP_SHARED_ADD) ? cur.n - cur.g * d.group_n : cur.n;
+                const float inv_sw = *reinterpret_cast<const float *>(d.wpack + (size_t)cur.g * d.wpack_gs);
+                const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+                const float floor_ = (d.epilogue & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
+                const bool pixok = oy < d.H && ox < d.W;
+                unsigned hw4e = hw4;
+                asm volatile("" : "+s"(hw4e));
+                const unsigned loff = (pixok ? 4u * (unsigned)(oy * d.W + ox) : 0u) + (unsigned)(cur.cb * 32 * NT + 4 * hl) * hw4;
+                const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)cur.n * d.cout * hw);
+                const __amdgpu_buffer_rsrc_t ra = h2_rsrc(HAS_ADD ? d.add + (size_t)na * d.add_c * hw : d.x);
+                const __amdgpu_buffer_rsrc_t rm = h2_rsrc(HAS_MASK ? d.mask + (size_t)cur.n * d.cout * hw : d.x);
+                const float *bias_row = lbias + (k & 1) * 64 + 4 * hl;
+                // gfx9 counts loads and stores in ONE in-order counter: a load issued behind a store returns only when that store has
+                // completed.  The residual / mask rows therefore come in batches through two register sets, the loads of batch k + 1 issued
+                // IN FRONT of the stores of batch k: they queue behind the stores of batch k - 1 only, and that round trip passes while batch
+                // k is formed and stored (the round-4 epilogue loaded a batch behind the previous batch's stores and waited it out).
+                constexpr int EB = (HAS_ADD && HAS_MASK) ? 4 : 8, NB = 16 * NT / EB;
+                float4 av[2][HAS_ADD ? EB : 1], mv[2][HAS_MASK ? EB : 1];
+                auto fetch_rows = [&](int g2, int buf) {
+#pragma unroll
+                    for (int kk = 0; kk < EB; ++kk) {
+                        const int c = g2 * EB + kk, cu = (c >> 4) * 32 + 8 * ((c >> 2) & 3) + (c & 3);
+                        if (HAS_ADD) av[buf][kk] = h2_load16(ra, loff, (unsigned)cu * hw4e);
+                        if (HAS_MASK) mv[buf][kk] = h2_load16(rm, loff, (unsigned)cu * hw4e);
+                    }
+                };
+                if (HAS_ADD || HAS_MASK) fetch_rows(0, 0);
+#pragma unroll
+                for (int g2 = 0; g2 < NB; ++g2) {
+                    if ((HAS_ADD || HAS_MASK) && g2 + 1 < NB) fetch_rows(g2 + 1, (g2 + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < EB; ++kk) {
+                        const int c = g2 * EB + kk, b = c >> 4, j = (c >> 2) & 3, i = c & 3, e = 4 * j + i, cu = b * 32 + 8 * j + i;
+                        const float bb = bias_row[cu];
+                        float4 o = make_float4(acc[0][b][e] * fin + bb, acc[1][b][e] * fin + bb, acc[2][b][e] * fin + bb, acc[3][b][e] * fin + bb);
+                        if (HAS_ADD) {
+                            const float4 a4 = av[g2 & 1][kk];
+                            o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+                        }
+                        o.x = o.x < floor_ ? floor_ : o.x;                  // ReLU, or nothing (floor = -inf); a NaN stays a NaN (torch.relu)
+                        o.y = o.y < floor_ ? floor_ : o.y;
+                        o.z = o.z < floor_ ? floor_ : o.z;
+                        o.w = o.w < floor_ ? floor_ : o.w;
+                        if (HAS_MASK) {
+                            const float4 mk = mv[g2 & 1][kk];
+                            o.x = mk.x > 0.f ? o.x : 0.f;
+                            o.y = mk.y > 0.f ? o.y : 0.f;
+                            o.z = mk.z > 0.f ? o.z : 0.f;
+                            o.w = mk.w > 0.f ? o.w : 0.f;
+                        }
+                        // (plane offset in the VECTOR offset: see risp_conv_f16x2.hip - a 16-byte buffer store reads its data registers late)
+                        if (pixok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, loff + (unsigned)cu * hw4e, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            WS_LAP(c_epi);
+            WS_BARRIER_LDS();                                          // end of the tile's last phase (the stores drain on their own)
+            WS_LAP(c_bar);
+        }
+    }
+    if constexpr (SPLIT) {                                             // the last tile's second block
+        epi_bias(16);
+        epi_bias(17);
+#pragma unroll
+        for (int p = 16; p < 32; ++p) {
+            if (p + 2 < 32) epi_bias(p + 2);
+            epi_piece(acc, p);
+        }
         WS_LAP(c_epi);
-        WS_BARRIER_LDS();                                              // end of the tile's last phase (the stores drain on their own)
-        WS_LAP(c_bar);
     }
 #ifdef RISP_WS_STAMPS
     if (lane == 0 && d.cvals) {
