@@ -39,6 +39,30 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Block-wide sum of NV per-thread partials; thread 0 of the block receives the totals in v[].
 // lds must hold NV * (blockDim.x/64) floats.  Contains barriers: call from all threads.
+// thread 0's half of a block sum: the waves' partial sums of every value, added in wave order.  With four waves (every launch of
+// this library) the NV x 4 LDS reads are issued together and waited for once: a loop over a run-time wave count made them NV x 4
+// dependent round trips - 9 us at the end of a workgroup with 30 values, which a launch of ONE resident round of workgroups (the
+// quadratic white balance's backward kernels) paid in full (tools/ab_wbq.sh: 16.1 -> 6.7 us of fixed cost).
+template <int NV>
+__device__ __forceinline__ void block_sum_finish(float (&v)[NV], const float *lds, int nw) {
+    if (nw == 4) {
+        float q[NV][4];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) q[i][w] = lds[i * 4 + w];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = (((0.f + q[i][0]) + q[i][1]) + q[i][2]) + q[i][3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += lds[i * nw + w];
+            v[i] = s;
+        }
+    }
+}
+
 template <int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -48,14 +72,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float *lds) {
         if (lane == 0) lds[i * nw + wave] = s;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += lds[i * nw + w];
-            v[i] = s;
-        }
-    }
+    if (threadIdx.x == 0) block_sum_finish<NV>(v, lds, nw);
     __syncthreads();
 }
 
@@ -141,11 +158,79 @@ inline int risp_bwd_blocks(int N, int HW) {
 // workgroups (512 = 2 per CU at their 2 waves per SIMD) with as many vectors per thread as that leaves, instead of 4 per thread.
 inline int risp_bwd_blocks_wbq(int N, int HW) {
     const int hw4 = HW / 4;
-    int bx = (512 + N - 1) / (N > 0 ? N : 1);
+#ifndef RISP_WBQ_WGS
+#define RISP_WBQ_WGS 512
+#endif
+    int bx = (RISP_WBQ_WGS + N - 1) / (N > 0 ? N : 1);
     const int most = (hw4 + 255) / 256;                        // at least one vector per thread
     if (bx > most) bx = most;
     if (bx > 64) bx = 64;
     return bx < 1 ? 1 : bx;
+}
+
+// one vector (4 pixels) of a BGR image and of its upstream gradient: six 16-byte plane loads
+struct BgrVec6 {
+    float4 b, g, r, db, dg, dr;
+    __device__ __forceinline__ void load(const float4 *xb, const float4 *gb, int hw4, int i) {
+        b = xb[i]; g = xb[hw4 + i]; r = xb[2 * hw4 + i];
+        db = gb[i]; dg = gb[hw4 + i]; dr = gb[2 * hw4 + i];
+    }
+};
+
+// work(vector, index) over the vectors blockIdx.x * blockDim.x + threadIdx.x + k * gridDim.x * blockDim.x < hw4 of a thread of a
+// 256-thread workgroup, with the loads running D vectors ahead of the work THROUGH LDS (D + 1 slots of 6 x 256 x 16 bytes in
+// `stage`): every wave sends the six plane rows of its 64 threads by LDS-DMA (global_load_lds_dwordx4: no registers, and nothing
+// the compiler could sink behind the arithmetic - hipcc moves plain prefetch loads down to their first use and then waits with the
+// counter at zero: the kernels that walk an image with one resident round of workgroups spent half of every wave's life in those
+// waits, tools/wbq_pmc.sh) and reads its own 16 bytes back when the counter says the row has landed.  The pipelined part covers
+// the K iterations EVERY thread of the workgroup takes part in (uniform trip count), in the order k = rot, rot + 1, .. (mod K);
+// the ragged end (at most one more vector for some of the threads) follows with plain loads.  The order is fixed per (thread,
+// rot): sums accumulated over it are bit-repeatable.  A slot is overwritten one iteration after it was read; work() may issue
+// vector-memory stores (they share the in-order counter: waited for with the row, a little early).
+template <int D, class F>
+__device__ __forceinline__ void bgr_walk_lds(const float4 *xb, const float4 *gb, int hw4, int rot, float4 *stage, F &&work) {
+    const int step = gridDim.x * blockDim.x, tid = threadIdx.x, i0 = blockIdx.x * blockDim.x + tid;
+    const int lastlane = blockIdx.x * blockDim.x + blockDim.x - 1;
+    const int K = lastlane < hw4 ? (hw4 - 1 - lastlane) / step + 1 : 0;
+    if (K > 0) {
+        const unsigned lds0 = lds_addr_of(stage) + 16u * (unsigned)(__builtin_amdgcn_readfirstlane(tid) & ~63);
+        const unsigned plane = 16u * (unsigned)hw4;
+        auto issue = [&](int slot, int i) {
+            const unsigned off = 16u * (unsigned)i;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                lds_dma16_m(xb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + p));
+                lds_dma16_m(gb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + 3 + p));
+            }
+        };
+        int r[D + 1];                                  // window of iteration k, k + 1, .., k + D
+        r[0] = rot % K;
+#pragma unroll
+        for (int j = 1; j <= D; ++j) r[j] = r[j - 1] + 1 < K ? r[j - 1] + 1 : 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) issue(j, i0 + r[j] * step);
+        int slot = 0;
+        for (int k = 0; k < K; ++k) {
+            const int ahead = slot + D > D ? slot - 1 : slot + D;          // (slot + D) mod (D + 1)
+            issue(ahead, i0 + r[D] * step);                                // (past the last iteration: a window read once more, unused)
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(6 * D) : "memory");
+            const float4 *sl = stage + slot * 6 * 256 + tid;
+            BgrVec6 v;
+            v.b = sl[0]; v.g = sl[256]; v.r = sl[512]; v.db = sl[768]; v.dg = sl[1024]; v.dr = sl[1280];
+            work(v, i0 + r[0] * step);
+#pragma unroll
+            for (int j = 0; j < D; ++j) r[j] = r[j + 1];
+            r[D] = r[D] + 1 < K ? r[D] + 1 : 0;
+            slot = slot + 1 > D ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");                 // the rows past the last iteration
+    }
+    const int it = i0 + K * step;
+    if (it < hw4) {
+        BgrVec6 t;
+        t.load(xb, gb, hw4, it);
+        work(t, it);
+    }
 }
 
 // sum of a wave's values, in every lane's row leader: butterflies inside the rows of 16 by DPP (no LDS round trips), then the four
@@ -170,14 +255,7 @@ __device__ __forceinline__ void block_sum_dpp(float (&v)[NV], float *lds) {
         if (lane == 0) lds[i * nw + wave] = s;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += lds[i * nw + w];
-            v[i] = s;
-        }
-    }
+    if (threadIdx.x == 0) block_sum_finish<NV>(v, lds, nw);
     __syncthreads();
 }
 

@@ -122,7 +122,15 @@ struct WbqCtx {  // coef[ch][j] = 10 p[10ch+j] - 5 ; features B2 G2 R2 BG BR GR 
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-            for (int j = 0; j < 10; ++j) c[ch][j] = p[n * 30 + ch * 10 + j] * 10.f - 5.f;
+            for (int j = 0; j < 10; ++j) {
+                // (wave-uniform, but formed by vector arithmetic - gfx9 has no scalar float unit - and therefore kept in vector
+                // registers: moved to scalar ones by hand, the 30 vector registers go to the kernels' prefetch depth and occupancy.
+                // The empty asm hides the uniformity from the compiler, which would fold the readfirstlane away; the instruction
+                // itself is the compiler's, with the wait states it needs)
+                float v = p[n * 30 + ch * 10 + j] * 10.f - 5.f;
+                asm("" : "+v"(v));
+                c[ch][j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+            }
     }
     __device__ float pre(const float *f, int ch) const {
         float s = f[0] * c[ch][0];

@@ -38,6 +38,9 @@ __global__ __launch_bounds__(256) void bgr_fwd_kernel(const float *__restrict__ 
 #ifndef RISP_WBQ_WAVES
 #define RISP_WBQ_WAVES 2
 #endif
+#ifndef RISP_WBQ_AHEAD
+#define RISP_WBQ_AHEAD 1
+#endif
 template <class Ctx>
 __global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_bwd_kernel(const float *__restrict__ x, const float *__restrict__ p,
                                                       const float *__restrict__ gy, float *__restrict__ gx,
@@ -57,25 +60,40 @@ __global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_b
     // (64 x 256 x 256: 63 us = 0.30 of the HBM rate with the loads at the top of the loop)
     const int step = gridDim.x * blockDim.x;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float4 nb, ng, nr, ndb, ndg, ndr;
-    if (i < hw4) {
-        nb = xb[i]; ng = xb[hw4 + i]; nr = xb[2 * hw4 + i];
-        ndb = gb[i]; ndg = gb[hw4 + i]; ndr = gb[2 * hw4 + i];
-    }
-    for (; i < hw4; i += step) {
-        const float4 b = nb, g = ng, r = nr, db = ndb, dg = ndg, dr = ndr;
-        const int j = i + step;
-        if (j < hw4) {
-            nb = xb[j]; ng = xb[hw4 + j]; nr = xb[2 * hw4 + j];
-            ndb = gb[j]; ndg = gb[hw4 + j]; ndr = gb[2 * hw4 + j];
+    if constexpr (Ctx::NP >= 30) {
+        // ... and for it TWO vectors ahead (bgr_walk_lds): one resident round of workgroups walks the image in lockstep, every
+        // wave waited 54 % of its life for the vector it had asked for one iteration earlier (tools/wbq_pmc.sh)
+        __shared__ float4 stage[(RISP_WBQ_AHEAD + 1) * 6 * 256];
+        bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, n, stage, [&](const BgrVec6 &c, int i) {
+            f3 o0 = ctx.bwd({c.b.x, c.g.x, c.r.x}, {c.db.x, c.dg.x, c.dr.x}, acc);
+            f3 o1 = ctx.bwd({c.b.y, c.g.y, c.r.y}, {c.db.y, c.dg.y, c.dr.y}, acc);
+            f3 o2 = ctx.bwd({c.b.z, c.g.z, c.r.z}, {c.db.z, c.dg.z, c.dr.z}, acc);
+            f3 o3 = ctx.bwd({c.b.w, c.g.w, c.r.w}, {c.db.w, c.dg.w, c.dr.w}, acc);
+            ob[i] = make_float4(o0.b, o1.b, o2.b, o3.b);
+            ob[hw4 + i] = make_float4(o0.g, o1.g, o2.g, o3.g);
+            ob[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
+        });
+    } else {
+        float4 nb, ng, nr, ndb, ndg, ndr;
+        if (i < hw4) {
+            nb = xb[i]; ng = xb[hw4 + i]; nr = xb[2 * hw4 + i];
+            ndb = gb[i]; ndg = gb[hw4 + i]; ndr = gb[2 * hw4 + i];
         }
-        f3 o0 = ctx.bwd({b.x, g.x, r.x}, {db.x, dg.x, dr.x}, acc);
-        f3 o1 = ctx.bwd({b.y, g.y, r.y}, {db.y, dg.y, dr.y}, acc);
-        f3 o2 = ctx.bwd({b.z, g.z, r.z}, {db.z, dg.z, dr.z}, acc);
-        f3 o3 = ctx.bwd({b.w, g.w, r.w}, {db.w, dg.w, dr.w}, acc);
-        ob[i] = make_float4(o0.b, o1.b, o2.b, o3.b);
-        ob[hw4 + i] = make_float4(o0.g, o1.g, o2.g, o3.g);
-        ob[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
+        for (; i < hw4; i += step) {
+            const float4 b = nb, g = ng, r = nr, db = ndb, dg = ndg, dr = ndr;
+            const int j = i + step;
+            if (j < hw4) {
+                nb = xb[j]; ng = xb[hw4 + j]; nr = xb[2 * hw4 + j];
+                ndb = gb[j]; ndg = gb[hw4 + j]; ndr = gb[2 * hw4 + j];
+            }
+            f3 o0 = ctx.bwd({b.x, g.x, r.x}, {db.x, dg.x, dr.x}, acc);
+            f3 o1 = ctx.bwd({b.y, g.y, r.y}, {db.y, dg.y, dr.y}, acc);
+            f3 o2 = ctx.bwd({b.z, g.z, r.z}, {db.z, dg.z, dr.z}, acc);
+            f3 o3 = ctx.bwd({b.w, g.w, r.w}, {db.w, dg.w, dr.w}, acc);
+            ob[i] = make_float4(o0.b, o1.b, o2.b, o3.b);
+            ob[hw4 + i] = make_float4(o0.g, o1.g, o2.g, o3.g);
+            ob[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
+        }
     }
     if (Ctx::NP >= 30) block_sum_dpp<Ctx::NP>(acc, red);
     else block_sum<Ctx::NP>(acc, red);

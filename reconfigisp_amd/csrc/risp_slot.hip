@@ -325,13 +325,19 @@ __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_d
 }
 
 // The 30 parameter sums of the slot's quadratic white balance (see slot_mix_bwd_kernel, WBQ = 2): slots SO_WQ .. SO_WQ + 29 of the
-// same partial rows.  The loads of the next vector are issued before the current one is worked on.
+// same partial rows.  The loads run two vectors ahead of the arithmetic.
 #ifndef RISP_WBQ_WAVES
 #define RISP_WBQ_WAVES 2
+#endif
+#ifndef RISP_WBQ_AHEAD
+#define RISP_WBQ_AHEAD 1
 #endif
 __global__ __launch_bounds__(256, RISP_WBQ_WAVES) void slot_wbq_params_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy, float *__restrict__ part,
                                                               int hw4, int bx_rows) {
     __shared__ float red[30 * 4];
+#if defined(RISP_WBQ_ABL) && RISP_WBQ_ABL == 3
+    return;                                          /* timing only: the empty launch */
+#endif
     const int n = blockIdx.y;
     int at = -1;
     for (int k = 0; k < d.K; ++k)
@@ -345,25 +351,29 @@ __global__ __launch_bounds__(256, RISP_WBQ_WAVES) void slot_wbq_params_kernel(co
     float acc[30];
 #pragma unroll
     for (int j = 0; j < 30; ++j) acc[j] = 0.f;
-    const int step = gridDim.x * blockDim.x;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float4 nb, ng, nr, ndb, ndg, ndr;
-    if (i < hw4) {
-        nb = xb[i]; ng = xb[hw4 + i]; nr = xb[2 * hw4 + i];
-        ndb = gb[i]; ndg = gb[hw4 + i]; ndr = gb[2 * hw4 + i];
-    }
-    for (; i < hw4; i += step) {
-        const float4 b = nb, g = ng, r = nr, db = ndb, dg = ndg, dr = ndr;
-        const int j = i + step;
-        if (j < hw4) {
-            nb = xb[j]; ng = xb[hw4 + j]; nr = xb[2 * hw4 + j];
-            ndb = gb[j]; ndg = gb[hw4 + j]; ndr = gb[2 * hw4 + j];
-        }
-        wq.bwd_gp({b.x, g.x, r.x}, {db.x * w, dg.x * w, dr.x * w}, acc);
-        wq.bwd_gp({b.y, g.y, r.y}, {db.y * w, dg.y * w, dr.y * w}, acc);
-        wq.bwd_gp({b.z, g.z, r.z}, {db.z * w, dg.z * w, dr.z * w}, acc);
-        wq.bwd_gp({b.w, g.w, r.w}, {db.w * w, dg.w * w, dr.w * w}, acc);
-    }
+    __shared__ float4 stage[(RISP_WBQ_AHEAD + 1) * 6 * 256];
+#if defined(RISP_WBQ_ABL) && (RISP_WBQ_ABL == 2 || RISP_WBQ_ABL == 4)
+    if (hw4 > 0) hw4 = gridDim.x * blockDim.x;       /* timing only: one vector per thread - the kernel's fixed cost */
+#endif
+    bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, n, stage, [&](const BgrVec6 &c, int) {           // two vectors ahead, as bgr_bwd_kernel<WbqCtx> (risp_pointwise.hip)
+#ifdef RISP_WBQ_ABL            /* timing only: the walk without the arithmetic */
+        acc[0] += ((c.b.x + c.g.x) + (c.r.x + c.db.x)) + (c.dg.x + c.dr.x) * w;
+        acc[1] += ((c.b.y + c.g.y) + (c.r.y + c.db.y)) + (c.dg.y + c.dr.y) * w;
+        acc[2] += ((c.b.z + c.g.z) + (c.r.z + c.db.z)) + (c.dg.z + c.dr.z) * w;
+        acc[3] += ((c.b.w + c.g.w) + (c.r.w + c.db.w)) + (c.dg.w + c.dr.w) * w;
+        return;
+#endif
+        wq.bwd_gp({c.b.x, c.g.x, c.r.x}, {c.db.x * w, c.dg.x * w, c.dr.x * w}, acc);
+        wq.bwd_gp({c.b.y, c.g.y, c.r.y}, {c.db.y * w, c.dg.y * w, c.dr.y * w}, acc);
+        wq.bwd_gp({c.b.z, c.g.z, c.r.z}, {c.db.z * w, c.dg.z * w, c.dr.z * w}, acc);
+        wq.bwd_gp({c.b.w, c.g.w, c.r.w}, {c.db.w * w, c.dg.w * w, c.dr.w * w}, acc);
+    });
+#if defined(RISP_WBQ_ABL) && RISP_WBQ_ABL == 4
+    if (acc[0] != 12345.f) return;                   /* timing only: one vector per thread, no reduction, no row */
+#endif
+#if defined(RISP_WBQ_ABL) && RISP_WBQ_ABL >= 4
+    hw4 = 0;
+#endif
     block_sum_dpp<30>(acc, red);
     if (threadIdx.x == 0) {
         // this workgroup's row of the main kernel's bx_rows partial rows per image; the rows beyond this kernel's own (coarser)

@@ -1,25 +1,21 @@
 #!/bin/bash
-# GPU box: the WbQuadratic parameter-sum kernels at 2 / 3 / 4 waves per SIMD (register caps 256 / 168 / 128): rocprofv3 kernel durations
+# GPU box: WbQuadratic's backward kernels under different build flags (one argument = one set of -D flags for risp_slot.hip /
+# risp_pointwise.hip, e.g. "-DRISP_WBQ_WAVES=3 -DRISP_WBQ_AHEAD=1"): rocprofv3 kernel durations.  The library is rebuilt on the box
+# and left in the LAST configuration.
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for w in ${WAVES:-2}; do
-  touch "$REPO/reconfigisp_amd/csrc/risp_slot.hip" "$REPO/reconfigisp_amd/csrc/risp_pointwise.hip"
-  make -C "$REPO/reconfigisp_amd/csrc" -j8 EXTRA="-DRISP_WBQ_WAVES=$w" > /dev/null 2>&1
-  rm -rf /tmp/abw; RISP_OPS_REPS=24 RISP_OPS_ONLY="quadratic forward +" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abw -o o -- python3 "$REPO/tools/bench_ops.py" > /dev/null 2>&1
-  python3 - $w <<'PY'
+for cfg in "$@"; do
+  touch "$REPO/reconfigisp_amd/csrc/risp_slot.hip" "$REPO/reconfigisp_amd/csrc/risp_pointwise.hip" "$REPO/reconfigisp_amd/csrc/risp_core.cpp" "$REPO/reconfigisp_amd/csrc/risp_reduce.hip"
+  make -C "$REPO/reconfigisp_amd/csrc" -j8 EXTRA="$cfg" > /dev/null 2>&1
+  for what in "quadratic forward +" "slot mixture fused forward +"; do
+    rm -rf /tmp/abw; RISP_OPS_REPS=24 RISP_OPS_ONLY="$what" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abw -o o -- python3 "$REPO/tools/bench_ops.py" > /dev/null 2>&1
+    python3 - "$cfg" <<'PY'
 import csv, glob, sys
 for f in glob.glob('/tmp/abw/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'Wbq' in r['Name'] or 'wbq' in r['Name']:
-            print('waves', sys.argv[1], r['Name'][:70], '%.1f us' % (float(r['AverageNs']) / 1e3))
+        if 'Wbq' in r['Name'] or 'wbq' in r['Name'] or 'slot_mix_bwd' in r['Name']:
+            print('[%s] %-60s %.1f us' % (sys.argv[1], r['Name'].replace('void ', '').replace('(anonymous namespace)::', '')[:60], float(r['AverageNs']) / 1e3))
 PY
-  rm -rf /tmp/abw; RISP_OPS_REPS=24 RISP_OPS_ONLY="slot mixture fused forward +" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abw -o o -- python3 "$REPO/tools/bench_ops.py" > /dev/null 2>&1
-  python3 - $w <<'PY'
-import csv, glob, sys
-for f in glob.glob('/tmp/abw/**/*kernel_stats.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        if 'slot_' in r['Name']:
-            print('waves', sys.argv[1], r['Name'][:70], '%.1f us' % (float(r['AverageNs']) / 1e3))
-PY
+  done
 done
