@@ -55,6 +55,32 @@ def test_pointwise_vs_oracle(F, shape):
     _fwd_bwd(F.grayworld, O.grayworld, rnd(*shape, seed=7), None, gy, 'grayworld')
 
 
+@pytest.mark.parametrize('shape', [(512, 3, 64, 64), (200, 3, 64, 64), (300, 3, 40, 52), (64, 3, 96, 128)])
+def test_wbq_backward_walks_of_several_vectors_per_thread(F, shape):
+    """The quadratic white balance's backward runs ONE resident round of workgroups (risp_common.h: risp_bwd_blocks_wbq): with
+    many images a thread walks several vectors, prefetched through LDS, in a window order rotated by the image index, and a ragged
+    end follows (bgr_walk_lds).  Shapes: 4 whole iterations per thread, 1 iteration + a ragged one, a ragged row width, 2 iterations
+    on larger planes (mixed with 1).  Against the float64 oracle: input gradient element by element, parameter sums as sums; twice: same bits."""
+    n = shape[0]
+    x = rnd(*shape, seed=11, lo=-0.15, hi=1.2)
+    gy = rnd(*shape, seed=12, lo=-0.5, hi=0.5)
+    # coefficients that keep every pre-activation inside (0.2, 0.8): no pixel sits at the clamp's edges, where fp32 and float64 gate
+    # differently (the gates have their own tests above) - this one is about which pixels a thread visits and how the sums are added
+    p = rnd(n, 30, seed=13, lo=0.497, hi=0.503)
+    p[:, 9::10] = 0.55
+    xc, pc = x.double().requires_grad_(True), p.double().requires_grad_(True)
+    yc = O.wb_quadratic(xc, pc)
+    assert 0.2 < float(yc.detach().min()) and float(yc.detach().max()) < 0.8
+    gc = torch.autograd.grad(yc, (xc, pc), gy.double())
+    outs = []
+    for _ in range(2):
+        xg, pg = x.cuda().requires_grad_(True), p.cuda().requires_grad_(True)
+        outs.append(torch.autograd.grad(F.wb_quadratic(xg, pg), (xg, pg), gy.cuda()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert_close(outs[0][0], gc[0].float(), what='wbq gx', floor=0.0)
+    assert_close(outs[0][1], gc[1].float(), what='wbq gp')
+
+
 def test_wbq_gtm_vs_reference_golden(F):
     g = load_golden('pointwise')
     x, p = T(g['x']).cuda().requires_grad_(True), T(g['wbq_p']).cuda().requires_grad_(True)

@@ -44,7 +44,7 @@ def _run(x, blocks, tensors, order, w, fused, gy):
 
 
 @pytest.mark.parametrize('shape,with_wbq', [((2, 16, 24), True), ((3, 40, 72), True), ((4, 256, 256), True), ((4, 256, 256), False),
-                                            ((2, 64, 64), False)])
+                                            ((2, 64, 64), False), ((160, 64, 64), True), ((40, 128, 128), True)])
 def test_fused_slot_mixture_equals_unfused(shape, with_wbq):
     n, h, w_ = shape
     x, blocks, tensors, order = _entries(n, h, w_, seed=h + n, with_wbq=with_wbq)
