@@ -177,50 +177,41 @@ struct BgrVec6 {
     }
 };
 
-// work(vector, index) over the vectors blockIdx.x * blockDim.x + threadIdx.x + k * gridDim.x * blockDim.x < hw4 of a thread of a
-// 256-thread workgroup, with the loads running D vectors ahead of the work THROUGH LDS (D + 1 slots of 6 x 256 x 16 bytes in
-// `stage`): every wave sends the six plane rows of its 64 threads by LDS-DMA (global_load_lds_dwordx4: no registers, and nothing
-// the compiler could sink behind the arithmetic - hipcc moves plain prefetch loads down to their first use and then waits with the
-// counter at zero: the kernels that walk an image with one resident round of workgroups spent half of every wave's life in those
-// waits, tools/wbq_pmc.sh) and reads its own 16 bytes back when the counter says the row has landed.  The pipelined part covers
-// the K iterations EVERY thread of the workgroup takes part in (uniform trip count), in the order k = rot, rot + 1, .. (mod K);
-// the ragged end (at most one more vector for some of the threads) follows with plain loads.  The order is fixed per (thread,
-// rot): sums accumulated over it are bit-repeatable.  A slot is overwritten one iteration after it was read; work() may issue
-// vector-memory stores (they share the in-order counter: waited for with the row, a little early).
+// work(vector, index) over the vectors i = blockIdx.x * blockDim.x + threadIdx.x + k * gridDim.x * blockDim.x < hw4 of a thread of a
+// 256-thread workgroup, k = 0, 1, .., with the loads running D vectors ahead of the work THROUGH LDS (D + 1 slots of 6 x 256 x 16
+// bytes in `stage`): every wave sends the six plane rows of its 64 threads by LDS-DMA (global_load_lds_dwordx4: no registers, and
+// nothing the compiler could sink behind the arithmetic - hipcc moves plain prefetch loads down to their first use and then waits
+// with the counter at zero; loads in inline asm are no way out: the compiler copies and spills their registers before the data has
+// landed) and reads its own 16 bytes back when the counter says the row has landed.  The pipelined part covers the K iterations
+// EVERY thread of the workgroup takes part in (a uniform trip count); the ragged end (at most one more vector for some of the
+// threads) follows with plain loads.  A slot is overwritten one iteration after it was read; work() may issue vector-memory
+// stores (they share the in-order counter: waited for with the row, a little early).
 template <int D, class F>
-__device__ __forceinline__ void bgr_walk_lds(const float4 *xb, const float4 *gb, int hw4, int rot, float4 *stage, F &&work) {
+__device__ __forceinline__ void bgr_walk_lds(const float4 *xb, const float4 *gb, int hw4, float4 *stage, F &&work) {
     const int step = gridDim.x * blockDim.x, tid = threadIdx.x, i0 = blockIdx.x * blockDim.x + tid;
     const int lastlane = blockIdx.x * blockDim.x + blockDim.x - 1;
     const int K = lastlane < hw4 ? (hw4 - 1 - lastlane) / step + 1 : 0;
     if (K > 0) {
         const unsigned lds0 = lds_addr_of(stage) + 16u * (unsigned)(__builtin_amdgcn_readfirstlane(tid) & ~63);
         const unsigned plane = 16u * (unsigned)hw4;
-        auto issue = [&](int slot, int i) {
-            const unsigned off = 16u * (unsigned)i;
+        auto issue = [&](int slot, int k) {                                // (k past the last iteration: the last vector once more, unused)
+            const unsigned off = 16u * (unsigned)(i0 + (k < K ? k : K - 1) * step);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 lds_dma16_m(xb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + p));
                 lds_dma16_m(gb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + 3 + p));
             }
         };
-        int r[D + 1];                                  // window of iteration k, k + 1, .., k + D
-        r[0] = rot % K;
 #pragma unroll
-        for (int j = 1; j <= D; ++j) r[j] = r[j - 1] + 1 < K ? r[j - 1] + 1 : 0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) issue(j, i0 + r[j] * step);
+        for (int j = 0; j < D; ++j) issue(j, j);
         int slot = 0;
         for (int k = 0; k < K; ++k) {
-            const int ahead = slot + D > D ? slot - 1 : slot + D;          // (slot + D) mod (D + 1)
-            issue(ahead, i0 + r[D] * step);                                // (past the last iteration: a window read once more, unused)
+            issue(slot + D > D ? slot - 1 : slot + D, k + D);              // slot (k + D) mod (D + 1)
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(6 * D) : "memory");
             const float4 *sl = stage + slot * 6 * 256 + tid;
             BgrVec6 v;
             v.b = sl[0]; v.g = sl[256]; v.r = sl[512]; v.db = sl[768]; v.dg = sl[1024]; v.dr = sl[1280];
-            work(v, i0 + r[0] * step);
-#pragma unroll
-            for (int j = 0; j < D; ++j) r[j] = r[j + 1];
-            r[D] = r[D] + 1 < K ? r[D] + 1 : 0;
+            work(v, i0 + k * step);
             slot = slot + 1 > D ? 0 : slot + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");                 // the rows past the last iteration

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_b
         // ... and for it TWO vectors ahead (bgr_walk_lds): one resident round of workgroups walks the image in lockstep, every
         // wave waited 54 % of its life for the vector it had asked for one iteration earlier (tools/wbq_pmc.sh)
         __shared__ float4 stage[(RISP_WBQ_AHEAD + 1) * 6 * 256];
-        bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, n, stage, [&](const BgrVec6 &c, int i) {
+        bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, stage, [&](const BgrVec6 &c, int i) {
             f3 o0 = ctx.bwd({c.b.x, c.g.x, c.r.x}, {c.db.x, c.dg.x, c.dr.x}, acc);
             f3 o1 = ctx.bwd({c.b.y, c.g.y, c.r.y}, {c.db.y, c.dg.y, c.dr.y}, acc);
             f3 o2 = ctx.bwd({c.b.z, c.g.z, c.r.z}, {c.db.z, c.dg.z, c.dr.z}, acc);

@@ -58,8 +58,7 @@ def test_pointwise_vs_oracle(F, shape):
 @pytest.mark.parametrize('shape', [(512, 3, 64, 64), (200, 3, 64, 64), (300, 3, 40, 52), (64, 3, 96, 128)])
 def test_wbq_backward_walks_of_several_vectors_per_thread(F, shape):
     """The quadratic white balance's backward runs ONE resident round of workgroups (risp_common.h: risp_bwd_blocks_wbq): with
-    many images a thread walks several vectors, prefetched through LDS, in a window order rotated by the image index, and a ragged
-    end follows (bgr_walk_lds).  Shapes: 4 whole iterations per thread, 1 iteration + a ragged one, a ragged row width, 2 iterations
+    many images a thread walks several vectors, prefetched through LDS, and a ragged end follows (bgr_walk_lds).  Shapes: 4 whole iterations per thread, 1 iteration + a ragged one, a ragged row width, 2 iterations
     on larger planes (mixed with 1).  Against the float64 oracle: input gradient element by element, parameter sums as sums; twice: same bits."""
     n = shape[0]
     x = rnd(*shape, seed=11, lo=-0.15, hi=1.2)

@@ -77,7 +77,9 @@ heads = {
     'batch32_nstep2.log': (TAG + '_batch32_search_step.txt', "# tools/profile_r05.sh (profile_darts.sh r05_b32 32 2 3): config 4's network at the global batch of 32 on one GPU"),
     'f32_arith_same_box.log': (TAG + '_f32_arith_same_box.txt', '# tools/profile_r05.sh: RISP_CONV_ARITH=f32 (the fp32 matrix-core kernels) on the same box, wall time: config 3, the rank-of-8 shard, config 5'),
     'first_layer_infer_same_box.log': (TAG + '_first_layer_infer_same_box.txt', "# tools/profile_r05.sh: RISP_CONV_TOEP_FIRST=infer (round 4's default: training forwards of the 9x9 first layers on the fp32 kernel) on the same box: config 3, the rank-of-8 shard"),
-    'ws_ladder.txt': (TAG + '_ws_ladder.txt', '# tools/profile_r05.sh section 6: risp_conv2d_f16x2, wave-specialised kernel (variant 1, the default) against the round-4 kernel (variant 0), interleaved rounds in one process\n# (tools/ab_ws.py: 3x3 64->64 at 32 / 21 / 4 images of 256 x 256, 5x5 64->32 and 32->64), then in-kernel stamps of the 3x3 kernel (tools/ws_stamps.py: -DRISP_WS_STAMPS)'),
+    'ws_ladder.txt': (TAG + '_ws_ladder.txt', '# tools/profile_r05.sh section 6: risp_conv2d_f16x2, wave-specialised kernel (variant 1, the default) against the round-4 kernel (variant 0), interleaved rounds in one process\n# (tools/ab_ws.py: 3x3 64->64 at 32 / 21 / 4 images of 256 x 256, 5x5 64->32 and 32->64), then builds of the kernel against each other (tools/ab_ws_build.py: default = the epilogue of residual / mask launches rides on the matrix steps,\n# -DWS_SPLIT=0 = never, -DWS_SPLIT=2 = also without a residual or mask), then in-kernel stamps of the 3x3 kernel (tools/ws_stamps.py: -DRISP_WS_STAMPS; epilogue modes 0-3 = ReLU / residual + ReLU /\n# mask / residual + mask; the last two blocks: modes 1 and 3 with -DWS_SPLIT=0)'),
+    'ws_conflicts.txt': (TAG + '_ws_conflicts.txt', '# tools/ws_conflicts.sh through tools/profile_r05.sh section 9: LDS bank conflicts of conv_f16x2_ws_kernel<3, 2> (3x3 64 -> 64, 32 x 256 x 256) per launch: the full kernel,\n# without the producers\' 4-byte halo writes, without any producer write (diagnostic builds, wrong results): ALL conflicts are in the halo writes'),
+    'wbq_ablation.txt': (TAG + '_wbq_ablation.txt', "# tools/ab_wbq.sh through tools/profile_r05.sh section 9, 64 x 256 x 256: WbQuadratic's backward kernels as ablation builds (-DRISP_WBQ_ABL: 3 = the empty launch,\n# 2 = ONE vector per thread: launch + prologue + block reduction + partial row, 1 = the whole walk without the arithmetic (slot_wbq_params_kernel only), none = the product)"),
     'wgrad_ft.txt': (TAG + '_wgrad_ft.txt', '# tools/profile_r05.sh section 7: risp_conv2d_wgrad on the three layers of SRCNNRes (tools/bench_wgrad.py) and one finetune_proxies() call (tools/bench_ft.py)'),
 }
 for src, (dst, head) in heads.items():

@@ -36,12 +36,20 @@ timeout 600 bash "$REPO/tools/conv_pmc.sh" r05_5x5 64 32 5 32 256 256 > "$OUT/co
   python3 "$REPO/tools/ab_ws.py" 4 256 256 2>&1 | grep "round-4"
   RISP_AB_K=5 python3 "$REPO/tools/ab_ws.py" 32 256 256 64 32 2>&1 | grep "round-4"
   RISP_AB_K=5 python3 "$REPO/tools/ab_ws.py" 32 256 256 32 64 2>&1 | grep "round-4"
+  RISP_AB_EPIS="0 2 3 4" python3 "$REPO/tools/ab_ws_build.py" "" "-DWS_SPLIT=0" "-DWS_SPLIT=2" 2>&1 | grep "bits"
+  RISP_AB_SHAPE="4 256 256" RISP_AB_EPIS="0 2" python3 "$REPO/tools/ab_ws_build.py" "" "-DWS_SPLIT=0" 2>&1 | grep "bits"
   for m in 0 1 2 3; do python3 "$REPO/tools/ws_stamps.py" $m 2>&1 | tail -3; done
+  for m in 1 3; do python3 "$REPO/tools/ws_stamps.py" $m -DWS_SPLIT=0 2>&1 | tail -3; done
 } > "$OUT/ws_ladder.txt" 2>&1
 # 7. weight gradients and the proxy fine-tuning step
 { python3 "$REPO/tools/bench_wgrad.py" 2>&1 | tail -3; python3 "$REPO/tools/bench_ft.py" 2>&1 | tail -1; } > "$OUT/wgrad_ft.txt" 2>&1
 # 8. every stand-alone kernel for the per-op table
 timeout 900 bash "$REPO/tools/profile_ops.sh" r05 > "$OUT/ops.log" 2>&1
+# 9. where the wave-specialised kernel's LDS bank conflicts come from (ablation builds under --pmc) and what WbQuadratic's backward
+#    kernels spend outside their loop (ablation builds: empty launch / one vector per thread / the walk without the arithmetic / full).
+#    Both rebuild the library on the box and leave it in the default configuration: last.
+timeout 900 bash "$REPO/tools/ws_conflicts.sh" > "$OUT/ws_conflicts.txt" 2>&1
+timeout 900 bash "$REPO/tools/ab_wbq.sh" "-DRISP_WBQ_ABL=3" "-DRISP_WBQ_ABL=2" "-DRISP_WBQ_ABL=1" "" 2>&1 | grep "wbq_params\|bwd_kernel<risp_ops::Wbq" > "$OUT/wbq_ablation.txt"
 # gpurun copies back at most 64 MiB: the raw traces and counter dumps stay on the box, the summaries made from them travel
 find "$REPO/gpurun_out" -name "*.csv" -size +256k -delete
 du -sh "$REPO/gpurun_out"
