@@ -227,6 +227,9 @@ __global__ __launch_bounds__(256) void bilateral4_kernel(const float *__restrict
                                                          const float *__restrict__ sig_s, int H, int W, int R,
                                                          float si, float so) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (the launches of the unrolled forms pass R == RT: as a compile-time constant the tile's pitch and plane size fold into the
+    // offset fields of the LDS reads - one vector add per read less)
+    if (RT > 0) R = RT;
     const int tw = tile4_tw(R), per = tw * (QY + 2 * R), RP = tile4_pad(R);
     const int n = blockIdx.z, x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
     stage_tile4<false>(x + (size_t)n * 3 * H * W, lds, 3, H, W, x0, y0, R, si);
