@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void fastnlm4_kernel(const float *__restrict__
                                                        const float *__restrict__ decay, int H, int W, int R,
                                                        float si, float so) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (FAST) R = 2;                                   // (launched for R == 2 only: the tile geometry as compile-time constants)
     const int tw = tile4_tw(R), per = tw * (QY + 2 * R), RP = tile4_pad(R);
     const int n = blockIdx.z, x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
     stage_tile4<false>(x + (size_t)n * 3 * H * W, lds, 3, H, W, x0, y0, R, si);
