@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_b
     const int step = gridDim.x * blockDim.x;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if constexpr (Ctx::NP >= 30) {
-        // ... and for it TWO vectors ahead (bgr_walk_lds): one resident round of workgroups walks the image in lockstep, every
-        // wave waited 54 % of its life for the vector it had asked for one iteration earlier (tools/wbq_pmc.sh)
+        // ... and for it through LDS-DMA, RISP_WBQ_AHEAD vectors ahead (bgr_walk_lds, risp_common.h: the compiler sinks register
+        // prefetches to their first use)
         __shared__ float4 stage[(RISP_WBQ_AHEAD + 1) * 6 * 256];
         bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, stage, [&](const BgrVec6 &c, int i) {
             f3 o0 = ctx.bwd({c.b.x, c.g.x, c.r.x}, {c.db.x, c.dg.x, c.dr.x}, acc);

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_d
 }
 
 // The 30 parameter sums of the slot's quadratic white balance (see slot_mix_bwd_kernel, WBQ = 2): slots SO_WQ .. SO_WQ + 29 of the
-// same partial rows.  The loads run two vectors ahead of the arithmetic.
+// same partial rows.  The loads run ahead of the arithmetic through LDS (bgr_walk_lds).
 #ifndef RISP_WBQ_WAVES
 #define RISP_WBQ_WAVES 2
 #endif
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, RISP_WBQ_WAVES) void slot_wbq_params_kernel(co
 #if defined(RISP_WBQ_ABL) && (RISP_WBQ_ABL == 2 || RISP_WBQ_ABL == 4)
     if (hw4 > 0) hw4 = gridDim.x * blockDim.x;       /* timing only: one vector per thread - the kernel's fixed cost */
 #endif
-    bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, stage, [&](const BgrVec6 &c, int) {           // two vectors ahead, as bgr_bwd_kernel<WbqCtx> (risp_pointwise.hip)
+    bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, stage, [&](const BgrVec6 &c, int) {           // the walk of bgr_bwd_kernel<WbqCtx> (risp_pointwise.hip)
 #ifdef RISP_WBQ_ABL            /* timing only: the walk without the arithmetic */
         acc[0] += ((c.b.x + c.g.x) + (c.r.x + c.db.x)) + (c.dg.x + c.dr.x) * w;
         acc[1] += ((c.b.y + c.g.y) + (c.r.y + c.db.y)) + (c.dg.y + c.dr.y) * w;
