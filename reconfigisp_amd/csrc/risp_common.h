@@ -185,44 +185,62 @@ struct BgrVec6 {
 // landed) and reads its own 16 bytes back when the counter says the row has landed.  The pipelined part covers the K iterations
 // EVERY thread of the workgroup takes part in (a uniform trip count); the ragged end (at most one more vector for some of the
 // threads) follows with plain loads.  A slot is overwritten one iteration after it was read; work() may issue vector-memory
-// stores (they share the in-order counter: waited for with the row, a little early).
-template <int D, class F>
-__device__ __forceinline__ void bgr_walk_lds(const float4 *xb, const float4 *gb, int hw4, float4 *stage, F &&work) {
-    const int step = gridDim.x * blockDim.x, tid = threadIdx.x, i0 = blockIdx.x * blockDim.x + tid;
-    const int lastlane = blockIdx.x * blockDim.x + blockDim.x - 1;
-    const int K = lastlane < hw4 ? (hw4 - 1 - lastlane) / step + 1 : 0;
-    if (K > 0) {
-        const unsigned lds0 = lds_addr_of(stage) + 16u * (unsigned)(__builtin_amdgcn_readfirstlane(tid) & ~63);
-        const unsigned plane = 16u * (unsigned)hw4;
-        auto issue = [&](int slot, int k) {                                // (k past the last iteration: the last vector once more, unused)
-            const unsigned off = 16u * (unsigned)(i0 + (k < K ? k : K - 1) * step);
+// stores (they share the in-order counter: waited for with the row, a little early).  prime() then run(work).
+template <int D>
+struct BgrWalkLds {
+    const float4 *xb, *gb;
+    float4 *stage;
+    int hw4, step, tid, i0, K;
+    unsigned lds0, plane;
+    __device__ __forceinline__ BgrWalkLds(const float4 *xb_, const float4 *gb_, int hw4_, float4 *stage_)
+        : xb(xb_), gb(gb_), stage(stage_), hw4(hw4_) {
+        step = gridDim.x * blockDim.x;
+        tid = threadIdx.x;
+        i0 = blockIdx.x * blockDim.x + tid;
+        const int lastlane = blockIdx.x * blockDim.x + blockDim.x - 1;
+        K = lastlane < hw4 ? (hw4 - 1 - lastlane) / step + 1 : 0;
+        lds0 = lds_addr_of(stage) + 16u * (unsigned)(__builtin_amdgcn_readfirstlane(tid) & ~63);
+        plane = 16u * (unsigned)hw4;
+    }
+    __device__ __forceinline__ void issue(int slot, int k) const {        // (k past the last iteration: the last vector once more, unused)
+        const unsigned off = 16u * (unsigned)(i0 + (k < K ? k : K - 1) * step);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                lds_dma16_m(xb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + p));
-                lds_dma16_m(gb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + 3 + p));
-            }
-        };
-#pragma unroll
-        for (int j = 0; j < D; ++j) issue(j, j);
-        int slot = 0;
-        for (int k = 0; k < K; ++k) {
-            issue(slot + D > D ? slot - 1 : slot + D, k + D);              // slot (k + D) mod (D + 1)
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(6 * D) : "memory");
-            const float4 *sl = stage + slot * 6 * 256 + tid;
-            BgrVec6 v;
-            v.b = sl[0]; v.g = sl[256]; v.r = sl[512]; v.db = sl[768]; v.dg = sl[1024]; v.dr = sl[1280];
-            work(v, i0 + k * step);
-            slot = slot + 1 > D ? 0 : slot + 1;
+        for (int p = 0; p < 3; ++p) {
+            lds_dma16_m(xb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + p));
+            lds_dma16_m(gb, off + p * plane, lds0 + 16u * 256u * (unsigned)(slot * 6 + 3 + p));
         }
-        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");                 // the rows past the last iteration
     }
-    const int it = i0 + K * step;
-    if (it < hw4) {
-        BgrVec6 t;
-        t.load(xb, gb, hw4, it);
-        work(t, it);
+    // the first D vectors: as early in the kernel as the pointers are known - their round trip runs beside the kernel's prologue
+    // (parameter loads, coefficient arithmetic)
+    __device__ __forceinline__ void prime() const {
+        if (K > 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) issue(j, j);
+        }
     }
-}
+    template <class F>
+    __device__ __forceinline__ void run(F &&work) const {
+        if (K > 0) {
+            int slot = 0;
+            for (int k = 0; k < K; ++k) {
+                issue(slot + D > D ? slot - 1 : slot + D, k + D);          // slot (k + D) mod (D + 1)
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(6 * D) : "memory");
+                const float4 *sl = stage + slot * 6 * 256 + tid;
+                BgrVec6 v;
+                v.b = sl[0]; v.g = sl[256]; v.r = sl[512]; v.db = sl[768]; v.dg = sl[1024]; v.dr = sl[1280];
+                work(v, i0 + k * step);
+                slot = slot + 1 > D ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");             // the rows past the last iteration
+        }
+        const int it = i0 + K * step;
+        if (it < hw4) {
+            BgrVec6 t;
+            t.load(xb, gb, hw4, it);
+            work(t, it);
+        }
+    }
+};
 
 // sum of a wave's values, in every lane's row leader: butterflies inside the rows of 16 by DPP (no LDS round trips), then the four
 // rows by readlane - a fixed order
@@ -248,6 +266,26 @@ __device__ __forceinline__ void block_sum_dpp(float (&v)[NV], float *lds) {
     __syncthreads();
     if (threadIdx.x == 0) block_sum_finish<NV>(v, lds, nw);
     __syncthreads();
+}
+
+// ... and with the totals spread over the lanes: thread j < NV returns the total of value j (0 elsewhere) - NV lanes add four
+// partials each and can store their element of a row side by side, instead of thread 0 adding 4 NV partials and storing NV scalars.
+// Same adds in the same order as block_sum_dpp.  256 threads.
+template <int NV>
+__device__ __forceinline__ float block_sum_dpp_lanes(const float (&v)[NV], float *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float s = wave_sum_dpp(v[i]);
+        if (lane == 0) lds[i * 4 + wave] = s;
+    }
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x < NV) {
+        const float *q = lds + 4 * threadIdx.x;
+        t = (((0.f + q[0]) + q[1]) + q[2]) + q[3];
+    }
+    return t;
 }
 
 struct f3 {

@@ -46,12 +46,15 @@ __global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_b
                                                       const float *__restrict__ gy, float *__restrict__ gx,
                                                       float *__restrict__ gp, int hw4) {
     __shared__ float red[Ctx::NP * 4];
+    __shared__ float4 stage[Ctx::NP >= 30 ? (RISP_WBQ_AHEAD + 1) * 6 * 256 : 1];
     const int n = blockIdx.y;
-    const Ctx ctx(p, n);
     const size_t base = (size_t)n * 3 * hw4;
     const float4 *xb = reinterpret_cast<const float4 *>(x) + base;
     const float4 *gb = reinterpret_cast<const float4 *>(gy) + base;
     float4 *ob = reinterpret_cast<float4 *>(gx) + base;
+    const BgrWalkLds<RISP_WBQ_AHEAD> walk(xb, gb, hw4, stage);           // (used by the quadratic white balance only, see below)
+    if constexpr (Ctx::NP >= 30) walk.prime();
+    const Ctx ctx(p, n);
     float acc[Ctx::NP];
 #pragma unroll
     for (int j = 0; j < Ctx::NP; ++j) acc[j] = 0.f;
@@ -63,8 +66,7 @@ __global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_b
     if constexpr (Ctx::NP >= 30) {
         // ... and for it through LDS-DMA, RISP_WBQ_AHEAD vectors ahead (bgr_walk_lds, risp_common.h: the compiler sinks register
         // prefetches to their first use)
-        __shared__ float4 stage[(RISP_WBQ_AHEAD + 1) * 6 * 256];
-        bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, stage, [&](const BgrVec6 &c, int i) {
+        walk.run([&](const BgrVec6 &c, int i) {
             f3 o0 = ctx.bwd({c.b.x, c.g.x, c.r.x}, {c.db.x, c.dg.x, c.dr.x}, acc);
             f3 o1 = ctx.bwd({c.b.y, c.g.y, c.r.y}, {c.db.y, c.dg.y, c.dr.y}, acc);
             f3 o2 = ctx.bwd({c.b.z, c.g.z, c.r.z}, {c.db.z, c.dg.z, c.dr.z}, acc);
@@ -95,11 +97,16 @@ __global__ __launch_bounds__(256, Ctx::NP >= 30 ? RISP_WBQ_WAVES : 1) void bgr_b
             ob[2 * hw4 + i] = make_float4(o0.r, o1.r, o2.r, o3.r);
         }
     }
-    if (Ctx::NP >= 30) block_sum_dpp<Ctx::NP>(acc, red);
-    else block_sum<Ctx::NP>(acc, red);
-    if (threadIdx.x == 0) {      // one partial row per workgroup; param_finish_kernel adds them in index order
+    // one partial row per workgroup; param_finish_kernel adds them in index order
+    if constexpr (Ctx::NP >= 30) {
+        const float t = block_sum_dpp_lanes<Ctx::NP>(acc, red);
+        if (threadIdx.x < Ctx::NP) gp[((size_t)n * gridDim.x + blockIdx.x) * Ctx::NP + threadIdx.x] = t * Ctx::pscale(threadIdx.x);
+    } else {
+        block_sum<Ctx::NP>(acc, red);
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int j = 0; j < Ctx::NP; ++j) gp[((size_t)n * gridDim.x + blockIdx.x) * Ctx::NP + j] = acc[j] * Ctx::pscale(j);
+            for (int j = 0; j < Ctx::NP; ++j) gp[((size_t)n * gridDim.x + blockIdx.x) * Ctx::NP + j] = acc[j] * Ctx::pscale(j);
+        }
     }
 }
 

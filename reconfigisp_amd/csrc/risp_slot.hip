@@ -339,23 +339,28 @@ __global__ __launch_bounds__(256, RISP_WBQ_WAVES) void slot_wbq_params_kernel(co
     return;                                          /* timing only: the empty launch */
 #endif
     const int n = blockIdx.y;
-    int at = -1;
-    for (int k = 0; k < d.K; ++k)
-        if (d.kind[k] == RISP_OP_WB_QUADRATIC) at = k;
-    if (at < 0) return;
-    const WbqCtx wq(d.ptr[at], n);
-    const float w = d.w[at];
-    const size_t base = (size_t)n * 3 * hw4;
-    const float4 *xb = reinterpret_cast<const float4 *>(d.x) + base;
-    const float4 *gb = reinterpret_cast<const float4 *>(gy) + base;
-    float acc[30];
-#pragma unroll
-    for (int j = 0; j < 30; ++j) acc[j] = 0.f;
     __shared__ float4 stage[(RISP_WBQ_AHEAD + 1) * 6 * 256];
 #if defined(RISP_WBQ_ABL) && (RISP_WBQ_ABL == 2 || RISP_WBQ_ABL == 4)
     if (hw4 > 0) hw4 = gridDim.x * blockDim.x;       /* timing only: one vector per thread - the kernel's fixed cost */
 #endif
-    bgr_walk_lds<RISP_WBQ_AHEAD>(xb, gb, hw4, stage, [&](const BgrVec6 &c, int) {           // the walk of bgr_bwd_kernel<WbqCtx> (risp_pointwise.hip)
+    const size_t base = (size_t)n * 3 * hw4;
+    const float4 *xb = reinterpret_cast<const float4 *>(d.x) + base;
+    const float4 *gb = reinterpret_cast<const float4 *>(gy) + base;
+    const BgrWalkLds<RISP_WBQ_AHEAD> walk(xb, gb, hw4, stage);
+    walk.prime();                                      // the first rows travel while the operand is looked up and its coefficients are formed
+    int at = -1;
+    for (int k = 0; k < d.K; ++k)
+        if (d.kind[k] == RISP_OP_WB_QUADRATIC) at = k;
+    if (at < 0) {
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        return;
+    }
+    const WbqCtx wq(d.ptr[at], n);
+    const float w = d.w[at];
+    float acc[30];
+#pragma unroll
+    for (int j = 0; j < 30; ++j) acc[j] = 0.f;
+    walk.run([&](const BgrVec6 &c, int) {           // the walk of bgr_bwd_kernel<WbqCtx> (risp_pointwise.hip)
 #ifdef RISP_WBQ_ABL            /* timing only: the walk without the arithmetic */
         acc[0] += ((c.b.x + c.g.x) + (c.r.x + c.db.x)) + (c.dg.x + c.dr.x) * w;
         acc[1] += ((c.b.y + c.g.y) + (c.r.y + c.db.y)) + (c.dg.y + c.dr.y) * w;
@@ -374,15 +379,12 @@ __global__ __launch_bounds__(256, RISP_WBQ_WAVES) void slot_wbq_params_kernel(co
 #if defined(RISP_WBQ_ABL) && RISP_WBQ_ABL >= 4
     hw4 = 0;
 #endif
-    block_sum_dpp<30>(acc, red);
-    if (threadIdx.x == 0) {
+    const float t = block_sum_dpp_lanes<30>(acc, red);
+    if (threadIdx.x < 30) {
         // this workgroup's row of the main kernel's bx_rows partial rows per image; the rows beyond this kernel's own (coarser)
         // grid receive zeros - the finish kernel adds all bx_rows in index order, and adding 0 changes no bit
-        for (int rb = blockIdx.x; rb < bx_rows; rb += gridDim.x) {
-            float *row = part + ((size_t)n * bx_rows + rb) * RISP_SLOT_ROW;
-#pragma unroll
-            for (int j = 0; j < 30; ++j) row[SO_WQ + j] = rb == (int)blockIdx.x ? acc[j] * 10.f : 0.f;      // WbqCtx::pscale
-        }
+        for (int rb = blockIdx.x; rb < bx_rows; rb += gridDim.x)
+            part[((size_t)n * bx_rows + rb) * RISP_SLOT_ROW + SO_WQ + threadIdx.x] = rb == (int)blockIdx.x ? t * 10.f : 0.f;      // WbqCtx::pscale
     }
 }
 
