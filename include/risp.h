@@ -298,11 +298,11 @@ int risp_conv2d_wino45(const risp_conv_desc *d, void *stream);
  * launches (group_n, strides in floats).  A tile's result does not depend on the batch it travels in. */
 size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize);
 int risp_conv2d_f16x2(const risp_conv_desc *d, void *stream);
-/* Diagnostics (A/B timing in one process, tests): which kernel serves risp_conv2d_f16x2 - 1 (default) = the wave-specialised
- * form of round 5 (one 8-wave workgroup per CU: four waves stage tiles and weights a chunk ahead, four issue the matrix
- * instructions), 0 = the round-4 form (two 4-wave workgroups per CU, every wave does both).  Same arithmetic in the same
- * order: the two give identical bits.  Returns the previous setting; any other argument only queries. */
-int risp_conv_f16x2_variant(int v);
+/* The same layer, same pack, same bits by the form risp_conv2d_f16x2 had in round 4: two 4-wave workgroups per CU in which every
+ * wave stages, waits and multiplies (risp_conv2d_f16x2 = one 8-wave workgroup per CU, four waves stage tiles and weights a chunk
+ * ahead, four issue the matrix instructions).  Serves the one-chunk 3x3 64-cout shape the wave-specialised form does not take;
+ * tests/test_gpu_f16x2.py holds the two to identical bits on every shape and epilogue.  The library keeps no switch between them. */
+int risp_conv2d_f16x2_uniform(const risp_conv_desc *d, void *stream);
 
 /* The same arithmetic for layers with at most 4 output channels and a 5- or 9-tap filter row (round 4; SRCNNRes conv 5x5 32 -> 3,
  * srcnn_res_arch.py:22; backward-data of its 9x9 first layer restricted to the 3 image channels, :18; backward-data of
@@ -380,11 +380,12 @@ int risp_group_sum(const float *stack, float *out, int G, int N, int C, int HW, 
 
 /* Backward-weight of the same layer: dw (cout,cin,k,k) = sum_{n,y,x} gy[n,co,y,x] * load(x)[n,ci,y+ky-p,x+kx-p]
  * (fully written).  Uses d->x, load_mode (PLAIN / CONSTCH), cin_img, cvals, N, H, W, cin, cout, ksize; gy is
- * (N,cout,H,W).  scratch: risp_conv_wgrad_scratch_floats(ksize) floats (per-workgroup partial sums: 768 slices of the pixel
- * tiles, dealt over the 32 x 32 blocks of (cout, cin), added in index order by a finishing launch - no atomics, the same bits on every run).
+ * (N,cout,H,W).  scratch: scratch_floats >= risp_conv_wgrad_scratch_floats(cin, cout, ksize) floats, checked (per-workgroup partial sums:
+ * 768 slices of the pixel tiles, dealt over the 32 x 32 blocks of (cout, cin), k * k slots each - k for the thin layers whose filter column
+ * is packed into the matrix -, added in index order by a finishing launch - no atomics, the same bits on every run).
  * Only the proxy fine-tuning path (darts_ft_model.py:206-246) needs weight gradients. */
-size_t risp_conv_wgrad_scratch_floats(int ksize);
-int risp_conv2d_wgrad(const risp_conv_desc *d, const float *gy, float *dw, float *scratch, void *stream);
+size_t risp_conv_wgrad_scratch_floats(int cin, int cout, int ksize);
+int risp_conv2d_wgrad(const risp_conv_desc *d, const float *gy, float *dw, float *scratch, size_t scratch_floats, void *stream);
 
 /* sum over H,W of channels [c0, c0+nc) of an (N,C,H,W) tensor -> out (N,nc) (SRCNNRes
  * gradient of the broadcast parameter planes). */
@@ -470,8 +471,8 @@ int risp_list_axpy_scalar(const risp_list_desc *d, const float *scalar, float fa
  * sqrt(exp_avg_sq) / bias2_sqrt + eps with a true division (torch's list-wide CUDA form; its CPU form multiplies by the
  * reciprocal: 1 ulp apart).  Rows whose gradient c is NULL are left alone. */
 int risp_sgd_momentum_step(const risp_list_desc *d, float lr, float momentum, int first, void *stream);
-int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
-                   float bias2_sqrt, float eps, void *stream);
+int risp_adam_step(const risp_list_desc *d, float lr_step, float beta2, float one_minus_beta1, float one_minus_beta2, float bias2_sqrt,
+                   float eps, void *stream);
 /* architecture gradient, :254-265 with :313-323: a = b - lr_meta * ((c - e) / 2 * eps[0]); zeros where b, c or e is NULL or
  * the finite-difference term holds a NaN (nan_flags[t] = 1 there; may be NULL).  numel <= 256. */
 int risp_darts_alpha_grad(const risp_list_desc *d, const float *eps, float lr_meta, int *nan_flags, void *stream);
@@ -586,7 +587,7 @@ int risp_resize_rggb(const uint16_t *src, uint16_t *dst, int H0, int W0, int H, 
  * in fp64 into sse[0].  sse: risp_sse_uint8_doubles() doubles - sse[1 ..] receive the workgroups' partial sums, added in index
  * order by a finishing launch (no atomics: the same bits on every run). */
 size_t risp_sse_uint8_doubles(void);
-int risp_sse_uint8(const float *a, const float *b, double *sse, size_t numel, void *stream);
+int risp_sse_uint8(const float *a, const float *b, double *sse, size_t sse_doubles, size_t numel, void *stream);
 
 /* Diagnostics: the kernel instance risp_bilateral_chain_fwd launches for these arguments, named as rocprofv3 prints it
  * (bench.py binds the committed counter readings of profiles/traffic.json to the kernel it actually launches). */

@@ -73,7 +73,7 @@ class ListAdam(torch.optim.Adam):
             for t, rows in by_step.items():
                 for at in range(0, len(rows), L.LIST_MAX):
                     d, _keep = _table(rows[at: at + L.LIST_MAX])
-                    L.call('risp_adam_step', C.byref(d), float(g['lr']) / (1.0 - beta1 ** t), float(beta1), float(beta2),
+                    L.call('risp_adam_step', C.byref(d), float(g['lr']) / (1.0 - beta1 ** t), float(beta2),
                            1.0 - beta1, 1.0 - beta2, math.sqrt(1.0 - beta2 ** t), float(g['eps']), F._stream())
             F._written([p for p in ps] + [self.state[p][k] for p in ps for k in ('exp_avg', 'exp_avg_sq')])
         return None

@@ -116,6 +116,6 @@ def psnr_tensors(a, b):
     if a.shape != b.shape:
         raise ValueError('shape mismatch %s vs %s' % (tuple(a.shape), tuple(b.shape)))
     sse = torch.empty(L.load().risp_sse_uint8_doubles(), device=a.device, dtype=torch.float64)
-    L.call('risp_sse_uint8', F._p(a), F._p(b), C.c_void_p(sse.data_ptr()), a.numel(), F._stream())
+    L.call('risp_sse_uint8', F._p(a), F._p(b), C.c_void_p(sse.data_ptr()), sse.numel(), a.numel(), F._stream())
     mse = sse[0].item() / a.numel()
     return float('inf') if mse == 0 else 10 * math.log10(1. / mse)     # identical images: inf, like numpy's 1./0.

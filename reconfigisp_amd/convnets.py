@@ -508,6 +508,19 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     return out
 
 
+_WGRAD_SCRATCH = {}                                     # per (device, stream): the partial-sum slots of risp_conv2d_wgrad, grown on demand
+
+
+def _wgrad_scratch(device, floats):
+    """one scratch per stream (launches on a stream are ordered: the finishing launch of one call has read the slots before the next
+    call writes them) instead of up to 255 MB from the caching allocator per call"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _WGRAD_SCRATCH.get(key)
+    if t is None or t.numel() < floats:
+        t = _WGRAD_SCRATCH[key] = torch.empty(floats, device=device, dtype=torch.float32)
+    return t
+
+
 def conv_wgrad(x, gy, cin, cout, k, n, h, w, load=LOAD_PLAIN, cin_img=0, cvals=None):
     """(dW (cout,cin,k,k), db (cout,)) of one layer from its input x and the gradient gy at its output (risp_conv2d_wgrad: per-workgroup
     partial sums added in index order - the same bits on every run).  ``load`` LOAD_CONSTCH (SRCNNRes' first layer, srcnn_res_arch.py:
@@ -515,17 +528,18 @@ def conv_wgrad(x, gy, cin, cout, k, n, h, w, load=LOAD_PLAIN, cin_img=0, cvals=N
     taps is cvals^T @ (rectangle sums of gy) - risp_rect_sums, the sums its backward-data pass needs anyway - and only the image channels
     go through the matrix kernel (cin_img * k <= 32: one chain per filter ROW with (channel, column) pairs as the matrix columns)."""
     gy = _dev(gy, 'grad')
-    if load == LOAD_CONSTCH and cin_img * k <= 32 and cvals is not None and h >= k // 2 and w >= k // 2:
+    if load == LOAD_CONSTCH and cin_img * k <= 32 and cvals is not None and h >= k // 2 and k // 2 <= w <= 8192:   # (risp_rect_sums: W <= 8192)
         dw_img, db = conv_wgrad(x, gy, cin_img, cout, k, n, h, w)
         rs = torch.empty((n, cout * k * k), device=gy.device, dtype=torch.float32)
         L.call('risp_rect_sums', _p(gy), _p(rs), n * cout, h, w, k, _stream())
-        dw_c = (cvals.t() @ rs).view(cin - cin_img, cout, k, k).transpose(0, 1)
+        # (C x n) @ (n x cout k k) as products and ONE reduction over the images (no BLAS: its blocking would own the summation order)
+        dw_c = (cvals.t().unsqueeze(2) * rs.unsqueeze(0)).sum(dim=1).view(cin - cin_img, cout, k, k).transpose(0, 1)
         return torch.cat([dw_img, dw_c], dim=1).contiguous(), db
     dw = torch.empty((cout, cin, k, k), device=gy.device, dtype=torch.float32)
-    ws = torch.empty(L.load().risp_conv_wgrad_scratch_floats(k), device=gy.device, dtype=torch.float32)
+    ws = _wgrad_scratch(gy.device, L.load().risp_conv_wgrad_scratch_floats(cin, cout, k))
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=k, load_mode=load, cin_img=cin_img, epilogue=0, add_c=0,
                    x=_p(x), wpack=None, bias=None, cvals=_p(cvals), add=None, mask=None, y=None)
-    L.call('risp_conv2d_wgrad', C.byref(d), _p(gy), _p(dw), _p(ws), _stream())
+    L.call('risp_conv2d_wgrad', C.byref(d), _p(gy), _p(dw), _p(ws), ws.numel(), _stream())
     sums = torch.empty((n, cout), device=gy.device, dtype=torch.float32)
     L.call('risp_plane_sums', _p(gy), _p(sums), n, cout, 0, cout, h * w, _stream())
     return dw, sums.sum(dim=0)

@@ -558,18 +558,11 @@ int launch_f16x2_epi(const risp_conv_desc &d, void *stream) {
     return a ? (m ? launch_f16x2<KS, NT, true, true>(d, stream) : launch_f16x2<KS, NT, true, false>(d, stream))
              : (m ? launch_f16x2<KS, NT, false, true>(d, stream) : launch_f16x2<KS, NT, false, false>(d, stream));
 }
-int g_h2_variant = 1;                                  // risp_conv_f16x2_variant()
 }  // namespace
 
 int risp_launch_f16x2_ws(const risp_conv_desc &d, void *stream);      // risp_conv_f16x2_ws.hip
 
 extern "C" {
-
-int risp_conv_f16x2_variant(int v) {
-    const int old = g_h2_variant;
-    if (v == 0 || v == 1) g_h2_variant = v;
-    return old;
-}
 
 #ifdef RISP_H2_STAMPS
 int risp_conv_f16x2_occupancy(void) {                 // diagnostic builds only: resident workgroups per CU
@@ -586,7 +579,7 @@ size_t risp_conv_f16x2_wpack_bytes(int cin, int cout, int ksize) {
     return 16 + (size_t)nch * ksize * ksize * 2 * 2 * nt * 32 * 16;
 }
 
-int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
+static int f16x2_check(const risp_conv_desc *dp) {
     RISP_CHECK_ARG(dp, "risp_conv2d_f16x2: null descriptor");
     const risp_conv_desc &d = *dp;
     RISP_CHECK_ARG(d.x && d.wpack && d.y, "risp_conv2d_f16x2: null tensor");
@@ -606,11 +599,25 @@ int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
     RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.add) |
                      reinterpret_cast<uintptr_t>(d.mask) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_f16x2: tensors must be 16-byte aligned");
-    // the wave-specialised form (same bits).  Its 64-cout 3x3 kernel spreads a tile's epilogue over the last chunk and the next tile's
-    // first one: a one-chunk layer (16 input channels: none in the proxies) stays on the kernel below
-    if (g_h2_variant == 1 && !(d.ksize == 3 && d.cout == 64 && d.cin < 32)) return risp_launch_f16x2_ws(d, stream);
+    return 0;
+}
+
+/* the form in which every wave stages, waits and multiplies (round 4): two 4-wave workgroups per CU */
+int risp_conv2d_f16x2_uniform(const risp_conv_desc *dp, void *stream) {
+    const int rc = f16x2_check(dp);
+    if (rc) return rc;
+    const risp_conv_desc &d = *dp;
     if (d.ksize == 5) return launch_f16x2_epi<5, 1>(d, stream);         // one cout block per tile: 64 couts = two tiles per pixel tile
     return d.cout == 64 ? launch_f16x2_epi<3, 2>(d, stream) : launch_f16x2_epi<3, 1>(d, stream);
+}
+
+int risp_conv2d_f16x2(const risp_conv_desc *dp, void *stream) {
+    const int rc = f16x2_check(dp);
+    if (rc) return rc;
+    // the wave-specialised form (same bits).  Its 64-cout 3x3 kernel spreads a tile's epilogue over the last chunk and the next tile's
+    // first one: a one-chunk layer (16 input channels: none in the proxies) takes the uniform form
+    if (dp->ksize == 3 && dp->cout == 64 && dp->cin < 32) return risp_conv2d_f16x2_uniform(dp, stream);
+    return risp_launch_f16x2_ws(*dp, stream);
 }
 
 }  // extern "C"

@@ -183,11 +183,19 @@ int launch_wgrad(const risp_conv_desc &d, const float *gy, float *dw, float *scr
 
 extern "C" {
 
-size_t risp_conv_wgrad_scratch_floats(int ksize) { return (size_t)WG_TOTAL * ksize * ksize * 1024; }
+// slots of 1024 floats: one per workgroup and tap chain - k * k chains per workgroup in the plain form, k where the filter column is
+// packed into the matrix (thin layers, see conv_wgrad_kernel)
+size_t risp_conv_wgrad_scratch_floats(int cin, int cout, int ksize) {
+    const bool thin = ksize > 1 && (cin * ksize <= 32 || cout * ksize <= 32);
+    return (size_t)WG_TOTAL * (thin ? ksize : ksize * ksize) * 1024;
+}
 
-int risp_conv2d_wgrad(const risp_conv_desc *dp, const float *gy, float *dw, float *scratch, void *stream) {
+int risp_conv2d_wgrad(const risp_conv_desc *dp, const float *gy, float *dw, float *scratch, size_t scratch_floats, void *stream) {
     RISP_CHECK_ARG(dp && gy && dw && scratch, "risp_conv2d_wgrad: null argument");
     const risp_conv_desc &d = *dp;
+    RISP_CHECK_ARG(scratch_floats >= risp_conv_wgrad_scratch_floats(d.cin, d.cout, d.ksize),
+                   "risp_conv2d_wgrad: scratch holds %zu floats, needs risp_conv_wgrad_scratch_floats(cin, cout, ksize) = %zu", scratch_floats,
+                   risp_conv_wgrad_scratch_floats(d.cin, d.cout, d.ksize));
     RISP_CHECK_ARG(d.group_n == 0, "risp_conv2d_wgrad: grouped descriptors are not supported (one weight gradient per launch)");
     RISP_CHECK_ARG(d.x && d.N > 0 && d.H > 0 && d.W > 0 && d.cin > 0 && d.cin <= 64 && d.cout > 0 && d.cout <= 64 &&
                        (d.ksize == 1 || d.ksize == 3 || d.ksize == 5 || d.ksize == 9),

@@ -485,8 +485,10 @@ int risp_plane_sums(const float *x, float *out, int N, int C, int c0, int nc, in
 
 size_t risp_sse_uint8_doubles(void) { return 1 + 1024; }
 
-int risp_sse_uint8(const float *a, const float *b, double *sse, size_t numel, void *stream) {
+int risp_sse_uint8(const float *a, const float *b, double *sse, size_t sse_doubles, size_t numel, void *stream) {
     RISP_CHECK_ARG(a && b && sse && numel > 0, "risp_sse_uint8: bad arguments");
+    RISP_CHECK_ARG(sse_doubles >= risp_sse_uint8_doubles(), "risp_sse_uint8: sse holds %zu doubles, needs risp_sse_uint8_doubles() = %zu",
+                   sse_doubles, risp_sse_uint8_doubles());
     size_t b_ = (numel + 256 * 16 - 1) / (256 * 16);
     int grid = (int)(b_ < 1 ? 1 : (b_ > 1024 ? 1024 : b_));
     hipLaunchKernelGGL(sse_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, sse, numel);

@@ -225,9 +225,8 @@ int risp_sgd_momentum_step(const risp_list_desc *d, float lr, float momentum, in
     return 0;
 }
 
-int risp_adam_step(const risp_list_desc *d, float lr_step, float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
-                   float bias2_sqrt, float eps, void *stream) {
-    (void)beta1;
+int risp_adam_step(const risp_list_desc *d, float lr_step, float beta2, float one_minus_beta1, float one_minus_beta2, float bias2_sqrt,
+                   float eps, void *stream) {
     if (int st = check_list(d, "risp_adam_step", 1 << 20)) return st;
     for (int t = 0; t < d->n; ++t) RISP_CHECK_ARG(d->b[t] && d->e[t], "risp_adam_step: tensor %d has no moment buffers", t);
     if (d->n == 0) return 0;

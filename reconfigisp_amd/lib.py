@@ -136,8 +136,8 @@ SIGNATURES = {
     'risp_conv_wino45_wpack_floats': (_z, [_i, _i]),
     'risp_conv2d_wino45': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_f16x2_wpack_bytes': (_z, [_i, _i, _i]),
-    'risp_conv_f16x2_variant': (_i, [_i]),
     'risp_conv2d_f16x2': (_i, [C.POINTER(ConvDesc), _s]),
+    'risp_conv2d_f16x2_uniform': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_toep_wpack_bytes': (_z, [_i, _i, _i]),
     'risp_conv2d_toep': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_toep_tiles': (_i, [_i, _i]),
@@ -145,8 +145,8 @@ SIGNATURES = {
     'risp_conv_toep_first_wpack_bytes': (_z, [_i, _i]),
     'risp_conv2d_toep_first': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv2d_toep_first_exact': (_i, [C.POINTER(ConvDesc), _f, C.c_longlong, C.c_void_p, C.c_uint, _s]),
-    'risp_conv_wgrad_scratch_floats': (_z, [_i]),
-    'risp_conv2d_wgrad': (_i, [C.POINTER(ConvDesc), _f, _f, _f, _s]),
+    'risp_conv_wgrad_scratch_floats': (_z, [_i, _i, _i]),
+    'risp_conv2d_wgrad': (_i, [C.POINTER(ConvDesc), _f, _f, _f, _z, _s]),
     'risp_plane_sums': (_i, [_f, _f, _i, _i, _i, _i, _i, _s]),
     'risp_cond_fc_row_floats': (_i, [C.POINTER(C.c_int), _i]),
     'risp_cond_fc_fwd': (_i, [_f, _f, C.POINTER(C.c_int), _i, _f, _f, _i, _s]),
@@ -165,7 +165,7 @@ SIGNATURES = {
     'risp_resize_rggb': (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _s]),
     'risp_bilateral_chain_kernel': (C.c_char_p, [_i, _i, _i]),
     'risp_sse_uint8_doubles': (_z, []),
-    'risp_sse_uint8': (_i, [_f, _f, _f, _z, _s]),
+    'risp_sse_uint8': (_i, [_f, _f, _f, _z, _z, _s]),
     'risp_prune_softmax_fwd': (_i, [_f, _f, _fl, _i, _f, _f, _f, _s]),
     'risp_prune_softmax_bwd': (_i, [_f, _f, _f, _i, _f, _s]),
     'risp_param_blocks_fwd': (_i, [C.POINTER(ParamBlocksDesc), _s]),
@@ -178,7 +178,7 @@ SIGNATURES = {
     'risp_list_axpy_scalar': (_i, [C.POINTER(ListDesc), _f, _fl, _s]),
     'risp_darts_alpha_grad': (_i, [C.POINTER(ListDesc), _f, _fl, _f, _s]),
     'risp_sgd_momentum_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _i, _s]),
-    'risp_adam_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _fl, _fl, _fl, _fl, _fl, _s]),
+    'risp_adam_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _fl, _fl, _fl, _fl, _s]),
     'risp_train_scratch_floats': (_z, [_i]),
     'risp_chain_train_step': (_i, [C.POINTER(TrainDesc), _s]),
 }

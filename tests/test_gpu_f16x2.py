@@ -262,24 +262,17 @@ def test_grouped_launch_equals_member_launches(k, cin, cout):
 @pytest.mark.parametrize('k,cin,cout', [(3, 64, 64), (3, 16, 64), (3, 64, 32), (3, 32, 32), (5, 64, 32), (5, 32, 64), (5, 16, 32)])
 @pytest.mark.parametrize('nhw', [(1, 8, 64), (3, 13, 68), (2, 40, 100), (1, 7, 4), (5, 24, 196), (300, 8, 64)])
 def test_wave_specialised_kernel_gives_the_bits_of_the_round4_kernel(k, cin, cout, nhw):
-    """risp_conv_f16x2_variant: 1 (default) = one 8-wave workgroup per CU with producer and consumer waves (risp_conv_f16x2_ws.hip),
-    0 = the round-4 kernel.  Same products in the same order into every accumulator: identical bits, every epilogue, one tile to
-    several tiles per persistent workgroup."""
-    from reconfigisp_amd import convnets as CN, lib as L
+    """risp_conv2d_f16x2 = one 8-wave workgroup per CU with producer and consumer waves (risp_conv_f16x2_ws.hip),
+    risp_conv2d_f16x2_uniform = the round-4 form in which every wave does both.  Same products in the same order into every
+    accumulator: identical bits, every epilogue, one tile to several tiles per persistent workgroup."""
+    from reconfigisp_amd import convnets as CN
     n, h, w = nhw
     wt, b = rnd(cout, cin, k, k, seed=111) * 0.05, rnd(cout, seed=112) * 0.1
     x, add, mask = rnd(n, cin, h, w, seed=113), rnd(n, cout, h, w, seed=114), rnd(n, cout, h, w, seed=115)
     x[:, : cin // 2] *= 1e-3                                     # the running exponent moves between the chunks
     pf = CN.f16x2_weights(wt, False)
-    lib = L.load()
-    assert lib.risp_conv_f16x2_variant(-1) == 1
-    try:
-        for epi, a, m in ((0, None, None), (CN.EPI_RELU, None, None), (CN.EPI_ADD | CN.EPI_RELU, add, None), (CN.EPI_MASK, None, mask),
-                          (CN.EPI_ADD | CN.EPI_MASK, add, mask)):
-            lib.risp_conv_f16x2_variant(1)
-            y1 = launch_k('risp_conv2d_f16x2', x, pf, b, n, h, w, cin, cout, k, epi, a, m)
-            lib.risp_conv_f16x2_variant(0)
-            y0 = launch_k('risp_conv2d_f16x2', x, pf, b, n, h, w, cin, cout, k, epi, a, m)
-            assert not torch.isnan(y1).any() and torch.equal(y0, y1), epi
-    finally:
-        lib.risp_conv_f16x2_variant(1)
+    for epi, a, m in ((0, None, None), (CN.EPI_RELU, None, None), (CN.EPI_ADD | CN.EPI_RELU, add, None), (CN.EPI_MASK, None, mask),
+                      (CN.EPI_ADD | CN.EPI_MASK, add, mask)):
+        y1 = launch_k('risp_conv2d_f16x2', x, pf, b, n, h, w, cin, cout, k, epi, a, m)
+        y0 = launch_k('risp_conv2d_f16x2_uniform', x, pf, b, n, h, w, cin, cout, k, epi, a, m)
+        assert not torch.isnan(y1).any() and torch.equal(y0, y1), epi

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: risp_conv2d_f16x2 3x3 / 5x5 (env RISP_AB_K), wave-specialised kernel (variant 1) against the round-4 kernel (variant 0), interleaved rounds in ONE
+"""GPU box: risp_conv2d_f16x2 3x3 / 5x5 (env RISP_AB_K), wave-specialised kernel (risp_conv2d_f16x2) against the round-4 form (risp_conv2d_f16x2_uniform), interleaved rounds in ONE
 process on the same tensors; plain / residual + ReLU / mask / residual + mask epilogues.  python tools/ab_ws.py [n h w [cin cout]]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +18,7 @@ add, mask = torch.rand(n, cout, h, w, device='cuda'), torch.randn(n, cout, h, w,
 y = torch.empty(n, cout, h, w, device='cuda')
 pack = CN.f16x2_weights(wt, False)
 lib = L.load()
+ENTRY = {0: 'risp_conv2d_f16x2_uniform', 1: 'risp_conv2d_f16x2'}
 def desc(epi):
     return L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=K, load_mode=0, cin_img=0, epilogue=epi, add_c=cout if epi & CN.EPI_ADD else 0,
                       x=x.data_ptr(), wpack=pack.data_ptr(), bias=b.data_ptr(), cvals=None, add=add.data_ptr() if epi & CN.EPI_ADD else None,
@@ -27,23 +28,20 @@ for what, epi in (('plain', 0), ('relu', CN.EPI_RELU), ('add+relu', CN.EPI_ADD |
     d = desc(epi)
     outs, res = {}, {0: [], 1: []}
     for v in (0, 1):
-        lib.risp_conv_f16x2_variant(v)
         y.fill_(float('nan'))
-        L.call('risp_conv2d_f16x2', C.byref(d), None)
+        L.call(ENTRY[v], C.byref(d), None)
         torch.cuda.synchronize()
         outs[v] = y.clone()
     for rnd in range(5):
         for v in (0, 1):
-            lib.risp_conv_f16x2_variant(v)
             for _ in range(2):
-                L.call('risp_conv2d_f16x2', C.byref(d), None)
+                L.call(ENTRY[v], C.byref(d), None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(); e0.record()
             for _ in range(10):
-                L.call('risp_conv2d_f16x2', C.byref(d), None)
+                L.call(ENTRY[v], C.byref(d), None)
             e1.record(); e1.synchronize()
             res[v].append(e0.elapsed_time(e1) / 10 * 1e3)
-    lib.risp_conv_f16x2_variant(1)
     m0, m1 = sorted(res[0])[2], sorted(res[1])[2]
     print('%-9s %dx%d %dx%dx%dx%d->%d  round-4 %.1f us (min %.1f)  wave-specialised %.1f us (min %.1f)  x%.3f  %.0f TFLOP/s issued (%.2f of 2516.6)  same bits %s nan %d'
           % (what, K, K, n, cin, h, w, cout, m0, min(res[0]), m1, min(res[1]), m0 / m1, flop / m1 / 1e6, flop / m1 / 1e6 / 2516.6,
