@@ -42,6 +42,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 MFMA_F16_PEAK_TFLOPS = 2516.6   # dense f16 / bf16 MFMA: 1024 FLOP / clk / SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF)
+MFMA_F16_SUSTAINED_TFLOPS = 1698.0   # what the bare f16 stream sustains on random halves under the power limit (profiles/r04_mfma_f16_power.txt)
 
 ARCH_HBM = 'Bayer_02_Demosaic_01_sRGB_11_01_14'           # element-wise only: one fused launch
 ARCH_DENOISE = 'Demosaic_01_sRGB_07_11_01_14'             # nearest demosaic, bilateral, WbManual, Gamma, GtmManual
@@ -345,10 +346,11 @@ def search_opt(n_step, distributed):
                                   lr_gamma=0.5, clear_state=False))
 
 
-def search_step_times(device, rank, world, distributed, global_batch, size, n_step, iters):
+def search_step_times(device, rank, world, distributed, global_batch, size, n_step, iters, counts=None):
     """Seconds per DARTS iteration (train.py's loop body: feed_data, update_learning_rate, optimize_alphas,
     optimize_parameters) on this rank's shard of the global batch, and the seconds of it spent inside the gradient
-    all-reduces (a second set of iterations with the collectives bracketed by device synchronisations)."""
+    all-reduces (a second set of iterations with the collectives bracketed by device synchronisations).  ``counts``: a dict
+    that receives, from one more iteration, the matrix FLOPs its launches issue and its C-ABI calls."""
     from reconfigisp_amd.codes.models import create_model
     from reconfigisp_amd.codes.data.synthetic_raw import make_batch
     torch.manual_seed(10)
@@ -391,6 +393,16 @@ def search_step_times(device, rank, world, distributed, global_batch, size, n_st
         comm, model.comm_seconds = model.comm_seconds / iters, None
     loss = model.log_dict['loss']
     per_rank = data[0].shape[0]
+    if counts is not None:
+        import reconfigisp_amd.convnets as CN
+        from reconfigisp_amd import lib as L
+        CN.MFMA_ISSUED, CN.MFMA_ISSUED_F16, L.CALLS = [0.0], [0.0], {}
+        try:
+            step(2 + 2 * iters)
+            torch.cuda.synchronize(device)
+            counts.update(f32_flop=CN.MFMA_ISSUED[0], f16_flop=CN.MFMA_ISSUED_F16[0], c_abi_calls=sum(L.CALLS.values()))
+        finally:
+            CN.MFMA_ISSUED = CN.MFMA_ISSUED_F16 = L.CALLS = None
     del model, data
     torch.cuda.empty_cache()
     return sec, comm, loss, per_rank
@@ -425,6 +437,79 @@ def search_step_leg(device, rank, world, global_batch=32, size=256, n_step=2, it
     return out
 
 
+def config3_leg(device, batch=32, size=256, n_step=3, iters=2):
+    """BASELINE config 3: the 5-slot search step (n_step 3) at batch 32 on one GPU - what train.py:162,220 prints as 'Average time
+    per iter'.  The matrix pipes' share: FLOPs the step's launches issue over the step time, f16 against the nameplate and against
+    what the pipe sustains on random halves under the chip's power limit (profiles/r04_mfma_f16_power.txt)."""
+    c = {}
+    sec, _, loss, _ = search_step_times(device, 0, 1, False, batch, size, n_step, iters, counts=c)
+    pix = 2 * batch * size * size
+    tf16, tf32 = c['f16_flop'] / sec / 1e12, c['f32_flop'] / sec / 1e12
+    return {'workload': 'DARTS iteration, 5-slot super-net (n_step %d, prune 0.2, alpha = 0), batch %d train + %d val %dx%d'
+                        % (n_step, batch, batch, size, size),
+            's_per_step': round(sec, 4), 'MPix_s': round(pix / sec / 1e6, 2), 'loss': round(loss, 6),
+            'c_abi_calls_per_step': c['c_abi_calls'],
+            'mfma_f16_issued_TFLOPs': round(tf16, 1), 'mfma_f32_issued_TFLOPs': round(tf32, 2),
+            'mfma_f16_issued_of_nameplate': round(tf16 / MFMA_F16_PEAK_TFLOPS, 4),
+            'mfma_f16_issued_of_sustained': round(tf16 / MFMA_F16_SUSTAINED_TFLOPS, 4),
+            'mfma_f32_issued_of_peak': round(tf32 / MFMA_F32_PEAK_TFLOPS, 4),
+            'note': 'issued = FLOPs of the matrix instructions the launches execute over the WHOLE step time (element-wise launches, '
+                    'reductions and host gaps included); nameplate %.1f, sustained %.0f TFLOP/s; kernel-time shares by family: '
+                    'profiles/r06_config3_darts_step_kernel_stats.txt' % (MFMA_F16_PEAK_TFLOPS, MFMA_F16_SUSTAINED_TFLOPS)}
+
+
+def shipped_search_leg(device, rank=0, world=1, iters=10):
+    """The search iteration at the geometry the reference ships (options/train/SID_search.yml:16-17,31-34, S7ISP_search.yml: batch 4,
+    48 x 48 crops, n_step 3, prune 0.2; README.md:10 launches it on 4 ranks): launch-bound - iterations per second and C-ABI calls
+    per iteration.  N > 1: the global batch of 4 sharded over the ranks (8 ranks: 8, one crop each - data/__init__.py:15 wants
+    batch %% world == 0), with the four gradient all-reduces."""
+    gb = 4 if 4 % world == 0 else world
+    c = {}
+    sec, comm, loss, per_rank = search_step_times(device, rank, world, world > 1, gb, 48, 3, iters, counts=c)
+    out = {'workload': 'DARTS iteration, 5-slot super-net (n_step 3, prune 0.2), global batch %d train + %d val 48x48 (SID_search.yml)' % (gb, gb),
+           'n_gpus': world, 'per_rank_batch': per_rank, 's_per_iter': round(sec, 5), 'iters_per_s': round(1.0 / sec, 2),
+           'c_abi_calls_per_iter': c['c_abi_calls'], 'loss_rank0': round(loss, 6)}
+    if world > 1:
+        out['allreduce_s_per_iter'] = round(comm, 6)
+    return out
+
+
+def config5_leg(device, tile_batch=21, reps=3):
+    """BASELINE config 5: test_split.py on one 4000 x 3000 frame (patch 512 / stride 480 -> 63 tiles, SID_test.yml:18-19) through
+    Bayer_01_Demosaic_02_sRGB_13; MPix/s on the 12 MPix frame.  First frame (packs built, buffers allocated) and steady state."""
+    from collections import OrderedDict
+    from reconfigisp_amd.codes.models import create_model
+    from reconfigisp_amd.codes.test_split import run_frame
+    H, W = 3000, 4000
+    opt = OrderedDict(model='isp', gpu_ids=[0], dist=False, is_train=False,
+                      network_G=dict(which_model_G='IspUniversal', architecture='Bayer_01_Demosaic_02_sRGB_13',
+                                     individual_module_paths=[None] * 3, module_path=None),
+                      path=dict(pretrain_model_G=None, strict_load=True))
+    torch.manual_seed(10)
+    model = create_model(opt)
+    g = torch.Generator().manual_seed(1)
+    frame = (torch.randint(0, 1024, (1, 1, H, W), generator=g).float() / 1023.).to(device)
+    torch.cuda.synchronize(device)
+    t = time.perf_counter()
+    out = run_frame(model, frame, (512, 512), (480, 480), tile_batch)
+    torch.cuda.synchronize(device)
+    first = time.perf_counter() - t
+    run_frame(model, frame, (512, 512), (480, 480), tile_batch)
+    torch.cuda.synchronize(device)
+    t = time.perf_counter()
+    for _ in range(reps):
+        out = run_frame(model, frame, (512, 512), (480, 480), tile_batch)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t) / reps
+    flop = 239680.0 * 63 * 512 * 512
+    res = {'workload': 'test_split: 1x1x3000x4000 RAW, 63 tiles of 512 (stride 480), tile batch %d, Bayer_01_Demosaic_02_sRGB_13' % tile_batch,
+           'ms_per_frame': round(dt * 1e3, 2), 'first_frame_ms': round(first * 1e3, 1), 'MPix_s_on_12MPix_frame': round(H * W / dt / 1e6, 1),
+           'effective_TFLOPs': round(flop / dt / 1e12, 1), 'finite': bool(torch.isfinite(out).all())}
+    del model, frame, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -445,6 +530,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-search', action='store_true', help='skip the distributed search-step leg (BASELINE config 4)')
     ap.add_argument('--search-batch', type=int, default=32, help='GLOBAL batch of the search-step leg')
+    ap.add_argument('--no-configs', action='store_true', help='skip BASELINE configs 3 / 5 and the shipped search geometry')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -566,12 +652,11 @@ def main():
                      cnn_arith=('2 x f16 split (3 products, f32 accumulate) for the wide 3x3 / 5x5 layers and, on rows of >= 192 pixels, the 9x9 / 5x5 few-channel ends; f32 elsewhere'
                                 if CN.CONV_ARITH == 'f16x2' else 'f32'),
                      cnn_effective_TFLOPs=round(tf(FLOP_PER_PIX_CNN * pix_per_step, dev_ms_c), 2),
-                     cnn_effective_frac=round(tf(FLOP_PER_PIX_CNN * pix_per_step, dev_ms_c) / MFMA_F32_PEAK_TFLOPS, 4),
                      cnn_mfma_issued_TFLOPs=round(tf(issued, dev_ms_c), 2),
                      cnn_mfma_f16_issued_TFLOPs=round(tf(issued16, dev_ms_c), 2),
                      cnn_mfma_issued_frac=round(tf(issued, dev_ms_c) / MFMA_F32_PEAK_TFLOPS + tf(issued16, dev_ms_c) / MFMA_F16_PEAK_TFLOPS, 4),
-                     cnn_note='effective = direct-convolution FLOPs (SURVEY 8d) / time, priced against the F32 matrix peak (it '
-                              'exceeds 1 where Winograd or the f16 pipe do the work: not a utilisation); issued = FLOPs of the MFMA '
+                     cnn_note='effective = direct-convolution FLOPs (SURVEY 8d) / time (exceeds the fp32 matrix peak where Winograd or the '
+                              'f16 pipe do the work: a rate, not a utilisation); issued = FLOPs of the MFMA '
                               'instructions the launches execute (Winograd halves the fp32 3x3 layers, cout padded to 32; the '
                               'split-precision layers issue 3 f16 products per tap; the small-cout layers run on vector FMAs '
                               'and count 0); cnn_mfma_issued_frac = f32 issued / %.1f + f16 issued / %.1f TFLOP/s: the share of the '
@@ -593,6 +678,24 @@ def main():
             leg = {'error': '%s: %s' % (type(e).__name__, e)}
         if rank == 0:
             extra['search_step'] = leg
+        try:
+            leg = shipped_search_leg(device, rank, world)
+        except Exception as e:                                  # noqa: BLE001
+            if world > 1:
+                raise
+            leg = {'error': '%s: %s' % (type(e).__name__, e)}
+        if rank == 0:
+            extra['search_step_shipped'] = leg
+    if not args.no_configs:
+        # BASELINE configs 3 and 5, driver-run (every rank runs them on its own GPU, after the collectives of the legs above: no
+        # rank waits in a collective meanwhile; rank 0's figures are reported)
+        for key, fn in (('config3', config3_leg), ('config5', config5_leg)):
+            try:
+                leg = fn(device)
+            except Exception as e:                              # noqa: BLE001
+                leg = {'error': '%s: %s' % (type(e).__name__, e)}
+            if rank == 0:
+                extra[key] = leg
 
     proof = None
     if world > 1:

@@ -207,9 +207,14 @@ def load():
     return lib
 
 
+CALLS = None            # diagnostics (bench.py, tools/): set to {} to count the C-ABI calls by entry point
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; raise RuntimeError with risp_last_error() on failure."""
     lib = load()
+    if CALLS is not None:
+        CALLS[name] = CALLS.get(name, 0) + 1
     status = getattr(lib, name)(*args)
     if status != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, status, lib.risp_last_error().decode()))

@@ -60,16 +60,33 @@ def test_darts_iterations_within_budget(fixture, n_step, toep_first, monkeypatch
     exactly as the slot's 15 architecture gradients are one vector: relative to the slot's largest gradient / update, still against
     float64, still within twice the reference's own error.  A wrong gradient of any operator shows up at its full size; the relative
     error of a cancelling scalar does not decide the test."""
-    from reconfigisp_amd.codes.models import create_model
     from reconfigisp_amd import convnets as CN
     if toep_first is not None:
         monkeypatch.setattr(CN, 'TOEP_FIRST', toep_first)
+    g = load_golden(fixture)
+    _darts_iterations(fixture, n_step, per_slot=float(g.get('fp32_vs_f64', 0.0)) > 2e-5)
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+def test_darts_shipped_geometry_per_tensor_on_the_fp32_route(monkeypatch):
+    """'darts_step_n3' (the reference's shipped search geometry) TENSOR BY TENSOR - every architecture gradient, every operator's
+    parameter gradient and state, no per-slot vectors, one outlier event in all - with the convolutions on the fp32 matrix-core
+    kernels (RISP_CONV_ARITH=f32, first layers of the training forwards on risp_conv2d_k3: RISP_CONV_TOEP_FIRST=infer).  Where
+    test_darts_iterations_within_budget judges the default arithmetic against float64 slot by slot, this one pins the step LOGIC of the
+    5-slot geometry on the GPU: a wrong gradient of any single operator fails at its own tensor."""
+    from reconfigisp_amd import convnets as CN
+    monkeypatch.setattr(CN, 'CONV_ARITH', 'f32')
+    monkeypatch.setattr(CN, 'TOEP_FIRST', 'infer')
+    _darts_iterations('darts_step_n3', 3, per_slot=False, outliers=1)
+
+
+def _darts_iterations(fixture, n_step, per_slot, outliers=None):
+    from reconfigisp_amd.codes.models import create_model
     g, f = load_golden(fixture), load_golden(fixture + '_f64')
-    per_slot = float(g.get('fp32_vs_f64', 0.0)) > 2e-5
     # outlier events (a tensor further from float64 than twice the reference's fp32 run on that very tensor): one per scenario where the
     # reference agrees with itself; one per ITERATION on the shipped geometry, where a flipped mask is the expectation (the reference's
     # own fp32 run shows one in each iteration: alpha_grad1 at 8.9e-5 and 2.1e-5 of its magnitude)
-    budget = ErrorBudget(outliers=2 if per_slot else 1)
+    budget = ErrorBudget(outliers=outliers if outliers is not None else (2 if per_slot else 1))
     model = create_model(darts_opt(torch.device('cuda'), n_step))
     seed_darts(model)
     data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
