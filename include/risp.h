@@ -324,6 +324,26 @@ int risp_conv2d_toep(const risp_conv_desc *d, void *stream);
 int risp_conv_toep_tiles(int H, int W);
 int risp_conv2d_toep_sums(const risp_conv_desc *d, float *psum, void *stream);
 
+/* The layers with at most 3 output channels and cin % 16 == 0 (SRCNNRes conv 5x5 32 -> 3 forward, srcnn_res_arch.py:22; backward-data of
+ * its 9x9 first layer restricted to the 3 image channels, :18) with the filter ROWS moved into the rows of the matrix instruction
+ * (round 6, risp_conv_tapout.hip): reduction index = 16 input channels (dense), rows = (cout, ky), the filter column kx = a shift of the
+ * pixel operand; one matrix pass per INPUT row, whose 3 x k results are added into a ring of output rows (every address by one lane
+ * in program order: bit-repeatable).  Half the matrix instructions of risp_conv2d_toep for 9x9 64 -> 3.  Split precision as in
+ * risp_conv2d_f16x2, activations scaled per (4 rows x 136 columns, 16 channels).
+ * wpack: risp_conv_tapout_wpack_bytes() bytes, 16-byte aligned: a 16-byte header whose first float is 1 / s_w, then [chunk of 16
+ * cin][kx][part: hi, lo][channel half][row m, 32][8 channels] _Float16 with row m = 4 ky + co (ky < 8) or 4 co + 3 (ky = 8)
+ * (reconfigisp_amd/convnets.py::tapout_weights).  ksize 5 or 9, cout <= 3, cin % 16 == 0, W % 4 == 0, H * W < 2^24, cin * H * W < 2^30;
+ * load_mode PLAIN; epilogue RELU | ADD (add_c <= cout) | NOBIAS; grouped launches.  seg_rows: rows of a work item's segment - 0 = chosen by the launch to fill
+ * the chip (training launches), else a multiple of 4 fixed by the caller: an image's result then does not depend on the batch it
+ * travels in (the scales follow the segment's row phase). */
+size_t risp_conv_tapout_wpack_bytes(int cin, int ksize);
+int risp_conv_tapout_seg_rows(int N, int H, int W);          /* what seg_rows = 0 chooses for a launch of N images (a pure function) */
+int risp_conv2d_tapout(const risp_conv_desc *d, int seg_rows, void *stream);
+/* ... and, on the way, the sum of every input channel over every work item's own pixels (ksize 9, cin 64):
+ * psum [N][risp_conv_tapout_items(N, H, W, seg_rows)][64] floats, finished by risp_rect_sums_tiles. */
+int risp_conv_tapout_items(int N, int H, int W, int seg_rows);
+int risp_conv2d_tapout_sums(const risp_conv_desc *d, int seg_rows, float *psum, void *stream);
+
 /* ... and for the 9x9 FIRST layers (few input channels, 64 couts: SRCNNRes 3 -> 64 with its broadcast planes folded out,
  * srcnn_res_arch.py:18, 41-46; SRCNNDemosaic 4 -> 64 on the mosaic, srcnn_demosaic_arch.py:14-16, 39-43 - what risp_conv2d_k3
  * does on the fp32 matrix pipe): rows = 32 couts, one accumulator per pixel position j of a block of 8, the 8 A operands are

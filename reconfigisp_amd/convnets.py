@@ -125,6 +125,36 @@ def toep_weights(w, transpose=False, keep=None):
     return torch.cat([hdr.view(torch.float16), band.reshape(-1)])
 
 
+def tapout_weights(w, transpose=False, keep=None):
+    """Pre-split pack of ``risp_conv2d_tapout`` (include/risp.h) from a layer's (cout <= 3, cin % 16 == 0, k, k) tensor, k = 5 or 9: a
+    16-byte header whose first float is 1 / s_w, then [chunk of 16 cin][kx][part: hi, lo][channel half][row m, 32][8 channels] halves of
+    w * s_w with row m = 4 ky + co for ky < 8 and 4 co + 3 for ky = 8 - the filter ROWS sit in the rows of the matrix instruction, the
+    filter column is a shift of the pixel operand.  ``transpose``: the backward-data layer of a FORWARD weight (roles swapped, taps
+    rotated by 180 degrees) restricted to its first ``keep`` input channels.  Scale and split as in ``f16x2_weights``; pure tensor
+    algebra on the device of ``w``.  Returns a float16 tensor."""
+    if transpose:
+        w = w[:, :keep].flip(2, 3).transpose(0, 1)
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    if k not in (5, 9) or co > 3 or ci % 16:
+        raise ValueError('tap-row pack: %d output channels (at most 3), %d input channels (a multiple of 16), %d taps (5 or 9)' % (co, ci, k))
+    _, e = torch.frexp(w.detach().abs().max())
+    sw = torch.ldexp(torch.ones((), device=w.device), 15 - e)
+    ws = w.detach().float() * sw
+    hi = ws.half()
+    parts = (hi, (ws - hi.float()).half())
+    rows = torch.zeros((2, ci, k, 32), device=w.device, dtype=torch.float16)                 # (part, ci, kx, m)
+    for c in range(co):
+        for ky in range(k):
+            m = 4 * ky + c if ky < 8 else 4 * c + 3
+            for part in range(2):
+                rows[part, :, :, m] = parts[part][c, :, ky, :]
+    #       (part, chunk, half, 8, kx, m) -> (chunk, kx, part, half, m, 8)
+    p = rows.view(2, ci // 16, 2, 8, k, 32).permute(1, 4, 0, 2, 5, 3).contiguous()
+    hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
+    hdr[0] = 1.0 / sw
+    return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
+
+
 def toep_first_weights(w):
     """Pre-split pack of ``risp_conv2d_toep_first`` (include/risp.h) from a 9x9 first layer's (cout, cin <= 16, 9, 9) tensor: a
     16-byte header whose first float is 1 / s_w, then [cout block of 32][cin][ky][part: hi, lo][taps 0-7 | tap 8 and 7 zeros][cout][8]
@@ -236,6 +266,11 @@ def small_has_toep(k, cout):
     return (k == 9 and cout <= 4) or (k == 5 and cout <= 12)
 
 
+def small_has_tapout(k, cin, cout):
+    """... and a tap-row pack for risp_conv2d_tapout (at most 3 couts, whole chunks of 16 input channels)"""
+    return k in (5, 9) and cout <= 3 and cin % 16 == 0 and cin > 0
+
+
 class PackedConv:
     """Device-side packed weights of one layer, forward and backward-data."""
 
@@ -276,6 +311,8 @@ class SmallConv:
         self.cin, self.k = self.wpack.shape[0], self.wpack.shape[2]
         # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts
         self.toep = toep_weights(w, transpose, keep) if small_has_toep(self.k, self.cout) else None
+        # ... and with the filter rows in the rows of the matrix instruction (risp_conv2d_tapout): half the matrix work of the band form
+        self.tapout = tapout_weights(w, transpose, keep) if small_has_tapout(self.k, self.cin, self.cout) else None
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
 
 
@@ -299,6 +336,11 @@ def toep_grid_ok(images, h, w):
     its input-channel split fills the chip better)"""
     tiles = ((h + 31) // 32) * ((w + 127) // 128) if w <= 128 else ((h + 15) // 16) * ((w + 255) // 256)
     return images * tiles >= TOEP_MIN_TILES
+
+
+def _tapout_ok(sc, h, w, epi=0):
+    return (CONV_ARITH == 'f16x2' and getattr(sc, 'tapout', None) is not None and not (epi & EPI_SHUFFLE2) and w % 4 == 0
+            and sc.cin * h * w < (1 << 30) and h * w < (1 << 24))
 
 
 def _toep_ok(sc, h, w):
@@ -334,27 +376,45 @@ def _tie_list(device):
 
 
 TOEP_MIN_TILES = 256                        # training launches: tiles below which the vector-FMA kernel with its channel split serves
+TAPOUT_MIN_ITEMS = 128                      # ... and work items (image, 128-column strip, 32-row segment) below which it serves instead of risp_conv2d_tapout
+TAPOUT_INFER_SEG = 64                       # rows of a work item's segment in inference launches (fixed: a result must not depend on the batch)
 
 
-def route_small(k, cin, cout, h, w, images, infer=False, has_mask=False, has_toep=True, split=None):
-    """The dispatch of ``conv_small`` (layers with at most 12 output channels): 5- and 9-tap layers that hold a Toeplitz-band pack
-    (at most 4 couts, or 5 .. 12 with 5 taps) run on risp_conv2d_toep (f16 matrix pipe, split precision) under RISP_CONV_ARITH=f16x2
-    when W % 4 == 0 and the launch has no mask - ALWAYS for inference (a tile's result must not depend on the batch it travels in),
-    for training when the grid holds at least TOEP_MIN_TILES tiles (or the caller forces ``split`` = 0: the per-member form of a
-    grouped launch follows the grouped grid); everything else on risp_conv2d_small (vector FMAs; small training grids split their
-    input channels over several workgroups per tile: risp_conv2d_small_split, never for inference)."""
-    toep = CONV_ARITH == 'f16x2' and has_toep and w % 4 == 0 and cin * h * w < (1 << 30) and not has_mask
-    if toep and (infer or (split == 0 if split is not None else toep_grid_ok(images, h, w))):
+def tapout_grid_ok(images, h, w):
+    """training launches: enough (strip, segment) work items for the persistent grid of ``risp_conv2d_tapout``"""
+    return images * ((w + 127) // 128) * max(1, h // 32) >= TAPOUT_MIN_ITEMS
+
+
+def tapout_seg(images, h, w, infer):
+    """rows of a work item's segment: fixed for inference, chosen by the grid of ALL the images of a (grouped) launch for training -
+    the per-member form of a grouped launch passes the grouped launch's value, so that both cut the planes alike (same bits)"""
+    return min(TAPOUT_INFER_SEG, h) if infer else L.load().risp_conv_tapout_seg_rows(images, h, w)
+
+
+def route_small(k, cin, cout, h, w, images, infer=False, has_mask=False, has_toep=True, split=None, has_tapout=False):
+    """The dispatch of ``conv_small`` (layers with at most 12 output channels).  Under RISP_CONV_ARITH=f16x2, W % 4 == 0, no mask:
+    layers that hold a tap-row pack (at most 3 couts, cin % 16 == 0, 5 or 9 taps) run on risp_conv2d_tapout, the other 5- and 9-tap
+    layers that hold a Toeplitz-band pack (4 couts, or 5 .. 12 with 5 taps, or odd channel counts) on risp_conv2d_toep (both: f16 matrix
+    pipe, split precision) - ALWAYS for inference (a tile's result must not depend on the batch it travels in), for training when the
+    grid holds enough work (TAPOUT_MIN_ITEMS / TOEP_MIN_TILES; or the caller forces ``split`` = 0: the per-member form of a grouped
+    launch follows the grouped grid); everything else on risp_conv2d_small (vector FMAs; small training grids split their input
+    channels over several workgroups per tile: risp_conv2d_small_split, never for inference)."""
+    mat = CONV_ARITH == 'f16x2' and w % 4 == 0 and cin * h * w < (1 << 30) and not has_mask
+    if mat and has_tapout and h * w < (1 << 24) and (infer or (split == 0 if split is not None else tapout_grid_ok(images, h, w))):
+        return 'risp_conv2d_tapout'
+    if mat and has_toep and (infer or (split == 0 if split is not None else toep_grid_ok(images, h, w))):
         return 'risp_conv2d_toep'
     return 'risp_conv2d_small'
 
 
-def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False, out=None, group=None, split=None, tile_sums=None):
+def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False, out=None, group=None, split=None, tile_sums=None,
+               seg_rows=None):
     """One launch of a layer with at most 12 output channels (``route_small``).  ``infer``: never split the input channels over
     workgroups - the split depends on the grid, and an inference result must not depend on the batch a tile travels in
     (test_split.py batches tiles).  ``group``: see ``_group_fields``; ``split``: force the channel split (the per-member form of a
-    grouped launch uses the split the grouped grid would take; 0 = the Toeplitz-band kernel).  ``tile_sums``: a list that receives
-    the per-tile sums of the input planes when the Toeplitz-band kernel serves the launch (see ``rect_sums``)."""
+    grouped launch uses the split the grouped grid would take; 0 = the matrix-pipe kernel) and ``seg_rows`` the segment height of
+    risp_conv2d_tapout (``tapout_seg`` of the grouped launch).  ``tile_sums``: a list that receives the per-tile sums of the input
+    planes when a matrix-pipe kernel serves the launch (see ``rect_sums``)."""
     if sc.bias is None:
         epi |= EPI_NOBIAS
     nn_ = n * (group[0] if group else 1)
@@ -364,8 +424,25 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
-    toep = getattr(sc, 'toep', None)
-    if route_small(sc.k, sc.cin, sc.cout, h, w, nn_, infer, mask is not None, toep is not None, split) == 'risp_conv2d_toep':
+    toep, tapout = getattr(sc, 'toep', None), getattr(sc, 'tapout', None)
+    if epi & EPI_SHUFFLE2:
+        tapout = None
+    entry = route_small(sc.k, sc.cin, sc.cout, h, w, nn_, infer, mask is not None, toep is not None, split, tapout is not None)
+    if entry == 'risp_conv2d_tapout':
+        # the f16 matrix pipe with the filter rows as the rows of the matrix instruction: half the matrix work of the band form
+        d.wpack = _p(tapout)
+        _group_fields(d, n, group, tapout, sc.bias)
+        seg = seg_rows if seg_rows is not None else tapout_seg(nn_, h, w, infer)
+        if tile_sums is not None and sc.k == 9 and sc.cin == 64:
+            ps = torch.empty((nn_, L.load().risp_conv_tapout_items(nn_, h, w, seg), 64), device=x.device, dtype=torch.float32)
+            L.call('risp_conv2d_tapout_sums', C.byref(d), seg, _p(ps), _stream())
+            tile_sums.append(ps)
+        else:
+            L.call('risp_conv2d_tapout', C.byref(d), seg, _stream())
+        if MFMA_ISSUED_F16 is not None:                # per filter column and chunk of 16 channels: 3 products of 32 rows x 16 channels per pixel
+            MFMA_ISSUED_F16[0] += 3 * 2.0 * 32 * sc.k * sc.cin * nn_ * h * w
+        return out
+    if entry == 'risp_conv2d_toep':
         # the f16 matrix pipe (Toeplitz bands of the filter rows as the A operand): 2.5-3 x the vector-FMA kernel on full grids
         d.wpack = _p(toep)
         _group_fields(d, n, group, toep, sc.bias)
@@ -882,7 +959,7 @@ def stack_packed(pcs):
 
 
 def stack_small(scs):
-    return _Stacked(scs, ('wpack', 'bias', 'toep'), ('cin', 'cout', 'k'))
+    return _Stacked(scs, ('wpack', 'bias', 'toep', 'tapout'), ('cin', 'cout', 'k'))
 
 
 def _stack_grads(gys, like):
@@ -963,7 +1040,8 @@ class _SrcnnResGroupFn(torch.autograd.Function):
                 s = slice(g * n, (g + 1) * n)
                 conv(x, c1.fold.img, n, h, w, epi=EPI_RELU | EPI_CASEBIAS, cvals=table[s], out=t1[s])
                 conv(t1[s], c2, n, h, w, epi=EPI_RELU, out=t2[s])
-                conv_small(t2[s], c1.fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, out=y[s], split=split)
+                conv_small(t2[s], c1.fold.tail, n, h, w, epi=EPI_ADD, add=x, add_c=3, out=y[s], split=split,
+                           seg_rows=tapout_seg(G * n, h, w, False))
             _count(3 + 3 * G)
         ctx.save_for_backward(t1, t2, arg, x)
         ctx.gp, ctx.dims, ctx.grouped, ctx.flags = gp, (n, h, w), grouped, flags
@@ -998,7 +1076,8 @@ class _SrcnnResGroupFn(torch.autograd.Function):
                 s = slice(g * n, (g + 1) * n)
                 conv(gy[s], c3, n, h, w, transpose=True, epi=EPI_MASK, mask=t2[s], out=g2[s])
                 conv(g2[s], c2, n, h, w, transpose=True, epi=EPI_MASK, mask=t1[s], out=g1[s])
-                conv_small(g1[s], c1.fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy[s], add_c=3, out=gxs[s], split=split, tile_sums=tsm)
+                conv_small(g1[s], c1.fold.bwd_img, n, h, w, epi=EPI_ADD, add=gy[s], add_c=3, out=gxs[s], split=split, tile_sums=tsm,
+                           seg_rows=tapout_seg(G * n, h, w, False))
             if tsm:
                 ts.append(torch.cat(tsm))
             _count(3 * G)
@@ -1019,7 +1098,10 @@ class _SrcnnResGroupFn(torch.autograd.Function):
 def _small_split(x, sc, n_total, h, w, epi, add_c):
     """the channel split ``conv_small`` would take for the grouped launch (so that the per-member form uses the same); 0 = the
     grouped launch runs on ``risp_conv2d_toep``"""
-    if _toep_ok(sc, h, w) and toep_grid_ok(n_total, h, w):
+    if _tapout_ok(sc, h, w, epi):
+        if tapout_grid_ok(n_total, h, w):
+            return 0
+    elif _toep_ok(sc, h, w) and toep_grid_ok(n_total, h, w):
         return 0
     d = L.ConvDesc(N=n_total, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=None, cvals=None, add=None, mask=None, y=None)

@@ -142,6 +142,11 @@ SIGNATURES = {
     'risp_conv2d_toep': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_toep_tiles': (_i, [_i, _i]),
     'risp_conv2d_toep_sums': (_i, [C.POINTER(ConvDesc), _f, _s]),
+    'risp_conv_tapout_wpack_bytes': (_z, [_i, _i]),
+    'risp_conv_tapout_seg_rows': (_i, [_i, _i, _i]),
+    'risp_conv2d_tapout': (_i, [C.POINTER(ConvDesc), _i, _s]),
+    'risp_conv_tapout_items': (_i, [_i, _i, _i, _i]),
+    'risp_conv2d_tapout_sums': (_i, [C.POINTER(ConvDesc), _i, _f, _s]),
     'risp_conv_toep_first_wpack_bytes': (_z, [_i, _i]),
     'risp_conv2d_toep_first': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv2d_toep_first_exact': (_i, [C.POINTER(ConvDesc), _f, C.c_longlong, C.c_void_p, C.c_uint, _s]),

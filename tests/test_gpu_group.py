@@ -49,10 +49,11 @@ def _run_group(mods, x, pvs, gys, grouped):
 @pytest.mark.parametrize('shape', [(4, 256, 256), (32, 256, 256), (3, 40, 72), (2, 16, 24)])
 def test_grouped_srcnn_res_equals_member_launches_and_per_op_path(shape):
     """batch 4 (a rank of the 8-GPU search) and batch 32 (BASELINE config 3) at 256 x 256, plus ragged shapes: one launch
-    per layer == eight launches per layer, bit for bit.  Against the per-operator path of round 2: the same bits when
-    both take the same form of the direct small-cout kernel (batch 32); on a small grid the per-operator launches split
-    their input channels over workgroups (risp_conv2d_small_split) and the grouped grid - eight times larger - does
-    not: the same sums in another order, compared at float tolerance."""
+    per layer == eight launches per layer, bit for bit.  Against the per-operator path of round 2: the same bits of every image
+    tensor when both take the matrix-pipe kernels (batch 32: risp_conv2d_tapout's step tiles sit on one 4-row grid however the
+    launch cuts its segments); the parameter gradients pass through per-work-item channel sums, which a launch of 32 images cuts
+    finer than one of 256 - the same sums in another order, compared at float tolerance, like everything on a small grid, where
+    the per-operator launches split their input channels over workgroups (risp_conv2d_small_split) and the grouped grid does not."""
     import reconfigisp_amd.functional as F
     n, h, w = shape
     mods = _family()
@@ -71,7 +72,7 @@ def test_grouped_srcnn_res_equals_member_launches_and_per_op_path(shape):
         gx, gp = torch.autograd.grad(y, (xo, po), gys[j])
         if n == 32:
             assert torch.equal(y, outs_g[j]), 'member %d forward' % j
-            assert torch.equal(gp, grads_g[1 + j]), 'member %d parameter gradient' % j
+            assert_close(gp, grads_g[1 + j], rtol=1e-5, floor=1.0, what='member %d parameter gradient' % j)
         else:
             assert_close(y, outs_g[j], rtol=1e-5, floor=1.0, what='member %d forward' % j)
             assert_close(gp, grads_g[1 + j], rtol=1e-5, floor=1.0, what='member %d parameter gradient' % j)

@@ -199,7 +199,7 @@ def test_conv_small_dispatch(monkeypatch):
         return real(name, *a)
     monkeypatch.setattr(CN.L, 'call', spy)
     monkeypatch.setattr(CN, 'TOEP_MIN_TILES', 256)
-    wt, b = rnd(3, 32, 5, 5, seed=90) * 0.05, rnd(3, seed=91) * 0.1
+    wt, b = rnd(4, 32, 5, 5, seed=90) * 0.05, rnd(4, seed=91) * 0.1      # 4 couts: the band kernel's layer (3 couts: test_gpu_tapout.py)
     sc = CN.SmallConv(wt, b)
     x = rnd(2, 32, 32, 256, seed=92)
     ref = TF.conv2d(x.double(), wt.double(), b.double(), padding=2)

@@ -297,6 +297,47 @@ def test_toeplitz_band_pack_reproduces_the_convolution(k, co, ci, tr):
     assert (out - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
 
 
+# --------------------------------------------------------------------------- filter rows in the matrix rows (risp_conv2d_tapout)
+@pytest.mark.parametrize('k,co,ci,tr', [(9, 3, 64, True), (5, 3, 32, False), (9, 2, 16, False), (5, 1, 48, True), (9, 3, 32, False)])
+def test_tap_row_pack_reproduces_the_convolution(k, co, ci, tr):
+    """convnets.tapout_weights: header = 1 / s_w, body [chunk of 16 cin][kx][hi, lo][channel half][row m][8 channels] with row
+    m = 4 ky + co (ky < 8) or 4 co + 3 (ky = 8).  As the kernel consumes it: per INPUT row y' one matrix pass
+    D[m][x] = sum_kx sum_ci W[m][ci][kx] in[ci][y'][x + kx - P], then out[co][y] = sum_ky D[m(co, ky)][y + ky - P] - the whole
+    convolution (or the backward-data one of the transposed pack)."""
+    torch.manual_seed(k + co + ci)
+    w = torch.randn(co, ci, k, k) * 0.05 if not tr else torch.randn(ci, co + 2, k, k) * 0.05
+    p = CN.tapout_weights(w, tr, co if tr else None)
+    nch, pad = ci // 16, k // 2
+    assert p.dtype == torch.float16 and p.numel() == 8 + nch * k * 2 * 2 * 32 * 8
+    inv = p[:2].view(torch.float32).item()
+    wt = w[:, :co].flip(2, 3).transpose(0, 1) if tr else w
+    sw = 1.0 / inv
+    assert 2.0 ** 14 <= wt.abs().max().item() * sw < 2.0 ** 15 and sw == 2.0 ** round(np.log2(sw))
+    body = p[8:].view(nch, k, 2, 2, 32, 8).double()
+    #     (chunk, kx, half, m, 8) -> W[m][ci = 16 chunk + 8 half + e][kx]
+    W = ((body[:, :, 0] + body[:, :, 1]) * inv).permute(3, 0, 2, 4, 1).reshape(32, ci, k)
+    row = lambda c, ky: 4 * ky + c if ky < 8 else 4 * c + 3
+    used = sorted(row(c, ky) for c in range(co) for ky in range(k))
+    assert len(set(used)) == co * k and max(used) < 32
+    unused = [m for m in range(32) if m not in used]
+    assert not unused or W[unused].abs().max().item() == 0
+    h, wd = 11, 20
+    x = torch.randn(2, ci, h, wd, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(x, wt.double(), padding=pad)
+    D = torch.nn.functional.conv2d(x, W.view(32, ci, 1, k), padding=(0, pad))              # (n, 32, h, wd): one pass per input row
+    out = torch.zeros(2, co, h, wd, dtype=torch.float64)
+    for c in range(co):
+        for ky in range(k):
+            for y in range(h):
+                if 0 <= y + ky - pad < h:
+                    out[:, c, y] += D[:, row(c, ky), y + ky - pad]
+    assert (out - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        CN.tapout_weights(torch.randn(4, 16, 9, 9))
+    with pytest.raises(ValueError):
+        CN.tapout_weights(torch.randn(3, 12, 5, 5))
+
+
 @pytest.mark.parametrize('co,ci', [(64, 3), (40, 4), (7, 2)])
 def test_first_layer_window_pack_reproduces_the_convolution(co, ci):
     """convnets.toep_first_weights: header = 1 / s_w, body [cout block][cin][ky][hi, lo][taps 0-7 | tap 8 + zeros][cout][8].  The kernel

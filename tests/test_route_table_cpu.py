@@ -41,8 +41,11 @@ CONV = {
 }
 SMALLS = {
     # (k, cin, cout, has_mask): {(mode, images): entry}
-    ('srcnn_res', '5x5 32->3 last', 'fwd'): ((5, 32, 3, False), {('train', BIG): 'risp_conv2d_toep', ('train', SMALL): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_toep', ('f32', BIG): 'risp_conv2d_small'}),
-    ('srcnn_res', '9x9 64->3 first', 'bwd'): ((9, 64, 3, False), {('train', BIG): 'risp_conv2d_toep', ('train', SMALL): 'risp_conv2d_small', ('f32', BIG): 'risp_conv2d_small'}),
+    # (round 6: the 3-cout layers with whole chunks of 16 input channels run with the filter rows in the rows of the matrix instruction -
+    # useful / issued products 0.84 for 9x9 64 -> 3 (27 of 32 rows, every reduction slot a channel) against 0.42 in the band form, 0.47
+    # against 0.23 for 5x5 32 -> 3; a batch of ONE 256 x 256 image is 16 work items: below TAPOUT_MIN_ITEMS, the vector kernel)
+    ('srcnn_res', '5x5 32->3 last', 'fwd'): ((5, 32, 3, False), {('train', BIG): 'risp_conv2d_tapout', ('train', SMALL): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_tapout', ('f32', BIG): 'risp_conv2d_small'}),
+    ('srcnn_res', '9x9 64->3 first', 'bwd'): ((9, 64, 3, False), {('train', BIG): 'risp_conv2d_tapout', ('train', SMALL): 'risp_conv2d_small', ('train', 8): 'risp_conv2d_tapout', ('f32', BIG): 'risp_conv2d_small'}),
     ('srcnn_demosaic', '5x5 32->12 last + PixelShuffle', 'fwd'): ((5, 32, 12, False), {('train', BIG): 'risp_conv2d_toep', ('train', SMALL): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_toep', ('f32', BIG): 'risp_conv2d_small'}),
     ('srcnn_demosaic', '9x9 64->4 first (through PixelShuffle)', 'bwd'): ((9, 64, 4, False), {('train', BIG): 'risp_conv2d_toep', ('train', SMALL): 'risp_conv2d_small', ('f32', BIG): 'risp_conv2d_small'}),
     ('path14l_bayer', '3x3 64->4 last + PixelShuffle', 'fwd'): ((3, 64, 4, False), {('train', BIG): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_small', ('f32', BIG): 'risp_conv2d_small'}),
@@ -78,8 +81,19 @@ def test_route_small_table(key, monkeypatch):
     (k, cin, cout, has_mask), want = SMALLS[key]
     for (mode, images), entry in want.items():
         infer = _mode(monkeypatch, mode)
-        got = CN.route_small(k, cin, cout, H, W, images, infer, has_mask, CN.small_has_toep(k, cout))
+        got = CN.route_small(k, cin, cout, H, W, images, infer, has_mask, CN.small_has_toep(k, cout), None, CN.small_has_tapout(k, cin, cout))
         assert got == entry, (key, mode, images, got)
+
+
+def test_useful_over_issued_products_of_the_few_channel_kernels():
+    """what a matrix instruction of each form carries: rows used x reduction slots used"""
+    band = lambda k, cout: (k / 16.0) * (cout / 4.0)                 # risp_conv2d_toep: 16-slot window, rows = 4 couts x 8 positions
+    taprow = lambda k, cout: (k * cout) / 32.0                      # risp_conv2d_tapout: rows = (cout, ky), every slot a channel
+    assert abs(band(9, 3) - 0.42) < 0.005 and abs(taprow(9, 3) - 0.84) < 0.005
+    assert abs(band(5, 3) - 0.23) < 0.005 and abs(taprow(5, 3) - 0.47) < 0.005
+    # the layers that stay on the band form: 4 couts (36 rows do not fit 32), 12 couts, channel counts that are no multiple of 16
+    assert not CN.small_has_tapout(9, 64, 4) and not CN.small_has_tapout(5, 32, 12) and not CN.small_has_tapout(5, 7, 1)
+    assert CN.small_has_tapout(9, 64, 3) and CN.small_has_tapout(5, 32, 3) and CN.small_has_tapout(5, 16, 1)
 
 
 def test_first_layer_switch_and_addressing(monkeypatch):

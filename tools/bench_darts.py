@@ -7,6 +7,9 @@ import torch
 from collections import OrderedDict
 from reconfigisp_amd.codes.models import create_model
 from reconfigisp_amd.codes.data.synthetic_raw import make_batch
+if os.environ.get('RISP_BENCH_NO_TAPOUT') == '1':          # A/B on one box: the 3-cout layers on the Toeplitz-band kernel of round 4
+    import reconfigisp_amd.convnets as CN
+    CN.small_has_tapout = lambda *a: False
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
