@@ -528,10 +528,16 @@ def route(k, cin, cout, h, w, transpose=False, load=LOAD_PLAIN, epi=0, add_c=0, 
 
 
 def _have(pc, transpose):
-    """the packs of a layer that ``route`` may pick from, for this direction"""
-    sfx = '_bwd' if transpose else '_fwd'
-    have = [name for name in ('wino43', 'wino45', 'f16x2') if getattr(pc, name + sfx, None) is not None]
-    have += [name for name in ('k3', 'toep_first') if getattr(pc, name, None) is not None]
+    """the packs of a layer that ``route`` may pick from, for this direction (kept on the pack object: a layer's packs do not change)"""
+    memo = pc.__dict__.get('_have_memo')
+    if memo is None:
+        memo = pc.__dict__['_have_memo'] = {}
+    have = memo.get(transpose)
+    if have is None:
+        sfx = '_bwd' if transpose else '_fwd'
+        have = [name for name in ('wino43', 'wino45', 'f16x2') if getattr(pc, name + sfx, None) is not None]
+        have += [name for name in ('k3', 'toep_first') if getattr(pc, name, None) is not None]
+        memo[transpose] = have
     return have
 
 
@@ -626,11 +632,20 @@ class PackCache:
     """Re-pack a module's conv weights only when a parameter changed (version counter / storage)."""
 
     def __init__(self):
-        self._key, self._packs = None, None
+        self._key, self._packs, self._params, self._age = None, None, None, 0
 
     def get(self, module, build):
-        key = tuple((p.data_ptr(), p._version) for p in module.parameters())      # (a device move changes data_ptr)
+        # the module tree is walked once and then every 64th call (module.parameters() recurses through named_modules: 35 us for a
+        # Path-Restore proxy, 150 times per search iteration - a quarter of the host time of the reference's shipped 48 x 48 geometry);
+        # in between the SAME Parameter objects are watched: in-place updates (optimizer steps, load_state_dict, .to()) move their
+        # version counter or storage
+        self._age -= 1
+        if self._params is None or self._age < 0:
+            self._params, self._age = list(module.parameters()), 64
+        key = tuple((p.data_ptr(), p._version) for p in self._params)              # (a device move changes data_ptr)
         if key != self._key:
+            self._params = list(module.parameters())
+            key = tuple((p.data_ptr(), p._version) for p in self._params)
             self._packs, self._key = build(), key
         return self._packs
 

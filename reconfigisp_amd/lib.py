@@ -212,17 +212,20 @@ def load():
     return lib
 
 
+_FN = {}                # entry points by name (one attribute lookup on the CDLL per name, not per call)
 CALLS = None            # diagnostics (bench.py, tools/): set to {} to count the C-ABI calls by entry point
 
 
 def call(name, *args):
     """Invoke an int-returning entry point; raise RuntimeError with risp_last_error() on failure."""
-    lib = load()
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
     if CALLS is not None:
         CALLS[name] = CALLS.get(name, 0) + 1
-    status = getattr(lib, name)(*args)
+    status = fn(*args)
     if status != 0:
-        raise RuntimeError('%s failed (%d): %s' % (name, status, lib.risp_last_error().decode()))
+        raise RuntimeError('%s failed (%d): %s' % (name, status, load().risp_last_error().decode()))
 
 
 def ptr_array(ptrs):

@@ -425,10 +425,13 @@ def gold_darts_kf5():
     """``darts_step_kf5`` (+ ``_f64``): gold_darts_kf's criterion on the FIVE-slot super-net (n_step 3: the slot count of the shipped search,
     options/train/SID_search.yml:31-32) at batch 2, 16 x 16 - the per-tensor pin of the 5-slot step logic and of every operator's
     gradient, which the shipped geometry itself (darts_step_n3: 48 x 48, no tie-free seed) can only be held to slot by slot."""
-    gold_darts_kf(n_step=3, name='darts_step_kf5', seeds=range(500, 900, 4))
+    # (over data seeds 500 .. 896 no scenario of this size agrees to 1e-5 in all four arithmetics; seed 844 is the closest: float64 9.0e-6,
+    # torch-native convolutions 2.4e-5, one thread 8.8e-6 - a quarter of the 1e-4 bar it is there to hold.  RISP_GOLD_KF5_SEED=0: search again)
+    forced = int(os.environ.get('RISP_GOLD_KF5_SEED', '844'))
+    gold_darts_kf(n_step=3, name='darts_step_kf5', seeds=[forced] if forced else range(500, 900, 4), agree=3e-5)
 
 
-def gold_darts_kf(n_step=2, name='darts_step_kf', seeds=range(100, 400, 4)):
+def gold_darts_kf(n_step=2, name='darts_step_kf', seeds=range(100, 400, 4), agree=1e-5):
     """``darts_step_kf`` (+ ``_f64``): gold_darts' scenario (n_step 2, batch 2, 16 x 16) on the first data seed for which the reference
     ITSELF is insensitive to its arithmetic - fp32 with oneDNN convolutions, fp32 with torch's native convolutions, fp32 on one thread
     (different summation splits) and float64 all agree to 1e-5 of every recorded tensor's magnitude over both iterations.  Why: a ReLU
@@ -442,14 +445,14 @@ def gold_darts_kf(n_step=2, name='darts_step_kf', seeds=range(100, 400, 4)):
         base = _darts_scenario(n_step, 2, 16, seed, margins=margins)
         d64 = _darts_scenario(n_step, 2, 16, seed, double=True)
         worst = [_scenario_distance(base, d64)]
-        if worst[0][0] <= 1e-5:
+        if worst[0][0] <= agree:
             with torch.backends.mkldnn.flags(enabled=False):
                 worst.append(_scenario_distance(_darts_scenario(n_step, 2, 16, seed), base))
             torch.set_num_threads(1)
             worst.append(_scenario_distance(_darts_scenario(n_step, 2, 16, seed), base))
             torch.set_num_threads(4)
         print('  seed %d: %s' % (seed, ', '.join('%.1e (%s)' % w for w in worst)))
-        if len(worst) == 3 and max(w[0] for w in worst) <= 1e-5:
+        if len(worst) == 3 and max(w[0] for w in worst) <= agree:
             break
     else:
         raise RuntimeError('no arithmetic-insensitive DARTS scenario found')
@@ -808,6 +811,6 @@ def gold_options():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['pointwise', 'conditional', 'cnn', 'supernet', 'fixed', 'darts', 'tiling', 'isp_model', 'plugin_calls',
-                             'f64', 'losses', 'options', 'darts_kf', 'darts_n3']
+                             'f64', 'losses', 'options', 'darts_kf', 'darts_n3', 'darts_kf5']
     for w in which:
         globals()['gold_' + w]()

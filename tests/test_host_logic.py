@@ -162,7 +162,10 @@ def seed_darts(model):
 # 0.2), where the reference's own fp32 run is 0.9e-4 from its float64 run (no tie-free seed exists at that size: ref_rtol adds the
 # golden's own distance); 'darts_step' - the round-1 scenario, which holds one first-layer pre-activation at 3.6e-9 of its layer: kept
 # as the regression of the fp32 first-layer route (RISP_CONV_TOEP_FIRST=0), whose rounding happens to take the reference's side of it.
-DARTS_FIXTURES = [('darts_step_kf', 2, None), ('darts_step_n3', 3, None), ('darts_step', 2, '0')]
+# 'darts_step_kf5' (round 6): the FIVE-slot super-net (n_step 3, the slot count of the shipped search) at batch 2, 16 x 16, on the data seed
+# where the reference's four arithmetics agree best (2.4e-5): every operator's gradient and state TENSOR BY TENSOR at the 1e-4 bar -
+# the per-operator pin that the shipped 48 x 48 geometry ('darts_step_n3': judged slot by slot against float64) cannot give.
+DARTS_FIXTURES = [('darts_step_kf', 2, None), ('darts_step_kf5', 3, None), ('darts_step_n3', 3, None), ('darts_step', 2, '0')]
 
 
 @pytest.mark.filterwarnings('ignore:Detected call of')

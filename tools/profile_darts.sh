@@ -1,16 +1,16 @@
 #!/bin/bash
 # GPU box: kernel statistics of the DARTS search step at a given batch (one stream, so that per-launch durations can
-# be attributed).  usage: tools/profile_darts.sh <tag> <batch> <n_step> <iters>   -> gpurun_out/darts_<tag>/summary.txt
+# be attributed).  usage: tools/profile_darts.sh <tag> <batch> <n_step> <iters> [size]   -> gpurun_out/darts_<tag>/summary.txt
 set -u
-TAG=${1:-r03}; BATCH=${2:-32}; NSTEP=${3:-2}; ITERS=${4:-3}
+TAG=${1:-r03}; BATCH=${2:-32}; NSTEP=${3:-2}; ITERS=${4:-3}; SIZE=${5:-256}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/darts_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-python3 "$REPO/tools/bench_darts.py" $BATCH 256 $NSTEP $ITERS 2>&1 | tail -1 > "$OUT/two_streams.log"
+python3 "$REPO/tools/bench_darts.py" $BATCH $SIZE $NSTEP $ITERS 2>&1 | tail -1 > "$OUT/two_streams.log"
 export RISP_SLOT_STREAMS=1
-python3 "$REPO/tools/bench_darts.py" $BATCH 256 $NSTEP $ITERS 2>&1 | tail -1 > "$OUT/one_stream.log"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o d -- python3 "$REPO/tools/bench_darts.py" $BATCH 256 $NSTEP $ITERS > "$OUT/prof.log" 2>&1
+python3 "$REPO/tools/bench_darts.py" $BATCH $SIZE $NSTEP $ITERS 2>&1 | tail -1 > "$OUT/one_stream.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o d -- python3 "$REPO/tools/bench_darts.py" $BATCH $SIZE $NSTEP $ITERS > "$OUT/prof.log" 2>&1
 python3 - "$OUT" $ITERS <<'PY'
 import csv, glob, os, sys
 root, iters = sys.argv[1], int(sys.argv[2]) + 1
