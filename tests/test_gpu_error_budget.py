@@ -14,7 +14,7 @@ import torch
 
 import isp_oracle as O
 from conftest import ErrorBudget, load_golden
-from test_host_logic import DARTS_FIXTURES, T, build_supernet, darts_opt, isp_opt, seed_darts, seed_ops
+from test_host_logic import DARTS_FIXTURES, KF_ITERS, T, build_supernet, darts_opt, isp_opt, seed_darts, seed_ops
 
 pytestmark = pytest.mark.gpu
 
@@ -83,7 +83,7 @@ def _darts_iterations(fixture, n_step, per_slot, outliers=None):
     data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
     prev = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}         # the constructor's state, identical in all three runs
     prev32, prev64 = {k: v.cpu().numpy() for k, v in prev.items()}, {k: v.double().cpu().numpy() for k, v in prev.items()}
-    for it in range(2):
+    for it in range(KF_ITERS.get(fixture, 2)):
         model.feed_data(data)
         model.update_learning_rate(it, warmup_iter=-1)
         model.optimize_alphas()

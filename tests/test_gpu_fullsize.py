@@ -143,3 +143,56 @@ def test_tiled_full_frame_4000x3000_path_restore(capsys):
     _, mids = model.test()
     for a, b_, k in zip(mids, rmids, names):
         assert_close(a, b_, floor=1.0, what='tile 31 stage ' + k)
+
+
+def _stages_within_budget(net, bay, arch, wts, what):
+    """every stage of an inference forward against the oracle in float64, each started from the GPU's previous stage output:
+    |hip - fp64| <= min(2 x |oracle32 - fp64|, 1e-4) + 4e-6 of the stage's magnitude (conftest.ErrorBudget)"""
+    from conftest import ErrorBudget
+    budget = ErrorBudget()
+    names = O.parse_architecture(arch)
+    n = bay.shape[0]
+    with torch.no_grad():
+        net(bay.cuda())
+    x = bay
+    dbl = lambda w: {k: v.double() for k, v in w.items()} if w is not None else None
+    for k, (name, got) in enumerate(zip(names, net.intermediate_results)):
+        par = None if not O.PARAM_INIT[name] else torch.sigmoid(torch.tensor(O.PARAM_INIT[name])).repeat(n, 1)
+        ref32 = O.apply_op(name, x, par, wts[k])
+        ref64 = O.apply_op(name, x.double(), None if par is None else par.double(), dbl(wts[k]))
+        budget(got, ref32, ref64, '%s stage %s' % (what, name))
+        x = got.detach().cpu()
+    budget.finish()
+
+
+@pytest.mark.parametrize('arith', ['f16x2', 'f32'])
+def test_config5_tile_and_reference_yaml_image_within_the_float64_budget_at_their_real_sizes(arith, monkeypatch):
+    """The CNN pipelines at the sizes they are quoted at, held to the float64 error budget instead of a norm-wise floor: tile 31 of
+    BASELINE config 5 (512 x 512 through Bayer_01_Demosaic_02_sRGB_13: Path-Restore-Bayer -> proxy demosaic -> WbQuadratic) and one
+    256 x 256 image of the reference's own 5-stage YAML (options/train/SID_isp.yml:28, Bayer_01_Demosaic_03_sRGB_01_13_11), on both
+    arithmetics of the wide layers."""
+    from test_host_logic import seed_ops
+    from reconfigisp_amd import convnets as CN
+    from reconfigisp_amd.codes.utils.util_path_restore import tile_grid
+    monkeypatch.setattr(CN, 'CONV_ARITH', arith)
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    # config 5, interior tile 31 of the 4000 x 3000 frame
+    arch = 'Bayer_01_Demosaic_02_sRGB_13'
+    model = _frame_model(arch)
+    seed_ops(model.netG.all_modules, model.netG.step_names, 600)
+    model.netG.cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    frame = torch.randint(0, 1024, (1, 1, 3000, 4000), generator=g).float() / 1023.
+    ty, tx = (int(v) for v in tile_grid(3000, 4000, (512, 512), (480, 480))[31])
+    tile = frame[:, :, ty:ty + 512, tx:tx + 512].contiguous()
+    _stages_within_budget(model.netG, tile, arch, [O.make_weights('path14l_bayer', 600), O.make_weights('srcnn_demosaic', 601), None], 'config 5 tile 31')
+    # pipeline 2b, one 256 x 256 image of the bench's synthetic RAW
+    arch = 'Bayer_01_Demosaic_03_sRGB_01_13_11'
+    from reconfigisp_amd.codes.models import networks
+    net = networks.define_G({'network_G': {'which_model_G': 'IspUniversal', 'architecture': arch, 'module_path': None,
+                                           'individual_module_paths': [None] * 8}})
+    seed_ops(net.all_modules, net.step_names, 500)
+    net = net.cuda().eval()
+    bay, _ = O.synthetic_raw(1, 256, 256, seed=4)
+    _stages_within_budget(net, bay, arch, [O.make_weights('path14l_bayer', 500), O.make_weights('srcnn_demosaic', 501), None, None, None], 'SID_isp.yml 256 x 256')
+

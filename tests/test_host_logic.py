@@ -164,7 +164,11 @@ def seed_darts(model):
 # as the regression of the fp32 first-layer route (RISP_CONV_TOEP_FIRST=0), whose rounding happens to take the reference's side of it.
 # 'darts_step_kf5' (round 6): the FIVE-slot super-net (n_step 3, the slot count of the shipped search) at batch 2, 16 x 16, on the data seed
 # where the reference's four arithmetics agree best (2.4e-5): every operator's gradient and state TENSOR BY TENSOR at the 1e-4 bar -
-# the per-operator pin that the shipped 48 x 48 geometry ('darts_step_n3': judged slot by slot against float64) cannot give.
+# the per-operator pin that the shipped 48 x 48 geometry ('darts_step_n3': judged slot by slot against float64) cannot give.  Judged
+# on its FIRST iteration only (KF_ITERS): the second one is not tie-free for arithmetics outside the four it was selected on - the
+# reference's own torch on another CPU (the GPU box's EPYC) moves it1_alpha_step1 by 3.3e-4, this build's kernels move all twelve
+# operator gradients of slot step1 together by 1e-4 .. 4e-4 (one mask bit downstream of the slot).
+KF_ITERS = {'darts_step_kf5': 1}
 DARTS_FIXTURES = [('darts_step_kf', 2, None), ('darts_step_kf5', 3, None), ('darts_step_n3', 3, None), ('darts_step', 2, '0')]
 
 
@@ -184,7 +188,7 @@ def test_darts_search_step_matches_reference(dev, fixture, n_step, toep_first, m
     model = create_model(darts_opt(dev, n_step))
     seed_darts(model)
     data = tuple(T(g[k]) for k in ('img', 'gt', 'val_img', 'val_gt'))
-    for it in range(2):
+    for it in range(KF_ITERS.get(fixture, 2)):
         model.feed_data(data)
         model.update_learning_rate(it, warmup_iter=-1)
         model.optimize_alphas()
