@@ -41,14 +41,22 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float *__restr
     const int plane = blockIdx.y;
     const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)plane * hw4;
     MinMax a = {INFINITY, -INFINITY, 0.f, 0x7fffffff, 0x7fffffff};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
-        float4 v = xb[i];
-        mm_take(a, v.x, 4 * i);
-        mm_take(a, v.y, 4 * i + 1);
-        mm_take(a, v.z, 4 * i + 2);
-        mm_take(a, v.w, 4 * i + 3);
+    // four vectors of a thread are requested together (one load per trip left 1 KB per wave in flight: 0.44 of the HBM rate at
+    // 64 x 3 planes of 256 x 256); same elements in the same order per thread: the same bits
+    const int step = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    auto take4 = [&](const float4 &v, int j) {
+        mm_take(a, v.x, 4 * j);
+        mm_take(a, v.y, 4 * j + 1);
+        mm_take(a, v.z, 4 * j + 2);
+        mm_take(a, v.w, 4 * j + 3);
         a.sum += (v.x + v.y) + (v.z + v.w);
+    };
+    for (; i + 3 * step < hw4; i += 4 * step) {
+        const float4 v0 = xb[i], v1 = xb[i + step], v2 = xb[i + 2 * step], v3 = xb[i + 3 * step];
+        take4(v0, i); take4(v1, i + step); take4(v2, i + 2 * step); take4(v3, i + 3 * step);
     }
+    for (; i < hw4; i += step) take4(xb[i], i);
     mm_wave(a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {

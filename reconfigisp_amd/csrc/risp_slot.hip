@@ -218,6 +218,15 @@ static_assert(SO_G3 + 3 == RISP_SLOT_ROW, "row layout");
 // SIMD, 0.34 of the HBM rate); 2 = with it, input gradient only - the 30 sums come from slot_wbq_params_kernel, which reads x and
 // gy once more (24 of ~250 B/pixel) at five waves per SIMD.  Same operations in the same order per thread and the same block
 // partition: the same bits.
+#ifndef RISP_SLOT_NT
+#define RISP_SLOT_NT 0
+#endif
+#if RISP_SLOT_NT
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define SLOT_ST(p, v) do { const float4 v_ = (v); __builtin_nontemporal_store(f32x4_t{v_.x, v_.y, v_.z, v_.w}, reinterpret_cast<f32x4_t *>(p)); } while (0)
+#else
+#define SLOT_ST(p, v) (*(p) = (v))
+#endif
 template <int WBQ>
 __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_desc d, const float *__restrict__ gy,
                                                            float *__restrict__ gx, float *__restrict__ part, int hw4) {
@@ -250,21 +259,36 @@ __global__ __launch_bounds__(256) void slot_mix_bwd_kernel(const risp_slot_mix_d
     for (int q = 0; q <= RISP_OP_GAIN3; ++q) dotk[q] = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += gridDim.x * blockDim.x) {
         const float4 db = gb[i], dg = gb[hw4 + i], dr = gb[2 * hw4 + i];
-        // ---- tensor operands: architecture term, and their gradient w_k gy
+        // ---- tensor operands: architecture term, and their gradient w_k gy.  (SLOT_TG > 1: the loads of that many operands issued together -
+        // measured 2, 3, 4: 252 us each against 251-255: the launch is not short of bytes in flight; NT stores: 264)
+#ifndef SLOT_TG
+#define SLOT_TG 1
+#endif
 #pragma unroll
-        for (int k = 0; k < RISP_MAX_MIX; ++k) {
-            if (k < d.K && d.kind[k] == RISP_SLOT_TENSOR) {
-                const float w = d.w[k];
-                const float4 *tb = reinterpret_cast<const float4 *>(d.ptr[k]) + base;
-                const float4 vb = tb[i], vg = tb[hw4 + i], vr = tb[2 * hw4 + i];
-                acc[k] += ((db.x * vb.x + db.y * vb.y) + (db.z * vb.z + db.w * vb.w)) +
-                          ((dg.x * vg.x + dg.y * vg.y) + (dg.z * vg.z + dg.w * vg.w)) +
-                          ((dr.x * vr.x + dr.y * vr.y) + (dr.z * vr.z + dr.w * vr.w));
-                if (d.go[k]) {
-                    float4 *gk = reinterpret_cast<float4 *>(d.go[k]) + base;
-                    gk[i] = make_float4(db.x * w, db.y * w, db.z * w, db.w * w);
-                    gk[hw4 + i] = make_float4(dg.x * w, dg.y * w, dg.z * w, dg.w * w);
-                    gk[2 * hw4 + i] = make_float4(dr.x * w, dr.y * w, dr.z * w, dr.w * w);
+        for (int k0 = 0; k0 < RISP_MAX_MIX; k0 += SLOT_TG) {
+            float4 vb[SLOT_TG], vg[SLOT_TG], vr[SLOT_TG];
+#pragma unroll
+            for (int j = 0; j < SLOT_TG; ++j) {
+                const int k = k0 + j;
+                if (k < RISP_MAX_MIX && k < d.K && d.kind[k] == RISP_SLOT_TENSOR) {
+                    const float4 *tb = reinterpret_cast<const float4 *>(d.ptr[k]) + base;
+                    vb[j] = tb[i]; vg[j] = tb[hw4 + i]; vr[j] = tb[2 * hw4 + i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SLOT_TG; ++j) {
+                const int k = k0 + j;
+                if (k < RISP_MAX_MIX && k < d.K && d.kind[k] == RISP_SLOT_TENSOR) {
+                    const float w = d.w[k];
+                    acc[k < RISP_MAX_MIX ? k : 0] += ((db.x * vb[j].x + db.y * vb[j].y) + (db.z * vb[j].z + db.w * vb[j].w)) +
+                                                     ((dg.x * vg[j].x + dg.y * vg[j].y) + (dg.z * vg[j].z + dg.w * vg[j].w)) +
+                                                     ((dr.x * vr[j].x + dr.y * vr[j].y) + (dr.z * vr[j].z + dr.w * vr[j].w));
+                    if (d.go[k]) {
+                        float4 *gk = reinterpret_cast<float4 *>(d.go[k]) + base;
+                        SLOT_ST(gk + i, make_float4(db.x * w, db.y * w, db.z * w, db.w * w));
+                        SLOT_ST(gk + hw4 + i, make_float4(dg.x * w, dg.y * w, dg.z * w, dg.w * w));
+                        SLOT_ST(gk + 2 * hw4 + i, make_float4(dr.x * w, dr.y * w, dr.z * w, dr.w * w));
+                    }
                 }
             }
         }
@@ -515,7 +539,7 @@ int risp_slot_mix_bwd(const risp_slot_mix_desc *d, const float *gy, float *gx, f
                    "risp_slot_mix_bwd: null or unaligned argument");
     const int hw4 = d->HW / 4, bx = risp_bwd_blocks(d->N, d->HW);
 #ifndef RISP_SLOT_WBQ_ONE_PASS
-#define RISP_SLOT_WBQ_ONE_PASS 0      /* A/B switch (tools/ab_build.sh): 1 = the 30 sums inside the main backward kernel */
+#define RISP_SLOT_WBQ_ONE_PASS 1      /* 1 = the 30 sums inside the main backward kernel (round 6: 250 us against 241 + 29 in two launches); 0: A/B */
 #endif
     if (wbq && RISP_SLOT_WBQ_ONE_PASS) {
         hipLaunchKernelGGL(slot_mix_bwd_kernel<1>, dim3(bx, d->N), dim3(256), 0, (hipStream_t)stream, *d, gy, gx, scratch, hw4);

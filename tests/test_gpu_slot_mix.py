@@ -57,7 +57,12 @@ def test_fused_slot_mixture_equals_unfused(shape, with_wbq):
     for a, b in zip(g_f[2:2 + nt], g_u[2:2 + nt]):                         # w_k * gy
         assert torch.equal(a, b)
     for name, a, b in zip(live, g_f[2 + nt:], g_u[2 + nt:]):               # parameter gradients: same block partition, same order
-        assert torch.equal(a, b), name
+        if name == 'wb_quadratic':
+            # round 6: the 30 sums ride in the slot's ONE backward launch, on the partition of the other operators; the stand-alone
+            # backward keeps its own single round of workgroups (risp_bwd_blocks_wbq): the same sums cut differently
+            assert_close(a, b, rtol=1e-6, floor=1.0, what='grad wb_quadratic')
+        else:
+            assert torch.equal(a, b), name
     assert_close(g_f[0], g_u[0], rtol=1e-5, floor=1.0, what='architecture terms <gy, o_k>')      # another summation order
     assert_close(g_f[1], g_u[1], rtol=1e-5, floor=1.0, what='input gradient')                    # operands added in kind order
 
