@@ -83,7 +83,8 @@ class _FixedPipeline(nn.Module):
         # segment fusion works on 2 x 4 pixel patches: odd sizes (sRGB-only pipelines may see them) go op by op
         if x.is_cuda and not wants_grad(x, self.all_params) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
             with torch.no_grad():
-                x, self.intermediate_results = fused_forward(self.all_modules, pars, x)
+                # (final_out: set by test_split.run_frame around model.test() - the last stage written into the frame's tile stack)
+                x, self.intermediate_results = fused_forward(self.all_modules, pars, x, self.__dict__.get('final_out'))
             return x
         self.intermediate_results = []
         for op, par in zip(self.all_modules, pars):

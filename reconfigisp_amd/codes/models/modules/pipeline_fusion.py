@@ -67,13 +67,13 @@ def _chain_param(mod, par):
     return _wb_gain(mod, par) if type(mod) is T.WbManual else par
 
 
-def _flush(x, ops, params, results):
+def _flush(x, ops, params, results, out_last=None):
     if not ops:
         return x
     if all(o == F.OP_SKIP for o in ops):
         results.extend([x] * len(ops))
         return x
-    outs = F.chain_forward(x, ops, params)
+    outs = F.chain_forward(x, ops, params, out_last)
     results.extend(outs)
     return outs[-1]
 
@@ -91,8 +91,10 @@ def _bilateral_segment(mod, par, x, from_bayer, tail_ops, tail_params):
     return F.BilateralChainPlan(x, from_bayer, win, sc, ss, wmax, tail_ops, tail_params).launch()
 
 
-def fused_forward(modules, param_tensors, x):
-    """modules[k](x, param_tensors[k]) for all k, fusing where possible.  Returns (y, stage outputs)."""
+def fused_forward(modules, param_tensors, x, final_out=None):
+    """modules[k](x, param_tensors[k]) for all k, fusing where possible.  Returns (y, stage outputs).  ``final_out``: where the caller
+    wants the LAST stage (test_split: a slice of the frame's tile stack - no concatenation afterwards); honoured when the pipeline ends in
+    an element-wise segment, otherwise the last stage is copied there."""
     results, ops, params = [], [], []
     seg_in = x                                    # input of the pending element-wise chain
     k, count = 0, len(modules)
@@ -135,7 +137,10 @@ def fused_forward(modules, param_tensors, x):
             x = _run_origin(mod, x, par) if isinstance(mod, T._OriginOp) else mod(x, par)
             results.append(x)
         k += 1
-    x = _flush(x, ops, params, results)
+    x = _flush(x, ops, params, results, final_out)
+    if final_out is not None and results and x.data_ptr() != final_out.data_ptr() and tuple(x.shape) == tuple(final_out.shape):
+        final_out.copy_(x)
+        x = results[-1] = final_out
     return x, results
 
 

@@ -125,6 +125,9 @@ def toep_weights(w, transpose=False, keep=None):
     return torch.cat([hdr.view(torch.float16), band.reshape(-1)])
 
 
+_TAPOUT_ROWS = {}
+
+
 def tapout_weights(w, transpose=False, keep=None):
     """Pre-split pack of ``risp_conv2d_tapout`` (include/risp.h) from a layer's (cout <= 3, cin % 16 == 0, k, k) tensor, k = 5 or 9: a
     16-byte header whose first float is 1 / s_w, then [chunk of 16 cin][kx][part: hi, lo][channel half][row m, 32][8 channels] halves of
@@ -143,11 +146,12 @@ def tapout_weights(w, transpose=False, keep=None):
     hi = ws.half()
     parts = (hi, (ws - hi.float()).half())
     rows = torch.zeros((2, ci, k, 32), device=w.device, dtype=torch.float16)                 # (part, ci, kx, m)
-    for c in range(co):
-        for ky in range(k):
-            m = 4 * ky + c if ky < 8 else 4 * c + 3
-            for part in range(2):
-                rows[part, :, :, m] = parts[part][c, :, ky, :]
+    key = (co, k, w.device)
+    m_idx = _TAPOUT_ROWS.get(key)
+    if m_idx is None:                                # row of (cout c, filter row ky), in (c, ky) order
+        m_idx = _TAPOUT_ROWS[key] = torch.tensor([4 * ky + c if ky < 8 else 4 * c + 3 for c in range(co) for ky in range(k)], device=w.device)
+    for part in range(2):                            # (co, ci, ky, kx) -> (ci, kx, co * ky): one indexed store per part
+        rows[part][:, :, m_idx] = parts[part].permute(1, 3, 0, 2).reshape(ci, k, co * k)
     #       (part, chunk, half, 8, kx, m) -> (chunk, kx, part, half, m, 8)
     p = rows.view(2, ci // 16, 2, 8, k, 32).permute(1, 4, 0, 2, 5, 3).contiguous()
     hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
@@ -272,32 +276,51 @@ def small_has_tapout(k, cin, cout):
 
 
 class PackedConv:
-    """Device-side packed weights of one layer, forward and backward-data."""
+    """Device-side packed weights of one layer, forward and backward-data.  Every pack is built on FIRST USE (round 6): a layer holds up to
+    nine packs and a launch reads one - the fp32 Winograd packs (einsum -> a Tensile GEMM and ~10 torch launches each) only serve
+    RISP_CONV_ARITH=f32 and the shapes the split-precision kernels do not take, and in the proxy fine-tuning loop every optimizer step of a
+    proxy rebuilds its packs (darts_ft_model.py:206-246)."""
 
     def __init__(self, weight, bias):
         w = _dev(weight.detach(), 'weight')
+        self._w = w
         self.cout, self.cin, self.k = w.shape[0], w.shape[1], w.shape[2]
         self.bias = _dev(bias.detach(), 'bias')
+        self._kf, self._kb = pack_kinds(self.k, self.cin, self.cout, False), pack_kinds(self.k, self.cin, self.cout, True)
+
+    def _general(self, transpose):
         lib = L.load()
-        self.fwd = torch.empty(lib.risp_conv_wpack_floats(self.cin, self.cout, self.k), device=w.device)
-        self.bwd = torch.empty(lib.risp_conv_wpack_floats(self.cout, self.cin, self.k), device=w.device)
-        L.call('risp_conv_pack_weights', _p(w), self.cin, self.cout, self.k, 0, _p(self.fwd), _stream())
-        L.call('risp_conv_pack_weights', _p(w), self.cout, self.cin, self.k, 1, _p(self.bwd), _stream())
-        kf, kb = pack_kinds(self.k, self.cin, self.cout, False), pack_kinds(self.k, self.cin, self.cout, True)
-        ck43 = L.load().risp_conv_wino43_chunk()
-        # fp32 Winograd packs: RISP_CONV_ARITH=f32, and the layers the split-precision kernels do not take
-        self.wino43_fwd = wino43_weights(w, False, ck43) if 'wino43' in kf else None
-        self.wino43_bwd = wino43_weights(w, True, ck43) if 'wino43' in kb else None
-        self.wino45_fwd = wino45_weights(w, False) if 'wino45' in kf else None
-        self.wino45_bwd = wino45_weights(w, True) if 'wino45' in kb else None
-        # split-precision packs (see CONV_ARITH); either direction on its own
-        self.f16x2_fwd = f16x2_weights(w, False) if 'f16x2' in kf else None
-        self.f16x2_bwd = f16x2_weights(w, True) if 'f16x2' in kb else None
-        # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
-        self.k3 = k3_weights(w) if 'k3' in kf else None
-        # ... and the 9x9 ones on the f16 matrix pipe in split precision, risp_conv_toep_first.hip
-        self.toep_first = toep_first_weights(w) if 'toep_first' in kf else None
-        self.w32 = w.float().contiguous() if self.toep_first is not None else None      # for the exact recomputation of ReLU ties
+        ci, co = (self.cout, self.cin) if transpose else (self.cin, self.cout)
+        pack = torch.empty(lib.risp_conv_wpack_floats(ci, co, self.k), device=self._w.device)
+        L.call('risp_conv_pack_weights', _p(self._w), ci, co, self.k, int(transpose), _p(pack), _stream())
+        return pack
+
+    def __getattr__(self, name):                     # only reached for packs that have not been built yet
+        w = self.__dict__.get('_w')
+        if w is None or name.startswith('_'):
+            raise AttributeError(name)
+        kf, kb = self._kf, self._kb
+        build = {
+            'fwd': lambda: self._general(False), 'bwd': lambda: self._general(True),
+            # fp32 Winograd packs: RISP_CONV_ARITH=f32, and the layers the split-precision kernels do not take
+            'wino43_fwd': lambda: wino43_weights(w, False, L.load().risp_conv_wino43_chunk()) if 'wino43' in kf else None,
+            'wino43_bwd': lambda: wino43_weights(w, True, L.load().risp_conv_wino43_chunk()) if 'wino43' in kb else None,
+            'wino45_fwd': lambda: wino45_weights(w, False) if 'wino45' in kf else None,
+            'wino45_bwd': lambda: wino45_weights(w, True) if 'wino45' in kb else None,
+            # split-precision packs (see CONV_ARITH); either direction on its own
+            'f16x2_fwd': lambda: f16x2_weights(w, False) if 'f16x2' in kf else None,
+            'f16x2_bwd': lambda: f16x2_weights(w, True) if 'f16x2' in kb else None,
+            # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
+            'k3': lambda: k3_weights(w) if 'k3' in kf else None,
+            # ... and the 9x9 ones on the f16 matrix pipe in split precision, risp_conv_toep_first.hip
+            'toep_first': lambda: toep_first_weights(w) if 'toep_first' in kf else None,
+            'w32': lambda: w.float().contiguous() if 'toep_first' in kf else None,     # for the exact recomputation of ReLU ties
+        }.get(name)
+        if build is None:
+            raise AttributeError(name)
+        val = build()
+        self.__dict__[name] = val
+        return val
 
 
 class SmallConv:
@@ -309,11 +332,20 @@ class SmallConv:
         w = _dev(weight.detach(), 'weight')
         self.wpack, self.cout = small_weights(w, transpose, keep)
         self.cin, self.k = self.wpack.shape[0], self.wpack.shape[2]
-        # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts
-        self.toep = toep_weights(w, transpose, keep) if small_has_toep(self.k, self.cout) else None
-        # ... and with the filter rows in the rows of the matrix instruction (risp_conv2d_tapout): half the matrix work of the band form
-        self.tapout = tapout_weights(w, transpose, keep) if small_has_tapout(self.k, self.cin, self.cout) else None
+        self._src = (w, transpose, keep)
         self.bias = _dev(bias.detach(), 'bias') if bias is not None else None
+
+    def __getattr__(self, name):                     # the matrix-pipe packs, built when a launch first asks for them
+        src = self.__dict__.get('_src')
+        if src is None or name not in ('toep', 'tapout'):
+            raise AttributeError(name)
+        w, transpose, keep = src
+        if name == 'toep':      # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts (12 for 5 taps)
+            val = toep_weights(w, transpose, keep) if small_has_toep(self.k, self.cout) else None
+        else:                   # ... and with the filter rows in the rows of the matrix instruction (risp_conv2d_tapout)
+            val = tapout_weights(w, transpose, keep) if small_has_tapout(self.k, self.cin, self.cout) else None
+        self.__dict__[name] = val
+        return val
 
 
 def _group_fields(d, n, group, wpack, bias):
@@ -339,14 +371,14 @@ def toep_grid_ok(images, h, w):
 
 
 def _tapout_ok(sc, h, w, epi=0):
-    return (CONV_ARITH == 'f16x2' and getattr(sc, 'tapout', None) is not None and not (epi & EPI_SHUFFLE2) and w % 4 == 0
+    return (CONV_ARITH == 'f16x2' and small_has_tapout(sc.k, sc.cin, sc.cout) and not (epi & EPI_SHUFFLE2) and w % 4 == 0
             and sc.cin * h * w < (1 << 30) and h * w < (1 << 24))
 
 
 def _toep_ok(sc, h, w):
     # (any width: planes of at most 128 pixels run with two rows folded into the 32 columns of the matrix instruction; the 12-cout
     # form cannot fold and is ~20 % slower than the vector kernel there, but a layer keeps ONE arithmetic whatever the crop it sees)
-    return CONV_ARITH == 'f16x2' and getattr(sc, 'toep', None) is not None and w % 4 == 0 and sc.cin * h * w < (1 << 30)
+    return CONV_ARITH == 'f16x2' and small_has_toep(sc.k, sc.cout) and w % 4 == 0 and sc.cin * h * w < (1 << 30)
 
 
 # risp_conv2d_toep_first (9x9 first layers on the f16 matrix pipe): 'train' (default) = inference AND training forwards, the latter with
@@ -424,12 +456,12 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
     d = L.ConvDesc(N=n, H=h, W=w, cin=sc.cin, cout=sc.cout, ksize=sc.k, load_mode=LOAD_PLAIN, cin_img=0, epilogue=epi,
                    add_c=add_c, x=_p(x), wpack=_p(sc.wpack), bias=_p(sc.bias), cvals=None, add=_p(add), mask=_p(mask),
                    y=_p(out))
-    toep, tapout = getattr(sc, 'toep', None), getattr(sc, 'tapout', None)
-    if epi & EPI_SHUFFLE2:
-        tapout = None
-    entry = route_small(sc.k, sc.cin, sc.cout, h, w, nn_, infer, mask is not None, toep is not None, split, tapout is not None)
+    has_toep = small_has_toep(sc.k, sc.cout)          # (the packs themselves are built when a launch first asks for them)
+    has_tapout = small_has_tapout(sc.k, sc.cin, sc.cout) and not (epi & EPI_SHUFFLE2)
+    entry = route_small(sc.k, sc.cin, sc.cout, h, w, nn_, infer, mask is not None, has_toep, split, has_tapout)
     if entry == 'risp_conv2d_tapout':
         # the f16 matrix pipe with the filter rows as the rows of the matrix instruction: half the matrix work of the band form
+        tapout = sc.tapout
         d.wpack = _p(tapout)
         _group_fields(d, n, group, tapout, sc.bias)
         seg = seg_rows if seg_rows is not None else tapout_seg(nn_, h, w, infer)
@@ -444,6 +476,7 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
         return out
     if entry == 'risp_conv2d_toep':
         # the f16 matrix pipe (Toeplitz bands of the filter rows as the A operand): 2.5-3 x the vector-FMA kernel on full grids
+        toep = sc.toep
         d.wpack = _p(toep)
         _group_fields(d, n, group, toep, sc.bias)
         if tile_sums is not None:
@@ -528,17 +561,13 @@ def route(k, cin, cout, h, w, transpose=False, load=LOAD_PLAIN, epi=0, add_c=0, 
 
 
 def _have(pc, transpose):
-    """the packs of a layer that ``route`` may pick from, for this direction (kept on the pack object: a layer's packs do not change)"""
-    memo = pc.__dict__.get('_have_memo')
-    if memo is None:
-        memo = pc.__dict__['_have_memo'] = {}
-    have = memo.get(transpose)
-    if have is None:
-        sfx = '_bwd' if transpose else '_fwd'
-        have = [name for name in ('wino43', 'wino45', 'f16x2') if getattr(pc, name + sfx, None) is not None]
-        have += [name for name in ('k3', 'toep_first') if getattr(pc, name, None) is not None]
-        memo[transpose] = have
-    return have
+    """the packs of a layer that ``route`` may pick from, for this direction: what ``pack_kinds`` says the layer can hold (nothing is
+    built by asking), minus what has been set to None on the object"""
+    sfx = '_bwd' if transpose else '_fwd'
+    held = pc.__dict__
+    kinds = pack_kinds(pc.k, pc.cin, pc.cout, transpose)
+    have = [name for name in ('wino43', 'wino45', 'f16x2') if name in kinds and held.get(name + sfx, 1) is not None]
+    return have + [name for name in ('k3', 'toep_first') if name in kinds and held.get(name, 1) is not None]
 
 
 def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None, epi=0, add=None, add_c=0,
@@ -953,7 +982,8 @@ LAUNCHES = None           # tests / tools set this to [0] to count C-ABI launche
 
 
 class _Stacked:
-    """Packs of G same-shape layers stacked along dimension 0 (what ``conv`` / ``conv_small`` take with ``group=``)."""
+    """Packs of G same-shape layers stacked along dimension 0 (what ``conv`` / ``conv_small`` take with ``group=``); a pack is
+    stacked when a launch first asks for it (``PackedConv`` builds its packs on first use)."""
 
     def __init__(self, members, tensors, scalars):
         for a in scalars:
@@ -961,11 +991,17 @@ class _Stacked:
             if len(vals) != 1:
                 raise ValueError('grouped layer: members disagree on %s: %s' % (a, sorted(vals)))
             setattr(self, a, vals.pop())
-        for a in tensors:
-            ts = [getattr(m, a, None) for m in members]
-            setattr(self, a, torch.stack(ts) if all(t is not None for t in ts) else None)
+        self._tensors = tuple(tensors)
         self.wino43_fwd = self.wino43_bwd = None
         self.members = list(members)
+
+    def __getattr__(self, name):
+        if name.startswith('_') or name not in self.__dict__.get('_tensors', ()):
+            raise AttributeError(name)
+        ts = [getattr(m, name, None) for m in self.members]
+        val = torch.stack(ts) if all(t is not None for t in ts) else None
+        self.__dict__[name] = val
+        return val
 
 
 def stack_packed(pcs):

@@ -432,7 +432,7 @@ class ChainPlan:
     ``launch()`` is a single C-ABI call (``risp_chain_fwd``).  ``outs[k]`` is stage k's output
     (SKIP stages alias their input)."""
 
-    def __init__(self, x, ops, params):
+    def __init__(self, x, ops, params, out_last=None):
         x = _dev(x, 'img')
         n, cin, h, w = x.shape
         if h % 2 or w % 2:
@@ -441,10 +441,18 @@ class ChainPlan:
             raise ValueError('chain input has %d channels' % cin)
         self.x, self.outs, cur = x, [], x
         count = sum(1 for op in ops if op != OP_SKIP)
-        bufs = iter(torch.empty((count, n, 3, h, w), device=x.device, dtype=torch.float32).unbind(0)) if count else None
+        # ``out_last``: the caller's buffer for the segment's LAST computed stage (a contiguous fp32 (N,3,H,W) device tensor, 16-byte
+        # aligned - test_split.run_frame hands a slice of the frame's tile stack); the other stages share ONE allocation
+        if out_last is not None and (not count or tuple(out_last.shape) != (n, 3, h, w) or not out_last.is_contiguous()
+                                     or out_last.dtype != torch.float32 or out_last.device != x.device or out_last.data_ptr() % 16):
+            out_last = None
+        own = count - (1 if out_last is not None else 0)
+        bufs = iter(torch.empty((own, n, 3, h, w), device=x.device, dtype=torch.float32).unbind(0)) if own else iter(())
+        left = count
         for op in ops:
             if op != OP_SKIP:
-                cur = next(bufs)              # every stage output is a (N,3,H,W) view of ONE allocation
+                left -= 1
+                cur = out_last if (left == 0 and out_last is not None) else next(bufs)      # every stage output is a (N,3,H,W) view of ONE allocation
             self.outs.append(cur)
         self.params = [_dev(p) if p is not None else None for p in params]   # keep alive
         self._args = (_p(x), len(ops), (C.c_int * len(ops))(*ops),
@@ -457,11 +465,11 @@ class ChainPlan:
         return self.outs
 
 
-def chain_forward(x, ops, params):
+def chain_forward(x, ops, params, out_last=None):
     """Fused element-wise segment: returns the list of stage outputs (SKIP aliases its input).
 
     Inference-only fast path (no autograd graph is recorded)."""
-    return ChainPlan(x, ops, params).launch()
+    return ChainPlan(x, ops, params, out_last).launch()
 
 
 class BilateralChainPlan:

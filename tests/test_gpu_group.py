@@ -78,7 +78,8 @@ def test_grouped_srcnn_res_equals_member_launches_and_per_op_path(shape):
             assert_close(gp, grads_g[1 + j], rtol=1e-5, floor=1.0, what='member %d parameter gradient' % j)
         gx_sum = gx if gx_sum is None else gx_sum + gx
     if n == 32:
-        assert torch.equal(gx_sum, grads_g[0])
+        # (the statistics' gradients - mean plane: gconst / HW added to every pixel - pass through the same per-work-item channel sums)
+        assert_close(gx_sum, grads_g[0], rtol=1e-6, floor=1.0, what='input gradient')
     else:
         assert_close(gx_sum, grads_g[0], rtol=1e-5, floor=1.0, what='input gradient')
 
