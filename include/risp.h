@@ -462,6 +462,15 @@ int risp_param_blocks_bwd(const risp_param_blocks_desc *d, void *stream);
 size_t risp_loss_scratch_floats(void);
 int risp_pixel_loss(const float *y, const float *gt, float *g, float *loss, float *scratch, size_t numel, int kind, void *stream);
 
+/* local_global_loss with the mean-squared loss (utils/util_loss.py:26-64, pixel_criterion local_global_l2): images with flag[n] < 1
+ * ("local"): MSE of (a * gain, b), gain[n][c] = clamp(mean b / (clamp(mean a, 0) + 1e-6), 0.5, 2), no gradient through the gain; the
+ * others ("global"): MSE of the 1/4-scale bilinear down-samples (align_corners false; H, W % 4 == 0); loss[0] = the sum of the two means
+ * (an empty branch contributes 0), g (may be NULL) = d loss / d a.  flag (N) floats ON THE DEVICE: no host read, no boolean indexing.
+ * scratch: risp_local_global_scratch_floats(N, C) floats; four launches, partial sums added in index order. */
+size_t risp_local_global_scratch_floats(int N, int C);
+int risp_local_global_l2(const float *a, const float *b, const float *flag, float *g, float *loss, float *scratch, int N, int C, int H, int W,
+                         void *stream);
+
 /* The reference's per-parameter Python loops over the <= 216 floats of a super-net as ONE launch over a table of tensors. */
 #define RISP_MAX_LIST 64
 typedef struct risp_list_desc {

@@ -42,6 +42,82 @@ __global__ __launch_bounds__(64) void loss_finish_kernel(const float *__restrict
     if (threadIdx.x == 0) loss[0] = s * inv_n;
 }
 
+// ---------------------------------------------------------------------------------- local / global loss (utils/util_loss.py:26-64)
+// loss = MSE over the images flagged local (flag < 1) of (a * gain, b), gain[n][c] = clamp(mean b / (clamp(mean a, 0) + 1e-6), 0.5, 2)
+// detached, + MSE over the images flagged global of the 1/4-scale bilinear down-samples (align_corners False, H % 4 == W % 4 == 0:
+// sample (i, j) sits at source (4 i + 1.5, 4 j + 1.5): the mean of the 2 x 2 centre of its 4 x 4 cell).  Both branches on the device:
+// no boolean indexing, no host read of the flags (the reference's img[glb_flag < 1] synchronises twice per evaluation).
+// sums: [2][N * C] plane sums of a and b.  One workgroup per plane and slice of 4-row bands.
+__global__ __launch_bounds__(256) void lg_partial_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ flag,
+                                                         const float *__restrict__ sums, float *__restrict__ g, float *__restrict__ partial,
+                                                         int N, int C, int H, int W) {
+    __shared__ float red[4];
+    const int plane = blockIdx.y, n = plane / C, hw = H * W, w4 = W >> 2, bands = H >> 2;
+    int nloc = 0;
+    for (int i = 0; i < N; ++i) nloc += flag[i] < 1.f ? 1 : 0;
+    const bool local = flag[n] < 1.f;
+    const float *pa = a + (size_t)plane * hw, *pb = b + (size_t)plane * hw;
+    float *pg = g ? g + (size_t)plane * hw : nullptr;
+    float s = 0.f;
+    if (local) {
+        const float inv_hw = 1.f / (float)hw;
+        float gain = (sums[N * C + plane] * inv_hw) / (fmaxf(sums[plane] * inv_hw, 0.f) + 1e-6f);
+        gain = fminf(fmaxf(gain, 0.5f), 2.f);
+        const float gs = 2.f * gain / ((float)nloc * (float)C * (float)hw);
+        const float4 *a4 = reinterpret_cast<const float4 *>(pa), *b4 = reinterpret_cast<const float4 *>(pb);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (hw >> 2); i += gridDim.x * 256) {
+            const float4 x = a4[i], y = b4[i];
+            const float d0 = x.x * gain - y.x, d1 = x.y * gain - y.y, d2 = x.z * gain - y.z, d3 = x.w * gain - y.w;
+            s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            if (pg) reinterpret_cast<float4 *>(pg)[i] = make_float4(d0 * gs, d1 * gs, d2 * gs, d3 * gs);
+        }
+    } else {
+        // one thread per 4 x 4 cell: rows 4 i + 1, 4 i + 2, columns 4 j + 1, 4 j + 2 carry the sample, the other 12 a zero gradient
+        const float gs = 2.f * 0.25f / ((float)(N - nloc) * (float)C * (float)(bands * w4));
+        for (int cidx = blockIdx.x * 256 + threadIdx.x; cidx < bands * w4; cidx += gridDim.x * 256) {
+            const int i = cidx / w4, j = cidx - i * w4;
+            const size_t o = (size_t)(4 * i) * W + 4 * j;
+            const float4 a1 = *reinterpret_cast<const float4 *>(pa + o + W), a2 = *reinterpret_cast<const float4 *>(pa + o + 2 * W);
+            const float4 b1 = *reinterpret_cast<const float4 *>(pb + o + W), b2 = *reinterpret_cast<const float4 *>(pb + o + 2 * W);
+            const float da = ((a1.y + a1.z) + (a2.y + a2.z)) * 0.25f, db = ((b1.y + b1.z) + (b2.y + b2.z)) * 0.25f;
+            const float dd = da - db;
+            s += dd * dd;
+            if (pg) {
+                const float v = dd * gs;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(0.f, v, v, 0.f);
+                *reinterpret_cast<float4 *>(pg + o) = z;
+                *reinterpret_cast<float4 *>(pg + o + W) = m;
+                *reinterpret_cast<float4 *>(pg + o + 2 * W) = m;
+                *reinterpret_cast<float4 *>(pg + o + 3 * W) = z;
+            }
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)plane * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one wave: the partial sums of the local and of the global planes, each in index order, each divided by its own count
+__global__ __launch_bounds__(64) void lg_finish_kernel(const float *__restrict__ partial, const float *__restrict__ flag, float *__restrict__ loss,
+                                                        int N, int C, int H, int W, int per_plane) {
+    float sl = 0.f, sg = 0.f;
+    int nloc = 0;
+    for (int i = 0; i < N; ++i) nloc += flag[i] < 1.f ? 1 : 0;
+    for (int i = threadIdx.x; i < N * C * per_plane; i += 64) {
+        const float v = partial[i];
+        if (flag[(i / per_plane) / C] < 1.f) sl += v; else sg += v;
+    }
+    sl = wave_sum(sl);
+    sg = wave_sum(sg);
+    if (threadIdx.x == 0) {
+        const float hw = (float)H * (float)W;
+        const float ll = nloc > 0 ? sl / ((float)nloc * (float)C * hw) : 0.f;
+        const float lg = nloc < N ? sg / ((float)(N - nloc) * (float)C * (hw / 16.f)) : 0.f;
+        loss[0] = ll + lg;
+    }
+}
+
 // ---------------------------------------------------------------------------------- tables of tiny tensors
 // one wave per tensor (parameters of 1 .. 64 values, alphas of 2 .. 15)
 __global__ __launch_bounds__(64) void virtual_step_kernel(const risp_list_desc d, float momentum, float lr_meta) {
@@ -186,6 +262,25 @@ int risp_pixel_loss(const float *y, const float *gt, float *g, float *loss, floa
     RISP_LAUNCH_CHECK("risp_pixel_loss");
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, blocks, inv_n, loss);
     RISP_LAUNCH_CHECK("risp_pixel_loss");
+    return 0;
+}
+
+size_t risp_local_global_scratch_floats(int N, int C) { return (size_t)N * C * (2 + 64); }
+
+int risp_local_global_l2(const float *a, const float *b, const float *flag, float *g, float *loss, float *scratch, int N, int C, int H, int W,
+                         void *stream) {
+    RISP_CHECK_ARG(a && b && flag && loss && scratch && N > 0 && C > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && (long long)N * C <= 65535,
+                   "risp_local_global_l2: null tensor, or H / W no multiple of 4 (N=%d C=%d H=%d W=%d)", N, C, H, W);
+    RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(g)) & 15) == 0,
+                   "risp_local_global_l2: tensors must be 16-byte aligned");
+    if (int st = risp_plane_sums(a, scratch, N, C, 0, C, H * W, stream)) return st;
+    if (int st = risp_plane_sums(b, scratch + (size_t)N * C, N, C, 0, C, H * W, stream)) return st;
+    int bx = (H * W / 4 + 256 * 8 - 1) / (256 * 8);
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    float *partial = scratch + 2 * (size_t)N * C;
+    hipLaunchKernelGGL(lg_partial_kernel, dim3(bx, N * C), dim3(256), 0, (hipStream_t)stream, a, b, flag, scratch, g, partial, N, C, H, W);
+    hipLaunchKernelGGL(lg_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, flag, loss, N, C, H, W, bx);
+    RISP_LAUNCH_CHECK("risp_local_global_l2");
     return 0;
 }
 

@@ -564,6 +564,30 @@ class _PixelLoss(torch.autograd.Function):
         return (g * gl if g is not None else None), None, None
 
 
+class _LocalGlobalL2(torch.autograd.Function):
+    """local_global_loss with the mean-squared loss (utils/util_loss.py:26-64) - both branches on the device in one call
+    (risp_local_global_l2), the flags never leave it; backward is a scaling of the gradient formed in the same pass."""
+
+    @staticmethod
+    def forward(ctx, y, gt, flag):
+        y, gt = _dev(y, 'output'), _dev(gt, 'target')
+        n, c, h, w = y.shape
+        lib = L.load()
+        flag = flag.to(device=y.device, dtype=torch.float32).contiguous()
+        g = torch.empty_like(y) if ctx.needs_input_grad[0] else None
+        loss = torch.empty((), device=y.device, dtype=torch.float32)
+        scratch = torch.empty(lib.risp_local_global_scratch_floats(n, c), device=y.device, dtype=torch.float32)
+        L.call('risp_local_global_l2', _p(y), _p(gt), _p(flag), _p(g), _p(loss), _p(scratch), n, c, h, w, _stream())
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        g, = ctx.saved_tensors
+        return (g * gl if g is not None else None), None, None
+
+
 def _written(tensors):
     """The C ABI wrote these tensors in place: bump their version counters as a torch in-place op would - the mixture-weight
     cache and the step-level reuse of the super-net key on them (a shifted parameter must miss)."""
@@ -598,6 +622,10 @@ class _HipImpl:
     @staticmethod
     def pixel_loss(y, gt, kind):
         return _PixelLoss.apply(y, gt, {'l2': 0, 'l1': 1}[kind])
+
+    @staticmethod
+    def local_global_l2(y, gt, flag):
+        return _LocalGlobalL2.apply(y, gt, flag)
 
     @staticmethod
     def darts_virtual_step(rows, momentum, lr_meta):
@@ -836,6 +864,11 @@ def can_fuse_slot(x, names, tensors=()):
 def pixel_loss(y, gt, kind='l2'):
     """nn.MSELoss ('l2') / nn.L1Loss ('l1') of the reference (models/darts_model.py:58-63, isp_model.py:29-34): a 0-dim tensor"""
     return _IMPL.pixel_loss(y, gt, kind)
+
+
+def local_global_l2(y, gt, flag):
+    """local_global_loss(y, gt, flag, nn.MSELoss()) of the reference (utils/util_loss.py:26-64): a 0-dim tensor"""
+    return _IMPL.local_global_l2(y, gt, flag)
 
 
 def darts_virtual_step(rows, momentum, lr_meta):

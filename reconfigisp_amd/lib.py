@@ -176,6 +176,8 @@ SIGNATURES = {
     'risp_param_blocks_fwd': (_i, [C.POINTER(ParamBlocksDesc), _s]),
     'risp_param_blocks_bwd': (_i, [C.POINTER(ParamBlocksDesc), _s]),
     'risp_loss_scratch_floats': (_z, []),
+    'risp_local_global_scratch_floats': (_z, [_i, _i]),
+    'risp_local_global_l2': (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _s]),
     'risp_pixel_loss': (_i, [_f, _f, _f, _f, _f, _z, _i, _s]),
     'risp_darts_virtual_step': (_i, [C.POINTER(ListDesc), _fl, _fl, _s]),
     'risp_list_norm_eps': (_i, [C.POINTER(ListDesc), _f, _s]),

@@ -354,6 +354,26 @@ def test_local_global_and_latency_losses_match_reference(dev):
         grad, = torch.autograd.grad(loss, a)
         _assert_close(loss, g['lg_%s_loss' % tag], rtol=1e-5, what=tag + ' loss')
         _assert_close(grad, g['lg_%s_grad' % tag], rtol=1e-5, floor=1.0, what=tag + ' grad')
+    if dev.type == 'cuda':
+        # the same three cases through the criterion the models build (darts_model._criterion: PixelLoss('l2')): both branches on the
+        # device in one call (risp_local_global_l2), no boolean indexing, no host read of the flags
+        from reconfigisp_amd.codes.models.darts_model import PixelLoss
+        from reconfigisp_amd import lib as L
+        L.CALLS = {}
+        try:
+            for tag in ('mixed', 'local', 'global'):
+                a = T(g['lg_in']).to(dev).requires_grad_(True)
+                loss = local_global_loss(a, b, T(g['lg_%s_flags' % tag]).to(dev), PixelLoss('l2'))
+                grad, = torch.autograd.grad(loss, a)
+                _assert_close(loss, g['lg_%s_loss' % tag], rtol=1e-5, what=tag + ' loss (device)')
+                _assert_close(grad, g['lg_%s_grad' % tag], rtol=1e-5, floor=1.0, what=tag + ' grad (device)')
+            a = T(g['lg_clamp_in']).to(dev).requires_grad_(True)
+            loss = local_global_loss(a, b[:2], torch.zeros(2, dtype=torch.int64, device=dev), PixelLoss('l2'))
+            _assert_close(loss, g['lg_clamp_loss'], rtol=1e-5, what='clamped gain loss (device)')
+            _assert_close(torch.autograd.grad(loss, a)[0], g['lg_clamp_grad'], rtol=1e-5, floor=1.0, what='clamped gain grad (device)')
+            assert L.CALLS.get('risp_local_global_l2') == 4, L.CALLS
+        finally:
+            L.CALLS = None
     a = T(g['lg_clamp_in']).to(dev).requires_grad_(True)
     loss = local_global_loss(a, b[:2], torch.zeros(2, dtype=torch.int64, device=dev), mse)
     _assert_close(loss, g['lg_clamp_loss'], rtol=1e-5, what='clamped gain loss')
