@@ -412,6 +412,10 @@ extern "C" {
 
 size_t risp_conv_toep_first_wpack_bytes(int cin, int cout) { return 16 + (size_t)((cout + 31) / 32) * cin * TF_WST * 16; }
 
+}  // extern "C"
+int risp_launch_xwin(const risp_conv_desc &d, unsigned *ties, unsigned max_ties, void *stream);      // risp_conv_xwin.hip
+extern "C" {
+
 static int toep_first_impl(const risp_conv_desc *dp, unsigned *ties, unsigned max_ties, void *stream) {
     RISP_CHECK_ARG(dp, "risp_conv2d_toep_first: null descriptor");
     const risp_conv_desc &d = *dp;
@@ -432,6 +436,10 @@ static int toep_first_impl(const risp_conv_desc *dp, unsigned *ties, unsigned ma
     RISP_CHECK_ARG(((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.y) | reinterpret_cast<uintptr_t>(d.wpack)) & 15) == 0,
                    "risp_conv2d_toep_first: tensors must be 16-byte aligned");
     const bool cb = (d.epilogue & RISP_EPI_CASEBIAS) != 0;
+    // 3 plain input channels: the (channel, tap) reduction index of risp_conv_xwin.hip - two matrix steps per filter row instead of three
+#ifndef RISP_XWIN_OFF                                        /* (A/B builds: tools/ab_xwin.py) */
+    if (!unshuf && d.cin == 3 && d.cout <= 64 && (unsigned long long)d.cout * d.H * d.W < (1ull << 29)) return risp_launch_xwin(d, ties, max_ties, stream);
+#endif
     if (unshuf) return cb ? launch_toep_first<true, true>(d, ties, max_ties, stream) : launch_toep_first<true, false>(d, ties, max_ties, stream);
     return cb ? launch_toep_first<false, true>(d, ties, max_ties, stream) : launch_toep_first<false, false>(d, ties, max_ties, stream);
 }
