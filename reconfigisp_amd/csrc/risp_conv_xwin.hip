@@ -3,34 +3,33 @@
 // The band kernel of risp_conv_toep_first.hip slides 8 windows of a zero-padded filter row over a 16-pixel window of ONE channel:
 // 9 of its 16 reduction slots carry a tap.  Here the reduction index of one filter row is (channel, tap): 27 values in 32 slots,
 //        out[co][y][x] = sum_ky sum_q W[co][ky][q] E[q][y + ky - 4][x],   E[(c, kx)][r][x] = in[c][r][x + kx - 4],
-// two matrix steps per filter row instead of three.  The expanded input E - per pixel four 16-byte slots: the 8-tap windows of the
-// three channels and the three ninth taps - costs 128 bytes per pixel and row, so it lives in a RING of 20 input rows of a 32-pixel
-// strip in LDS and a persistent workgroup walks DOWN its strip: every input row is expanded once.  The weights of the layer (72 KB) stay
-// in LDS.  (2 x 108 matrix instructions per 4 rows x 32 pixels x 64 couts; the band form 2 x 162.)  One scale per work item - the
-// largest magnitude of the image's strip - because an accumulator sums over rows that were staged at different times.
+// ONE v_mfma_f32_16x16x32_f16 per filter row, 16 pixels, 16 couts and product.  The expanded input E - per pixel four 16-byte slots: the
+// 8-tap windows of the three channels and the three ninth taps - costs 128 bytes per pixel and row, so it lives in a RING of 16 input
+// rows of a 32-pixel strip in LDS and a persistent workgroup walks DOWN its strip: every input row is expanded once.  The weights of the
+// layer (72 KB) stay in LDS.  Matrix work: 0.67 of the band form's.  One scale per work item - the largest magnitude of the image's strip -
+// because an accumulator sums over rows that were staged at different times.
 //
-// Kernel.  ONE workgroup of 8 waves per CU.  Work item = (image, strip of 32 columns, segment of rows); row block b = 4 input rows; group
-// g = 4 output rows, needs blocks g .. g + 2.
-//   waves 4-7  PRODUCERS: thread = (row of the block, pixel, slot pair): 12-18 loads, the scaled and split windows, 4 16-byte LDS writes.
-//              Phase p stages block p + 3 (requested a phase earlier).
-//   waves 0-3  CONSUMERS = 2 cout blocks x 2 PAIRS.  A group takes two phases - reduction half 0 (channels 0, 1), then half 1 (channel 2
-//              and the ninth taps) + epilogue - and the pairs alternate: in phase p pair p & 1 starts group p while the other finishes
-//              group p - 1, so that 4 new rows per phase suffice (16 rows in use + 4 being staged = the ring).  Within a phase a wave walks
-//              the 12 input rows of its group: the row's operand is read once and serves the (output row, filter row) pairs with
-//              t + ky = r; the filter rows' operands roll through 5 register sets.  48 LDS reads per 108 matrix instructions.
-// One barrier per phase.
-#include <type_traits>
+// Kernel.  ONE workgroup of 8 waves per CU in two TEAMS of four; waves w and w + 4 share a SIMD.  Work item = (image, strip of 32 columns,
+// segment of rows); row block b = 4 input rows; group g = 4 output rows, needs blocks g .. g + 2; phase p computes group p.
+//   the team p & 1 COMPUTES group p: wave = a quarter of the couts (16) x 4 rows x 32 pixels = 8 accumulators of 4 registers; it walks the
+//       group's 12 input rows - a row's two pixel operands are read once and serve the (output row, filter row) pairs with t + ky = r, the
+//       filter rows' operands roll through 5 register sets: 72 LDS reads per 216 matrix instructions;
+//   the other team SERVES: the epilogue of the group it computed in the previous phase (a lane holds 4 consecutive pixels of a cout: 16-byte
+//       stores) and the expansion of block p + 3 (thread = (row, pixel, slot pair): 16 loads requested two phases earlier, 4 16-byte LDS
+//       writes) - vector work that issues beside its SIMD partner's matrix instructions.
+// The teams swap roles every phase; one barrier per phase.  (s_setprio for the computing team: no change, 1.92 against 1.88 ms.  The first form of this kernel - 4 consumer waves of 32x32x16 instructions and
+// 4 producer waves - ran every SIMD's matrix pipe half of the time at best: a consumer's epilogue cost as much as its products.  2.13 ms
+// per grouped launch of config 3 against the band form's 2.97.)
 #include "risp_f16x2.h"
 
 namespace {
-#ifndef XW_SPLIT
-#define XW_SPLIT 6            /* input rows of reduction half 1 that a group's FIRST phase already takes */
-#endif
-constexpr int XW_TW = 32, XW_RING = 20, XW_KS = 9, XW_P = 4;
+constexpr int XW_TW = 32, XW_RING = 16, XW_KS = 9, XW_P = 4;
 constexpr int XW_ROW = 2 * 4 * XW_TW;                               // slots of a ring row: [part][slot][pixel]
-constexpr int XW_WST = 2 * XW_KS * 2 * 2 * 2 * 32;                 // weight slots: [cout block][ky][reduction half][part][channel half][cout]
-constexpr int XW_LDS_BYTES = (XW_RING * XW_ROW + XW_WST) * 16 + 64 + 2 * 64 * 4;      // ... + the maxima + per cout: bias, interior border-case value
+constexpr int XW_WST = 4 * XW_KS * 2 * 4 * 16;                     // weight slots: [cout quarter][ky][part][slot][cout]
+constexpr int XW_TS = 36;                                            // floats of a cout row of a wave's transposition scratch (32 pixels + 4: bank spread)
+constexpr int XW_LDS_BYTES = (XW_RING * XW_ROW + XW_WST) * 16 + 64 + 2 * 64 * 4 + 8 * 16 * XW_TS * 4;      // ... + the maxima + per cout: bias, interior border-case value + the scratch
 static_assert(XW_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define XW_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define XW_BARRIER_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -51,7 +50,9 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
     float *btab = red + 16;                                             // [64] bias, [64] the interior border-case value of the item's image
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hl = lane >> 5;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int team = wave >> 2, cq = wave & 3;
+    float *tsc = btab + 128 + wave * (16 * XW_TS);                      // this wave's [16 couts][32 pixels] scratch: the epilogue's transposition
     const size_t hw = (size_t)d.H * d.W;
     const unsigned hw4 = (unsigned)hw * 4u;
     // a workgroup takes a run of consecutive items: the strips of an image, the images of a member - its weights stay in LDS
@@ -75,6 +76,9 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
 #else
 #define XWSTAMP(acc_) do { } while (0)
 #endif
+    // staging task of a thread inside its team: row j of a block, pixel, slot pair sp (0: the windows of channels 0, 1; 1: the window of
+    // channel 2 and the ninth taps of the three channels)
+    const int st = tid & 255, sj = st >> 6, spx = st & 31, sp = (st >> 5) & 1;
 
     for (int t = t_first; t < t_end; ++t) {
         XwItem it;
@@ -84,21 +88,21 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
         const float *xin = d.x + (size_t)nx * 3 * hw;
         const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack + (size_t)it.g * d.wpack_gs);
         XW_BARRIER_ALL();                                               // every wave has left the previous item: ring, weights and maxima are free
-        // ---- all 8 waves: the member's weights into LDS (from the pack of risp_conv_toep_first_wpack_bytes: [cout block][ci][ky][part]
-        // [taps 0-7 | tap 8][cout][8]) and the largest magnitude of the strip (all rows of the image, the strip's columns + 4 each side)
+        // ---- the member's weights into LDS (from the pack of risp_conv_toep_first_wpack_bytes: [cout block][ci][ky][part][taps 0-7 | tap
+        // 8][cout][8]) and the largest magnitude of the strip (all rows of the image, the strip's columns + 4 each side)
         if (it.g != g_loaded) {
             for (int s = tid; s < XW_WST; s += 512) {
-                const int co = s & 31, h = (s >> 5) & 1, part = (s >> 6) & 1, ks = (s >> 7) & 1, rest = s >> 8, ky = rest % KS, cb = rest / KS;
-                const int slot = 2 * ks + h;
+                const int c = s & 15, slot = (s >> 4) & 3, part = (s >> 6) & 1, rest = s >> 7, ky = rest % KS, q4 = rest / KS;
+                const int co = 16 * q4 + c, cb = co >> 5, cl = co & 31;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (32 * cb >= d.cout) {                                // a layer of at most 32 couts has no second block
+                if (co >= d.cout) {
                 } else if (slot < 3) {
-                    v = wp[1 + ((((size_t)cb * 3 + slot) * KS + ky) * 2 + part) * 64 + co];
+                    v = wp[1 + ((((size_t)cb * 3 + slot) * KS + ky) * 2 + part) * 64 + cl];
                 } else {                                                // the ninth taps of the three channels
                     unsigned short q[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        q[c] = *reinterpret_cast<const unsigned short *>(wp + 1 + ((((size_t)cb * 3 + c) * KS + ky) * 2 + part) * 64 + 32 + co);
+                    for (int ch = 0; ch < 3; ++ch)
+                        q[ch] = *reinterpret_cast<const unsigned short *>(wp + 1 + ((((size_t)cb * 3 + ch) * KS + ky) * 2 + part) * 64 + 32 + cl);
                     v = make_uint4((unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2], 0u, 0u);
                 }
                 wl[s] = v;
@@ -130,242 +134,202 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
         se = se > 100 ? 100 : se;                                       // an all-zero or denormal strip: any scale will do
         XWSTAMP(t_pre);
 
-        if (wave >= 4) {
-            // =========================================================================================== producers
-            // thread = (row j of a block, pixel, slot pair sp): sp 0 -> slots 0, 1 (channels 0, 1: 2 x 8 loads), sp 1 -> slots 2, 3 (channel
-            // 2: 9 loads, element 8 = its ninth tap, + the ninth taps of channels 0 and 1)
-            const int pt = tid - 256, j = pt >> 6, px = pt & 31, sp = (pt >> 5) & 1;
-            const float sc = __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
-            const int gx0 = it.x0 + px - P;
-            // byte offsets (column + channel plane) of the thread's two slots; out of range -> 0x80000000: the buffer returns zeros.
-            // sp 0: slot A = the window of channel 0, slot B = that of channel 1; sp 1: A = channel 2, B = the ninth taps of channels 0, 1, 2
-            unsigned offa[8], offb[8];
+        // ---- staging: byte offsets (column + channel plane) of the thread's two slots; out of range -> 0x80000000: the buffer returns zeros
+        const float sc = __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+        const int gx0 = it.x0 + spx - P;
+        unsigned offa[8], offb[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool in = gx0 + e >= 0 && gx0 + e < d.W, in8 = gx0 + 8 >= 0 && gx0 + 8 < d.W;
-                offa[e] = in ? 4u * (unsigned)(gx0 + e) + (sp ? 2u * hw4 : 0u) : 0x80000000u;
-                offb[e] = sp ? ((e < 3 && in8) ? 4u * (unsigned)(gx0 + 8) + (unsigned)e * hw4 : 0x80000000u) : (in ? 4u * (unsigned)(gx0 + e) + hw4 : 0x80000000u);
+        for (int e = 0; e < 8; ++e) {
+            const bool in = gx0 + e >= 0 && gx0 + e < d.W, in8 = gx0 + 8 >= 0 && gx0 + 8 < d.W;
+            offa[e] = in ? 4u * (unsigned)(gx0 + e) + (sp ? 2u * hw4 : 0u) : 0x80000000u;
+            offb[e] = sp ? ((e < 3 && in8) ? 4u * (unsigned)(gx0 + 8) + (unsigned)e * hw4 : 0x80000000u) : (in ? 4u * (unsigned)(gx0 + e) + hw4 : 0x80000000u);
+        }
+        const __amdgpu_buffer_rsrc_t rx = h2_rsrc(xin);
+        float va[8], vb[8];
+        auto fetch = [&](int b) {                                       // block b: input rows ys - 4 + 4 b + j
+            const int y = it.ys - P + 4 * b + sj;
+            const bool ok = b < nblocks && y >= 0 && y < d.H;
+            const unsigned ro = 4u * (unsigned)(ok ? y * d.W : 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                               // (a valid row + an invalid column stays >= 2^31)
+                va[e] = h2_load4(rx, ok ? ro + offa[e] : 0x80000000u, 0u);
+                vb[e] = h2_load4(rx, ok ? ro + offb[e] : 0x80000000u, 0u);
             }
-            const __amdgpu_buffer_rsrc_t rx = h2_rsrc(xin);
-            float va[8], vb[8];
-            auto fetch = [&](int b) {                                   // block b: input rows ys - 4 + 4 b + j
-                const int y = it.ys - P + 4 * b + j;
-                const bool ok = b < nblocks && y >= 0 && y < d.H;
-                const unsigned ro = 4u * (unsigned)(ok ? y * d.W : 0);
+        };
+        auto stage = [&](int b) {
+            if (b >= nblocks) return;
+            uint4 h0, l0, h1, l1;
+            split8(va, sc, h0, l0);
+            split8(vb, sc, h1, l1);
+            uint4 *row = ring + ((4 * b + sj) % RING) * ROW + spx;
+            row[(0 * 4 + 2 * sp) * TW] = h0;
+            row[(0 * 4 + 2 * sp + 1) * TW] = h1;
+            row[(1 * 4 + 2 * sp) * TW] = l0;
+            row[(1 * 4 + 2 * sp + 1) * TW] = l1;
+        };
+        // ---- epilogue constants
+        const float inv_sw = *reinterpret_cast<const float *>(wp);
+        const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+        // |error| of a sum here <~ 2^-22 x (sum of |terms|) <= 2^-22 x 81 x max|w| x 3 tmax; inv_sw 2^15 >= max|w|: a margin of 2 more bits
+        const float tau = 3.f * tmax * inv_sw * (81.f * 32768.f / 1048576.f);
+        const float floor_ = (d.epilogue & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
+        const __amdgpu_buffer_rsrc_t rc = h2_rsrc(CASEB ? d.cvals + (size_t)it.n * d.cout * (KS * KS) : d.x);
+        const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)it.n * d.cout * hw);
+        const unsigned tbase = (unsigned)((size_t)it.n * d.cout * hw);
+        const uint4 *ws = wl + (size_t)cq * (KS * 2 * 4 * 16) + lane;   // + (ky * 2 + part) * 64: slot lane >> 4, cout lane & 15
+        f32x4 acc[4][2];                                                // [output row][half of the strip]; a lane: pixels 16 hp + 4 (lane >> 4) + {0 .. 3}
+
+        // prologue: blocks 0 and 1 by the two teams, block 2 by team 0; team 1 serves in phase 0 (block 3), team 0 in phase 1 (block 4)
+        fetch(team);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage(team);
+        if (team == 0) {
+            fetch(2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage(2);
+            fetch(4);
+        } else {
+            fetch(3);
+        }
+        XW_BARRIER_LDS();
+        XWSTAMP(t_work);
+        for (int p = 0; p <= ng; ++p) {
+            if ((p & 1) == team) {
+                if (p < ng) {
+                    // ======================================================================================= compute group p
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {                           // (a valid row + an invalid column stays >= 2^31)
-                    va[e] = h2_load4(rx, ok ? ro + offa[e] : 0x80000000u, 0u);
-                    vb[e] = h2_load4(rx, ok ? ro + offb[e] : 0x80000000u, 0u);
-                }
-            };
-            auto stage = [&](int b) {
-                if (b >= nblocks) return;
-                uint4 h0, l0, h1, l1;
-                split8(va, sc, h0, l0);
-                split8(vb, sc, h1, l1);
-                uint4 *row = ring + ((4 * b + j) % RING) * ROW + px;
-                row[(0 * 4 + 2 * sp) * TW] = h0;
-                row[(0 * 4 + 2 * sp + 1) * TW] = h1;
-                row[(1 * 4 + 2 * sp) * TW] = l0;
-                row[(1 * 4 + 2 * sp + 1) * TW] = l1;
-            };
-            // prologue: blocks 0, 1, 2; then phase p stages block p + 3, requested TWO phases earlier (two register sets: the first touch of an
-            // input row is an HBM miss, and a phase is shorter than its latency)
-            float wa[8], wb[8];
-            auto fetch2 = [&](int b) {
-                const int y = it.ys - P + 4 * b + j;
-                const bool ok = b < nblocks && y >= 0 && y < d.H;
-                const unsigned ro = 4u * (unsigned)(ok ? y * d.W : 0);
+                    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    wa[e] = h2_load4(rx, ok ? ro + offa[e] : 0x80000000u, 0u);
-                    wb[e] = h2_load4(rx, ok ? ro + offb[e] : 0x80000000u, 0u);
+                        for (int hp = 0; hp < 2; ++hp) acc[a][hp] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int rbase = (4 * p) % RING;
+                    h8 av[5][2], bv[2][2][2];              // (5 weight sets: the row ahead lands while the 4 in use are read); [buffer][half][part]
+                    auto load_a = [&](int ky) {
+                        av[ky % 5][0] = __builtin_bit_cast(h8, ws[(ky * 2 + 0) * 64]);
+                        av[ky % 5][1] = __builtin_bit_cast(h8, ws[(ky * 2 + 1) * 64]);
+                    };
+                    auto load_b = [&](int r, int buf) {
+                        int rr = rbase + r;
+                        rr = rr >= RING ? rr - RING : rr;
+                        const uint4 *row = ring + rr * ROW + kg * TW + l15;
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp) {
+                            bv[buf][hp][0] = __builtin_bit_cast(h8, row[16 * hp]);
+                            bv[buf][hp][1] = __builtin_bit_cast(h8, row[4 * TW + 16 * hp]);
+                        }
+                    };
+                    load_a(0);
+                    load_b(0, 0);
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) {
+                        if (r + 1 < 12) load_b(r + 1, (r + 1) & 1);
+                        if (r + 1 < KS) load_a(r + 1);
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        // rows of the product = pixels (the expanded input is the first operand), columns = couts
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int ky = r - a;
+                            if (ky >= 0 && ky < KS) {
+#pragma unroll
+                                for (int hp = 0; hp < 2; ++hp) acc[a][hp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv[r & 1][hp][1], av[ky % 5][0], acc[a][hp], 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int ky = r - a;
+                            if (ky >= 0 && ky < KS) {
+#pragma unroll
+                                for (int hp = 0; hp < 2; ++hp) acc[a][hp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv[r & 1][hp][0], av[ky % 5][1], acc[a][hp], 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int ky = r - a;
+                            if (ky >= 0 && ky < KS) {
+#pragma unroll
+                                for (int hp = 0; hp < 2; ++hp) acc[a][hp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv[r & 1][hp][0], av[ky % 5][0], acc[a][hp], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-            };
-            auto stage2 = [&](int b) {
-                if (b >= nblocks) return;
-                uint4 h0, l0, h1, l1;
-                split8(wa, sc, h0, l0);
-                split8(wb, sc, h1, l1);
-                uint4 *row = ring + ((4 * b + j) % RING) * ROW + px;
-                row[(0 * 4 + 2 * sp) * TW] = h0;
-                row[(0 * 4 + 2 * sp + 1) * TW] = h1;
-                row[(1 * 4 + 2 * sp) * TW] = l0;
-                row[(1 * 4 + 2 * sp + 1) * TW] = l1;
-            };
-            for (int b = 0; b < 3; ++b) {
-                fetch(b);
+                XWSTAMP(t_work);
+            } else {
+                // =========================================================================================== serve
+                // ---- the expansion of block p + 3 (requested two phases ago: nothing younger than its loads is in flight except this team's
+                // stores of two phases ago), then the request of block p + 5 - ahead of the epilogue's stores
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                stage(b);
-            }
-            fetch(3);                                                   // set 1: odd blocks; set 2: even blocks
-            fetch2(4);
-            XW_BARRIER_LDS();
-            XWSTAMP(t_work);
-            for (int p = 0; p <= ng; p += 2) {
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // block p + 3 has landed (behind it: the 16 loads of block p + 4)
                 stage(p + 3);
                 fetch(p + 5);
                 XWSTAMP(t_work);
-                XW_BARRIER_LDS();
-                XWSTAMP(t_wait);
-                if (p + 1 > ng) break;
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                stage2(p + 4);
-                fetch2(p + 6);
-                XWSTAMP(t_work);
-                XW_BARRIER_LDS();
-                XWSTAMP(t_wait);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            // =========================================================================================== consumers
-            const int cb = wave & 1, pair = wave >> 1;
-            const float inv_sw = *reinterpret_cast<const float *>(wp);
-            const float fin = inv_sw * __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
-            // |error| of a sum here <~ 2^-22 x (sum of |terms|) <= 2^-22 x 81 x max|w| x 3 tmax; inv_sw 2^15 >= max|w|: a margin of 2 more bits
-            const float tau = 3.f * tmax * inv_sw * (81.f * 32768.f / 1048576.f);
-            const int epi = d.epilogue;
-            const float floor_ = (epi & RISP_EPI_RELU) ? 0.f : -__builtin_inff();
-            const __amdgpu_buffer_rsrc_t rc = h2_rsrc(CASEB ? d.cvals + (size_t)it.n * d.cout * (KS * KS) : d.x);
-            const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)it.n * d.cout * hw);
-            const unsigned tbase = (unsigned)((size_t)it.n * d.cout * hw);
-            const uint4 *ws = wl + (size_t)cb * (KS * 2 * 2 * 2 * 32) + hl * 32 + l31;      // + ((ky * 2 + ks) * 2 + part) * 64
-            f32x16 acc[4];
-            XW_BARRIER_LDS();                                           // blocks 0 .. 2 are staged
-            XWSTAMP(t_wait);
-            for (int p = 0; p <= ng; ++p) {
-                const bool start = (p & 1) == pair && p < ng;           // this pair starts group p (reduction half 0) ...
-                const bool finish = (p & 1) != pair && p >= 1;          // ... or finishes group p - 1 (half 1 + epilogue)
-                if (start || finish) {
-                    const int g = start ? p : p - 1;
-                    if (start) {
+                if (p >= 1 && p - 1 < ng) {
+                    // ---- epilogue of group g = p - 1 (computed by this team in the previous phase).  The product leaves a lane 4 consecutive
+                    // pixels of cout (lane & 15) - 64-byte pieces of 16 cout rows per store; through the wave's LDS scratch a lane takes 4 pixels
+                    // of cout (lane >> 3) instead: 8 lanes = the strip's 32 pixels = one 128-byte line per cout (the 16-byte stores in 64-byte
+                    // pieces cost 0.6 of the kernel's 2.17 ms)
+                    const int g = p - 1;
+                    const int q8 = lane & 7, c8 = lane >> 3;
+                    const int px_ = it.x0 + 4 * q8;
 #pragma unroll
-                        for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < 4; ++a) {
+                        const int oy = it.ys + 4 * g + a;
+                        const bool rok = oy < it.ye;
+                        const int ycase = CASEB ? xw_border_case(oy < d.H ? oy : d.H - 1, d.H) : XW_P;
+                        // the border-case values: the interior one unless the row or one of the strip's pixels sits within 4 pixels of the image's
+                        // edge (a wave-uniform test; then the table's other entries are read from memory - ahead of the stores)
+                        const bool edge = CASEB && rok && (ycase != XW_P || it.x0 < XW_P || it.x0 + TW > d.W - XW_P);
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
-                    }
-                    // the walk over the group's 12 input rows: row r = ring row (4 g + r) % RING; its operand serves (t, ky = r - t).  A group
-                    // is reduction half 0 over all rows + half 1 over rows [0, XW_SPLIT) in its first phase, the rest of half 1 + the epilogue
-                    // in its second: the epilogue is as long as half a walk, and a phase lasts as long as its slower pair
-                    const int rbase = (4 * g) % RING;
-                    auto walk = [&](auto ks_c, auto r0_c, auto r1_c) {
-                        constexpr int ks = decltype(ks_c)::value, R0 = decltype(r0_c)::value, R1 = decltype(r1_c)::value;
-                        h8 av[5][2], bv[2][2];             // (5 weight sets: the row ahead lands while the 4 in use are read)
-                        auto load_a = [&](int ky) {
-                            av[ky % 5][0] = __builtin_bit_cast(h8, ws[((ky * 2 + ks) * 2 + 0) * 64]);
-                            av[ky % 5][1] = __builtin_bit_cast(h8, ws[((ky * 2 + ks) * 2 + 1) * 64]);
-                        };
-                        auto load_b = [&](int r, int buf) {
-                            int rr = rbase + r;
-                            rr = rr >= RING ? rr - RING : rr;
-                            const uint4 *row = ring + rr * ROW + (2 * ks + hl) * TW + l31;
-                            bv[buf][0] = __builtin_bit_cast(h8, row[0]);
-                            bv[buf][1] = __builtin_bit_cast(h8, row[4 * TW]);
-                        };
+                        for (int hp = 0; hp < 2; ++hp) *reinterpret_cast<f32x4 *>(tsc + l15 * XW_TS + 16 * hp + 4 * kg) = acc[a][hp];
 #pragma unroll
-                        for (int ky = (R0 - 3 > 0 ? R0 - 3 : 0); ky <= R0 && ky < KS; ++ky) load_a(ky);
-                        load_b(R0, R0 & 1);
-#pragma unroll
-                        for (int r = R0; r < R1; ++r) {
-                            if (r + 1 < R1) load_b(r + 1, (r + 1) & 1);
-                            if (r + 1 < KS && r + 1 < R1) load_a(r + 1);
-                            asm volatile("" ::: "memory");
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const int ky = r - a;
-                                if (ky >= 0 && ky < KS) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[r & 1][1], av[ky % 5][0], acc[a], 0, 0, 0);
-                            }
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const int ky = r - a;
-                                if (ky >= 0 && ky < KS) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[r & 1][0], av[ky % 5][1], acc[a], 0, 0, 0);
-                            }
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const int ky = r - a;
-                                if (ky >= 0 && ky < KS) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[r & 1][0], av[ky % 5][0], acc[a], 0, 0, 0);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    };
-                    using I0 = std::integral_constant<int, 0>;
-                    using I1 = std::integral_constant<int, 1>;
-                    using IS = std::integral_constant<int, XW_SPLIT>;
-                    using I12 = std::integral_constant<int, 12>;
-                    if (start) {
-                        walk(I0{}, I0{}, I12{});
-                        walk(I1{}, I0{}, IS{});
-                    } else {
-                        walk(I1{}, IS{}, I12{});
-                    }
-                    XWSTAMP(t_work);
-                    if (finish) {
-                        // ---- epilogue of group g.  The pixels are the ROWS of the matrix product (the expanded input is its first operand): a lane
-                        // holds cout 32 cb + (lane & 31) and, per accumulator (output row a), pixels 8 q + 4 half + {0 .. 3} for q = element >> 2 -
-                        // four consecutive pixels: 16-byte stores, 16 per group instead of 64 4-byte ones
-                        const int co = 32 * cb + l31;
-                        const bool cok = co < d.cout;
-                        const float bb = btab[co], c40 = btab[64 + co];
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const int oy = it.ys + 4 * g + a;
-                            const bool rok = oy < it.ye;
-                            const int ycase = CASEB ? xw_border_case(oy < d.H ? oy : d.H - 1, d.H) : XW_P;
-                            // the border-case values: the interior one unless the row or one of the wave's pixels sits within 4 pixels of the
-                            // image's edge (a wave-uniform test; then the table's other entries are read from memory - ahead of the stores)
-                            const bool edge = CASEB && rok && (ycase != XW_P || it.x0 < XW_P || it.x0 + TW > d.W - XW_P);
-                            float tv[16];
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) tv[e] = c40;
+                        for (int half = 0; half < 2; ++half) {
+                            const int cc = 16 * cq + 8 * half + c8;                       // this lane's cout of the pass
+                            const bool ck = cc < d.cout;
+                            const f32x4 raw = *reinterpret_cast<const f32x4 *>(tsc + (8 * half + c8) * XW_TS + 4 * q8);
+                            const float bb = btab[cc], c40 = btab[64 + cc];
+                            float tv[4] = {c40, c40, c40, c40};
                             if (edge) {
 #pragma unroll
-                                for (int e = 0; e < 16; ++e) {
-                                    const int px_ = it.x0 + 8 * (e >> 2) + 4 * hl + (e & 3);
-                                    const int xc = xw_border_case(px_ < d.W ? px_ : d.W - 1, d.W);
-                                    tv[e] = h2_load4(rc, (cok && px_ < d.W) ? 4u * (unsigned)(co * (KS * KS) + ycase * KS + xc) : 0x80000000u, 0u);
-                                }
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int px_ = it.x0 + 8 * q + 4 * hl;
-                                float o[4];
-                                bool near = false;
-#pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    float v = acc[a][4 * q + i] * fin + bb;
-                                    if (CASEB) v += tv[4 * q + i];
-                                    // a pre-activation this close to zero has no reliable sign in fp32: listed for toep_first_ties_kernel
-                                    near = near || fabsf(v) < tau;
-                                    o[i] = v;
+                                    const int xc = xw_border_case(px_ + i < d.W ? px_ + i : d.W - 1, d.W);
+                                    tv[i] = h2_load4(rc, (ck && px_ + i < d.W) ? 4u * (unsigned)(cc * (KS * KS) + ycase * KS + xc) : 0x80000000u, 0u);
                                 }
-                                if (TIES && __builtin_amdgcn_ballot_w64(near && rok && cok) != 0) {      // (rare: a wave-uniform test first)
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        if (rok && cok && px_ + i < d.W && fabsf(o[i]) < tau) {
-                                            const unsigned slot = atomicAdd(ties, 1u);
-                                            if (slot < max_ties) ties[1 + slot] = tbase + (unsigned)co * (unsigned)hw + (unsigned)(oy * d.W + px_ + i);   // (< 2^32 outputs: checked by the entry point)
-                                        }
-                                }
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) o[i] = o[i] < floor_ ? floor_ : o[i];
-                                const unsigned vo = (rok && cok && px_ < d.W) ? 4u * (unsigned)(oy * d.W + px_) + (unsigned)co * hw4 : 0x80000000u;
-#ifndef XW_NO_STORE
-                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, o[0]), __builtin_bit_cast(unsigned, o[1]), __builtin_bit_cast(unsigned, o[2]),
-                                                                             __builtin_bit_cast(unsigned, o[3])}, ry, vo, 0u, 0);
-#else
-                                if (o[0] + o[1] + o[2] + o[3] == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(0u, ry, vo, 0u, 0);
-#endif
                             }
+                            float o[4];
+                            bool near = false;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                float v = raw[i] * fin + bb;
+                                if (CASEB) v += tv[i];
+                                // a pre-activation this close to zero has no reliable sign in fp32: listed for toep_first_ties_kernel
+                                near = near || fabsf(v) < tau;
+                                o[i] = v;
+                            }
+                            if (TIES && __builtin_amdgcn_ballot_w64(near && rok && ck) != 0) {      // (rare: a wave-uniform test first)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (rok && ck && px_ + i < d.W && fabsf(o[i]) < tau) {
+                                        const unsigned slot = atomicAdd(ties, 1u);
+                                        if (slot < max_ties) ties[1 + slot] = tbase + (unsigned)cc * (unsigned)hw + (unsigned)(oy * d.W + px_ + i);   // (< 2^32 outputs: checked by the entry point)
+                                    }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[i] = o[i] < floor_ ? floor_ : o[i];
+                            const unsigned vo = (rok && ck && px_ < d.W) ? 4u * (unsigned)(oy * d.W + px_) + (unsigned)cc * hw4 : 0x80000000u;
+#ifndef XW_NO_STORE
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, o[0]), __builtin_bit_cast(unsigned, o[1]), __builtin_bit_cast(unsigned, o[2]),
+                                                                         __builtin_bit_cast(unsigned, o[3])}, ry, vo, 0u, 0);
+#else
+                            if (o[0] + o[1] + o[2] + o[3] == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(0u, ry, vo, 0u, 0);
+#endif
                         }
                     }
                 }
                 XWSTAMP(t_epi);
-                XW_BARRIER_LDS();
-                XWSTAMP(t_wait);
             }
+            XW_BARRIER_LDS();
+            XWSTAMP(t_wait);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifdef RISP_XW_STAMPS
     if (lane == 0 && max_ties == 0xABCDu && ties) {      // diagnostic build: cycle shares of a wave's life (tools/xwin_stamps.py)

@@ -40,8 +40,8 @@ t = buf[:nwg * 64].view(nwg, 8, 8).double()
 cons, prod = t[:, :4], t[:, 4:]
 life = cons[..., 4].median().item()
 phases = G * n * ((w + 31) // 32) * (h // 4 + 1) / nwg
-print('9x9 3 -> 64, %d x 3 x %d x %d: %.0f us per launch (stamped build, with the tie-recompute launch); wave life %.0f cycles = %.0f per phase (108 matrix instructions = 3456 cycles); clock ~%.2f GHz'
+print('9x9 3 -> 64, %d x 3 x %d x %d: %.0f us per launch (stamped build, with the tie-recompute launch); wave life %.0f cycles = %.0f per phase (a team's 216 16x16x32 matrix instructions every other phase = 3456 cycles); clock ~%.2f GHz'
       % (G * n, h, w, us, life, life / phases, life / us / 1e3))
-for nm, grp in (('consumers', cons), ('producers', prod)):
-    print('  %s: item preamble (weights, strip maximum) %.3f, barrier wait %.3f, work %.3f, epilogue %.3f of the life'
+for nm, grp in (('team 0 (waves 0-3)', cons), ('team 1 (waves 4-7)', prod)):
+    print('  %s: item preamble (weights, strip maximum) %.3f, barrier wait %.3f, products + expansion of input rows %.3f, epilogue %.3f of the life'
           % ((nm,) + tuple(grp[..., i].sum().item() / grp[..., 4].sum().item() for i in (0, 1, 2, 3))))
