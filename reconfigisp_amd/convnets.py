@@ -613,11 +613,26 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
         if MFMA_ISSUED_F16 is not None:
             MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * pc.k * cin * cout * nn_ * h * w
     elif entry.startswith('risp_conv2d_toep_first'):
-        if MFMA_ISSUED_F16 is not None:                # 16 window slots per filter row (9 carry a tap), cout padded to 32
-            MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * 16 * cin * ((cout + 31) // 32 * 32) * nn_ * h * w
+        if MFMA_ISSUED_F16 is not None:
+            MFMA_ISSUED_F16[0] += first_layer_issued(cin, cout, h, w, load == LOAD_UNSHUFFLE2) * nn_ * h * w
     elif MFMA_ISSUED is not None:
         MFMA_ISSUED[0] += _issued_flops(entry, cin, cout, pc.k, nn_ * h * w)
     return out
+
+
+def first_layer_form(cin, cout, h, w, unshuffle=False):
+    """which kernel ``risp_conv2d_toep_first`` launches (the dispatch of toep_first_impl, risp_conv_toep_first.hip): 'xwin' = the
+    (channel, tap) reduction index of risp_conv_xwin.hip for 3 plain input channels, 'band' = the 16-slot window of round 5"""
+    return 'xwin' if (not unshuffle and cin == 3 and cout <= 64 and cout * h * w < (1 << 29)) else 'band'
+
+
+def first_layer_issued(cin, cout, h, w, unshuffle=False):
+    """f16 matrix flops ISSUED per output pixel by the 9x9 first layer's kernel (3 split-precision products): 'xwin' spends one 32-slot
+    reduction step per filter row (27 slots carry a (channel, tap)) on 64 couts; 'band' spends 16 window slots per (channel, filter
+    row) (9 carry a tap) on the couts padded to 32"""
+    if first_layer_form(cin, cout, h, w, unshuffle) == 'xwin':
+        return 3 * 2.0 * 9 * 32 * 64
+    return 3 * 2.0 * 9 * 16 * cin * ((cout + 31) // 32 * 32)
 
 
 _WGRAD_SCRATCH = {}                                     # per (device, stream): the partial-sum slots of risp_conv2d_wgrad, grown on demand

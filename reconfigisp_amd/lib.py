@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libreconfigisp_hip.so')
+# RISP_HIP_LIBRARY: another BUILD of the same library (the diagnostic / ablation builds of tools/*.sh live in /tmp, the in-tree file is
+# never rebuilt under a measurement); absent, the in-tree library
+LIB_PATH = os.environ.get('RISP_HIP_LIBRARY') or os.path.join(_HERE, 'lib', 'libreconfigisp_hip.so')
 
 _f = C.c_void_p        # device float*
 _i = C.c_int

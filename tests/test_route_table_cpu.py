@@ -91,6 +91,12 @@ def test_useful_over_issued_products_of_the_few_channel_kernels():
     taprow = lambda k, cout: (k * cout) / 32.0                      # risp_conv2d_tapout: rows = (cout, ky), every slot a channel
     assert abs(band(9, 3) - 0.42) < 0.005 and abs(taprow(9, 3) - 0.84) < 0.005
     assert abs(band(5, 3) - 0.23) < 0.005 and abs(taprow(5, 3) - 0.47) < 0.005
+    # the 9x9 3 -> 64 first layer: (channel, tap) reduction index (27 of 32 slots) against 16 window slots per (channel, filter row)
+    useful = 3 * 2.0 * 81 * 3 * 64
+    assert CN.first_layer_form(3, 64, 256, 256) == 'xwin' and abs(useful / CN.first_layer_issued(3, 64, 256, 256) - 0.84) < 0.005
+    assert CN.first_layer_form(3, 64, 256, 256, True) == 'band' and abs(useful / CN.first_layer_issued(3, 64, 256, 256, True) - 0.5625) < 1e-9
+    assert CN.first_layer_form(3, 64, 3000, 4000) == 'band' and CN.first_layer_form(4, 64, 256, 256) == 'band'
+    assert abs(3 * 2.0 * 81 * 3 * 32 / CN.first_layer_issued(3, 32, 256, 256) - 0.42) < 0.005      # 32 couts: half the rows carry zeros
     # the layers that stay on the band form: 4 couts (36 rows do not fit 32), 12 couts, channel counts that are no multiple of 16
     assert not CN.small_has_tapout(9, 64, 4) and not CN.small_has_tapout(5, 32, 12) and not CN.small_has_tapout(5, 7, 1)
     assert CN.small_has_tapout(9, 64, 3) and CN.small_has_tapout(5, 32, 3) and CN.small_has_tapout(5, 16, 1)

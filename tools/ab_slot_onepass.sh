@@ -1,13 +1,13 @@
 #!/bin/bash
-# GPU box: the fused slot mixture's backward with WbQuadratic's 30 sums in a second launch (default) against one launch
-# (-DRISP_SLOT_WBQ_ONE_PASS=1): rocprofv3 kernel durations of tools/bench_ops.py (slot section only) for both builds.  The library
-# is rebuilt in the box's scratch copy and left in its default configuration.
+# GPU box: the fused slot mixture's backward with WbQuadratic's 30 sums inside the one launch (the default since round 6) against a second
+# launch (-DRISP_SLOT_WBQ_ONE_PASS=0) and other builds of risp_slot.hip given as arguments: rocprofv3 kernel durations of
+# tools/bench_ops.py (slot section only).  Every build goes to /tmp (tools/build_variant.sh); the in-tree library is not touched.
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-trap 'touch "$REPO"/reconfigisp_amd/csrc/risp_slot.hip; make -s -C "$REPO/reconfigisp_amd/csrc" -j8 > /tmp/ab_build.log 2>&1' EXIT
+i=0
 for v in "" "$@"; do
-  touch "$REPO"/reconfigisp_amd/csrc/risp_slot.hip
-  make -s -C "$REPO/reconfigisp_amd/csrc" -j8 EXTRA="$v" > /tmp/ab_build.log 2>&1 || { tail -5 /tmp/ab_build.log; exit 1; }
+  i=$((i + 1))
+  export RISP_HIP_LIBRARY=$(bash "$REPO/tools/build_variant.sh" /tmp/ab_slot_$i "$v" risp_slot.hip) || exit 1
   rm -rf /tmp/ab_slot_prof
   RISP_OPS_ONLY=slot RISP_OPS_REPS=24 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_slot_prof -o o -- python3 "$REPO/tools/bench_ops.py" > /tmp/ab_slot.log 2>&1
   echo "== build [$v]"

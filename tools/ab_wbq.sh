@@ -1,13 +1,14 @@
 #!/bin/bash
 # GPU box: WbQuadratic's backward kernels under different build flags (one argument = one set of -D flags for risp_slot.hip /
-# risp_pointwise.hip, e.g. "-DRISP_WBQ_WAVES=3 -DRISP_WBQ_AHEAD=1"): rocprofv3 kernel durations.  The library is rebuilt on the box
-# and left in the LAST configuration.
+# risp_pointwise.hip, e.g. "-DRISP_WBQ_WAVES=3 -DRISP_WBQ_AHEAD=1"): rocprofv3 kernel durations.  Every build goes to /tmp (tools/build_variant.sh); the
+# in-tree library is not touched.
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
+i=0
 for cfg in "$@"; do
-  touch "$REPO/reconfigisp_amd/csrc/risp_slot.hip" "$REPO/reconfigisp_amd/csrc/risp_pointwise.hip" "$REPO/reconfigisp_amd/csrc/risp_core.cpp" "$REPO/reconfigisp_amd/csrc/risp_reduce.hip"
-  make -C "$REPO/reconfigisp_amd/csrc" -j8 EXTRA="$cfg" > /dev/null 2>&1
+  i=$((i + 1))
+  export RISP_HIP_LIBRARY=$(bash "$REPO/tools/build_variant.sh" /tmp/ab_wbq_$i "$cfg" risp_slot.hip risp_pointwise.hip risp_core.cpp risp_reduce.hip) || exit 1
   for what in "quadratic forward +" "slot mixture fused forward +"; do
     rm -rf /tmp/abw; RISP_OPS_REPS=24 RISP_OPS_ONLY="$what" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abw -o o -- python3 "$REPO/tools/bench_ops.py" > /dev/null 2>&1
     python3 - "$cfg" <<'PY'
