@@ -31,6 +31,7 @@
 //              ring, the retiring rows and their stores.
 // One barrier per chunk, 12 K matrix instructions per consumer wave between two of them.
 #include "risp_f16x2.h"
+#include <type_traits>
 
 namespace {
 constexpr int TO_TW = 128, TO_RS = 4;
@@ -111,6 +112,9 @@ __global__ __launch_bounds__(512, 2) void conv_tapout_kernel(const risp_conv_des
     // step retires the group of 4 output rows whose last input row it held (LAG steps behind)
     auto first_step = [&](const ToItem &r) { return r.ys - P < 0 ? (P - r.ys) / RS : 0; };
     auto last_step = [&](const ToItem &r) { return ((r.ye + P < d.H ? r.ye + P : d.H) - 1 - (r.ys - P)) / RS; };
+#ifndef TO_PSPLIT
+#define TO_PSPLIT 0
+#endif
 #ifdef RISP_TO_STAMPS
     unsigned long long t_wait = 0, t_work = 0, t_tail = 0, t0 = TO_T(), t1;
     const unsigned long long t_start = t0;
@@ -207,7 +211,12 @@ __global__ __launch_bounds__(512, 2) void conv_tapout_kernel(const risp_conv_des
         }
         int ps_pending = -1;                                            // item whose channel sums sit in psred, to be finished after the next barrier
         // largest magnitude of a chunk -> red[slot][pw]; its own pixels into the channel sums
-        auto amax = [&](Set &z, int slot) {
+        // (`ctag`: the chunk's index among the item step's 4 as a compile-time constant - the four phases of a step are four instances of the
+        // code; indexed with z.c the sums' registers were addressed through s_set_gpr_idx_on / _off, 64 mode switches per chunk.  The sums
+        // themselves: 32 additions per chunk - as v_add_f32.  Paired by the SLP vectoriser into 16 v_pk_add_f32 they took 1700 cycles
+        // beside the consumers' matrix instructions (350 unpaired): the library is built with -fno-slp-vectorize, see the Makefile.)
+        auto amax = [&](Set &z, int slot, auto ctag) {
+            constexpr int C = decltype(ctag)::value;
             if (!z.valid) return;
             float m = 0.f;
 #pragma unroll
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void conv_tapout_kernel(const risp_conv_des
             if (PSUM) {
                 if (z.own) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) psacc[z.c & 3][k] += (z.v[k].x + z.v[k].y) + (z.v[k].z + z.v[k].w);
+                    for (int k = 0; k < 8; ++k) psacc[PSUM ? C : 0][k] += (z.v[k].x + z.v[k].y) + (z.v[k].z + z.v[k].w);
                 }
                 if (z.last) {
                     // the item's channel sums: lanes of one half hold the same 8 channels of each chunk; rows of 16 lanes by DPP, the two rows of a
@@ -278,6 +287,11 @@ __global__ __launch_bounds__(512, 2) void conv_tapout_kernel(const risp_conv_des
                     *reinterpret_cast<_Float16 *>(tb + hdst + 16 * k + PART * 16) = ll;
                 }
             }
+            // every lane has requested the halo values, the halo lanes alone read them: for the others hipcc keeps the request "in flight"
+            // and, where it next reuses those registers (the addresses of the following request), waits for EVERY vector-memory operation -
+            // the weight pieces above included.  A use by all lanes, here where the next wait asks for more anyway:
+#pragma unroll
+            for (int k = 0; k < P; ++k) asm volatile("" :: "v"(z.hv[k]));
         };
         auto finish_psum = [&]() {
             if (PSUM && ps_pending >= 0) {
@@ -285,6 +299,9 @@ __global__ __launch_bounds__(512, 2) void conv_tapout_kernel(const risp_conv_des
                     const int n = ps_pending / per;
                     psum[((size_t)n * per + (ps_pending - n * per)) * 64 + pt] = (psred[pt] + psred[64 + pt]) + (psred[128 + pt] + psred[192 + pt]);
                 }
+                // the store retires HERE, once per item, with a wait the compiler can see (where this branch joins the phase it would
+                // otherwise assume the store in flight when it next reuses the store's registers)
+                __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
                 ps_pending = -1;
             }
         };
@@ -293,25 +310,41 @@ __global__ __launch_bounds__(512, 2) void conv_tapout_kernel(const risp_conv_des
         fetch(za);                                                      // chunk 0
         fetch(zb);                                                      // chunk 1
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NLOAD) : "memory");      // chunk 0 has landed (chunk 1's loads still in flight)
-        amax(za, 0);
+        amax(za, 0, std::integral_constant<int, 0>{});
         TO_BARRIER_LDS();                                               // barrier "-1": the maxima of chunk 0 are visible
         // phase p: stage chunk p (set p & 1), take the maxima of chunk p + 1 (the other set), request chunk p + 2 (into the set just freed)
-        auto phase = [&](Set &zs, Set &zn, int p) {
+        auto phase = [&](Set &zs, Set &zn, int p, auto ctag) {
             TOSTAMP(t_wait);
             finish_psum();
             stage(zs, p & 3, p & 1);
+#if defined(RISP_TO_STAMPS) && TO_PSPLIT == 1                /* (tools/tapout_stamps.py -DTO_PSPLIT=n: the producers' phase up to a point, in t_tail) */
+            TOSTAMP(t_tail);
+#endif
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PW) : "memory");      // chunk p + 1 has landed (behind it: this phase's weight pieces)
-            amax(zn, (p + 1) & 3);
+#if defined(RISP_TO_STAMPS) && TO_PSPLIT == 2
+            TOSTAMP(t_tail);
+#endif
+            amax(zn, (p + 1) & 3, ctag);
+#if defined(RISP_TO_STAMPS) && TO_PSPLIT == 3
+            TOSTAMP(t_tail);
+#endif
             fetch(zs);
+#if defined(RISP_TO_STAMPS) && TO_PSPLIT == 4
+            TOSTAMP(t_tail);
+#endif
             asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::NLOAD) : "memory");      // the weight pieces have landed (behind them: chunk p + 2)
             TOSTAMP(t_work);
             TO_BARRIER_LDS();
         };
-        for (int p = 0;; p += 2) {
+        for (int p = 0;; p += 4) {                                      // (with the channel sums: 64 channels = 4 chunks, chunk of phase p = p & 3)
             if (!za.valid) break;
-            phase(za, zb, p);
+            phase(za, zb, p, std::integral_constant<int, 1>{});
             if (!zb.valid) break;
-            phase(zb, za, p + 1);
+            phase(zb, za, p + 1, std::integral_constant<int, 2>{});
+            if (!za.valid) break;
+            phase(za, zb, p + 2, std::integral_constant<int, 3>{});
+            if (!zb.valid) break;
+            phase(zb, za, p + 3, std::integral_constant<int, 0>{});
         }
         finish_psum();
     } else {

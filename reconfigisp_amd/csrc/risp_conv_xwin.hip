@@ -21,13 +21,15 @@
 // 4 producer waves - ran every SIMD's matrix pipe half of the time at best: a consumer's epilogue cost as much as its products.  2.13 ms
 // per grouped launch of config 3 against the band form's 2.97.)
 #include "risp_f16x2.h"
+#include <type_traits>
 
 namespace {
 constexpr int XW_TW = 32, XW_RING = 16, XW_KS = 9, XW_P = 4;
 constexpr int XW_ROW = 2 * 4 * XW_TW;                               // slots of a ring row: [part][slot][pixel]
 constexpr int XW_WST = 4 * XW_KS * 2 * 4 * 16;                     // weight slots: [cout quarter][ky][part][slot][cout]
 constexpr int XW_TS = 36;                                            // floats of a cout row of a wave's transposition scratch (32 pixels + 4: bank spread)
-constexpr int XW_LDS_BYTES = (XW_RING * XW_ROW + XW_WST) * 16 + 64 + 2 * 64 * 4 + 8 * 16 * XW_TS * 4;      // ... + the maxima + per cout: bias, interior border-case value + the scratch
+constexpr int XW_TL = 511;                                          // entries of the workgroup's own tie list (behind its counter)
+constexpr int XW_LDS_BYTES = (XW_RING * XW_ROW + XW_WST) * 16 + 64 + 2 * 64 * 4 + 8 * 16 * XW_TS * 4 + (1 + XW_TL) * 4 + 64 * XW_KS * 4;      // ... + the maxima + per cout: bias, interior border-case value + the scratch + the tie list + the border-case values of an interior row
 static_assert(XW_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -53,6 +55,12 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
     const int l15 = lane & 15, kg = lane >> 4;
     const int team = wave >> 2, cq = wave & 3;
     float *tsc = btab + 128 + wave * (16 * XW_TS);                      // this wave's [16 couts][32 pixels] scratch: the epilogue's transposition
+    // ties (TIES): an item's near-zero pre-activations are collected in LDS and handed to the global list once per item.  (One global
+    // atomic per tie made a serving wave wait out a device-scope round trip, and its team's phase with it: 1.84 -> 2.39 ms at the ~5e-5
+    // ties per output of a training forward.)
+    unsigned *tl = reinterpret_cast<unsigned *>(btab + 128 + 8 * (16 * XW_TS));
+    float *bt9 = reinterpret_cast<float *>(tl + 1 + XW_TL);             // [64 couts][9 column cases] of row case 4 (every row but the image's first and last 4)
+    if (TIES && tid == 0) tl[0] = 0u;                                   // (the item loop opens with a barrier)
     const size_t hw = (size_t)d.H * d.W;
     const unsigned hw4 = (unsigned)hw * 4u;
     // a workgroup takes a run of consecutive items: the strips of an image, the images of a member - its weights stay in LDS
@@ -113,6 +121,12 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
             const bool has = tid < d.cout;
             btab[tid] = (has && !(d.epilogue & RISP_EPI_NOBIAS)) ? d.bias[(size_t)it.g * d.bias_gs + tid] : 0.f;
             btab[64 + tid] = (CASEB && has) ? d.cvals[((size_t)it.n * d.cout + tid) * (KS * KS) + XW_P * KS + XW_P] : 0.f;
+        }
+        if (CASEB) {
+            for (int s = tid; s < 64 * KS; s += 512) {
+                const int co = s / KS, xc = s - co * KS;
+                bt9[s] = co < d.cout ? d.cvals[((size_t)it.n * d.cout + co) * (KS * KS) + XW_P * KS + xc] : 0.f;
+            }
         }
         {
             float m = 0.f;
@@ -176,6 +190,10 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
         const __amdgpu_buffer_rsrc_t rc = h2_rsrc(CASEB ? d.cvals + (size_t)it.n * d.cout * (KS * KS) : d.x);
         const __amdgpu_buffer_rsrc_t ry = h2_rsrc(d.y + (size_t)it.n * d.cout * hw);
         const unsigned tbase = (unsigned)((size_t)it.n * d.cout * hw);
+        const int q8 = lane & 7, c8 = lane >> 3, px_ = it.x0 + 4 * q8;   // the epilogue's lane: 4 pixels of cout c8 of a pass
+        int xcase[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xcase[i] = xw_border_case(px_ + i < d.W ? px_ + i : d.W - 1, d.W);
         const uint4 *ws = wl + (size_t)cq * (KS * 2 * 4 * 16) + lane;   // + (ky * 2 + part) * 64: slot lane >> 4, cout lane & 15
         f32x4 acc[4][2];                                                // [output row][half of the strip]; a lane: pixels 16 hp + 4 (lane >> 4) + {0 .. 3}
 
@@ -259,77 +277,121 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
                 // ---- the expansion of block p + 3 (requested two phases ago: nothing younger than its loads is in flight except this team's
                 // stores of two phases ago), then the request of block p + 5 - ahead of the epilogue's stores
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef XW_NO_STAGE                                          /* (diagnostic builds, wrong results: what a part of the serving phase costs) */
                 stage(p + 3);
                 fetch(p + 5);
+#endif
                 XWSTAMP(t_work);
+#ifndef XW_NO_EPI
                 if (p >= 1 && p - 1 < ng) {
                     // ---- epilogue of group g = p - 1 (computed by this team in the previous phase).  The product leaves a lane 4 consecutive
                     // pixels of cout (lane & 15) - 64-byte pieces of 16 cout rows per store; through the wave's LDS scratch a lane takes 4 pixels
                     // of cout (lane >> 3) instead: 8 lanes = the strip's 32 pixels = one 128-byte line per cout (the 16-byte stores in 64-byte
-                    // pieces cost 0.6 of the kernel's 2.17 ms)
+                    // pieces cost 0.6 of the kernel's 2.17 ms).
+                    // The border-case value of a pixel: from the LDS table of the interior row case - unless the group holds one of the image's
+                    // first or last 4 rows (a wave-uniform test), whose values are read from memory.  Two instances of the code: hipcc waits
+                    // where the paths of a branch around a load meet, for every vector-memory operation in flight - the previous STORE included
+                    // (800 cycles per store, 6500 of a serving phase's 9000 while the other team's products take 4000).
                     const int g = p - 1;
-                    const int q8 = lane & 7, c8 = lane >> 3;
-                    const int px_ = it.x0 + 4 * q8;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int oy = it.ys + 4 * g + a;
-                        const bool rok = oy < it.ye;
-                        const int ycase = CASEB ? xw_border_case(oy < d.H ? oy : d.H - 1, d.H) : XW_P;
-                        // the border-case values: the interior one unless the row or one of the strip's pixels sits within 4 pixels of the image's
-                        // edge (a wave-uniform test; then the table's other entries are read from memory - ahead of the stores)
-                        const bool edge = CASEB && rok && (ycase != XW_P || it.x0 < XW_P || it.x0 + TW > d.W - XW_P);
-#pragma unroll
-                        for (int hp = 0; hp < 2; ++hp) *reinterpret_cast<f32x4 *>(tsc + l15 * XW_TS + 16 * hp + 4 * kg) = acc[a][hp];
+                    const bool gedge = CASEB && (it.ys + 4 * g < XW_P || it.ys + 4 * g + 3 >= d.H - XW_P);
+                    auto epilogue = [&](auto edge_tag) {
+                        constexpr bool EDGE = decltype(edge_tag)::value;
+                        // per cout of the lane's two passes: bias, and (rows of the interior case) the border-case values of its 4 pixels
+                        float bb[2], tvi[2][4];
 #pragma unroll
                         for (int half = 0; half < 2; ++half) {
-                            const int cc = 16 * cq + 8 * half + c8;                       // this lane's cout of the pass
-                            const bool ck = cc < d.cout;
-                            const f32x4 raw = *reinterpret_cast<const f32x4 *>(tsc + (8 * half + c8) * XW_TS + 4 * q8);
-                            const float bb = btab[cc], c40 = btab[64 + cc];
-                            float tv[4] = {c40, c40, c40, c40};
-                            if (edge) {
+                            const int cc = 16 * cq + 8 * half + c8;
+                            bb[half] = btab[cc];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) tvi[half][i] = (CASEB && !EDGE) ? bt9[cc * KS + xcase[i]] : 0.f;
+                        }
+                        // the transposition, one row ahead: row a + 1 goes into the scratch behind the reads of row a (a wave's LDS operations
+                        // complete in order) while row a is finished and stored - one exposed LDS round trip per phase instead of four
+                        f32x4 raw[2][2];
+                        auto put_get = [&](int a) {
+#pragma unroll
+                            for (int hp = 0; hp < 2; ++hp) *reinterpret_cast<f32x4 *>(tsc + l15 * XW_TS + 16 * hp + 4 * kg) = acc[a][hp];
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) raw[a & 1][half] = *reinterpret_cast<const f32x4 *>(tsc + (8 * half + c8) * XW_TS + 4 * q8);
+                        };
+                        put_get(0);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            if (a + 1 < 4) put_get(a + 1);
+                            const int oy = it.ys + 4 * g + a;
+                            const bool rok = oy < it.ye;
+                            const int ycase = EDGE ? xw_border_case(oy < d.H ? oy : d.H - 1, d.H) : XW_P;
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                const int cc = 16 * cq + 8 * half + c8;                   // this lane's cout of the pass
+                                const bool ck = cc < d.cout;
+                                float tv[4];
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    const int xc = xw_border_case(px_ + i < d.W ? px_ + i : d.W - 1, d.W);
-                                    tv[i] = h2_load4(rc, (ck && px_ + i < d.W) ? 4u * (unsigned)(cc * (KS * KS) + ycase * KS + xc) : 0x80000000u, 0u);
+                                    if (CASEB && EDGE) tv[i] = h2_load4(rc, (ck && px_ + i < d.W) ? 4u * (unsigned)(cc * (KS * KS) + ycase * KS + xcase[i]) : 0x80000000u, 0u);
+                                    else tv[i] = tvi[half][i];
                                 }
-                            }
-                            float o[4];
-                            bool near = false;
+                                float o[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                float v = raw[i] * fin + bb;
-                                if (CASEB) v += tv[i];
+                                for (int i = 0; i < 4; ++i) {
+                                    float v = raw[a & 1][half][i] * fin + bb[half];
+                                    if (CASEB) v += tv[i];
+                                    o[i] = v;
+                                }
                                 // a pre-activation this close to zero has no reliable sign in fp32: listed for toep_first_ties_kernel
-                                near = near || fabsf(v) < tau;
-                                o[i] = v;
-                            }
-                            if (TIES && __builtin_amdgcn_ballot_w64(near && rok && ck) != 0) {      // (rare: a wave-uniform test first)
+                                const bool near = TIES && fminf(fminf(fabsf(o[0]), fabsf(o[1])), fminf(fabsf(o[2]), fabsf(o[3]))) < tau;
+                                if (TIES && __builtin_amdgcn_ballot_w64(near && rok && ck) != 0) {      // (rare: a wave-uniform test first)
 #pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (rok && ck && px_ + i < d.W && fabsf(o[i]) < tau) {
-                                        const unsigned slot = atomicAdd(ties, 1u);
-                                        if (slot < max_ties) ties[1 + slot] = tbase + (unsigned)cc * (unsigned)hw + (unsigned)(oy * d.W + px_ + i);   // (< 2^32 outputs: checked by the entry point)
-                                    }
-                            }
+                                    for (int i = 0; i < 4; ++i)
+                                        if (rok && ck && px_ + i < d.W && fabsf(o[i]) < tau) {
+                                            const unsigned idx = tbase + (unsigned)cc * (unsigned)hw + (unsigned)(oy * d.W + px_ + i);   // (< 2^32 outputs: checked by the entry point)
+                                            const unsigned ls = __hip_atomic_fetch_add(tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                            if (ls < (unsigned)XW_TL) {
+                                                tl[1 + ls] = idx;
+                                            } else {                    // the item's list is full (a flat image region): straight to the global list
+                                                const unsigned slot = atomicAdd(ties, 1u);
+                                                if (slot < max_ties) ties[1 + slot] = idx;
+                                            }
+                                        }
+                                }
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) o[i] = o[i] < floor_ ? floor_ : o[i];
-                            const unsigned vo = (rok && ck && px_ < d.W) ? 4u * (unsigned)(oy * d.W + px_) + (unsigned)cc * hw4 : 0x80000000u;
+                                for (int i = 0; i < 4; ++i) o[i] = o[i] < floor_ ? floor_ : o[i];
+                                const unsigned vo = (rok && ck && px_ < d.W) ? 4u * (unsigned)(oy * d.W + px_) + (unsigned)cc * hw4 : 0x80000000u;
 #ifndef XW_NO_STORE
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, o[0]), __builtin_bit_cast(unsigned, o[1]), __builtin_bit_cast(unsigned, o[2]),
-                                                                         __builtin_bit_cast(unsigned, o[3])}, ry, vo, 0u, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, o[0]), __builtin_bit_cast(unsigned, o[1]), __builtin_bit_cast(unsigned, o[2]),
+                                                                             __builtin_bit_cast(unsigned, o[3])}, ry, vo, 0u, 0);
 #else
-                            if (o[0] + o[1] + o[2] + o[3] == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(0u, ry, vo, 0u, 0);
+                                if (o[0] + o[1] + o[2] + o[3] == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(0u, ry, vo, 0u, 0);
 #endif
+                            }
                         }
-                    }
+                    };
+                    if (gedge) epilogue(std::true_type{});
+                    else epilogue(std::false_type{});
                 }
+#else
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    asm volatile("" :: "v"(acc[a][0]), "v"(acc[a][1]));      // (the products stay alive)
+                }
+#endif
                 XWSTAMP(t_epi);
             }
             XW_BARRIER_LDS();
             XWSTAMP(t_wait);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (TIES && wave == 0) {                                        // (behind the last phase's barrier: every append of the item is in LDS)
+            const unsigned all = tl[0], cnt = all < (unsigned)XW_TL ? all : (unsigned)XW_TL;
+            if (cnt) {
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(ties, cnt);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                for (unsigned i = lane; i < cnt; i += 64u)
+                    if (base + i < max_ties) ties[1 + base + i] = tl[1 + i];
+            }
+            if (lane == 0) tl[0] = 0u;                                  // (LDS operations of a wave complete in order; the next item opens with a barrier)
+        }
     }
 #ifdef RISP_XW_STAMPS
     if (lane == 0 && max_ties == 0xABCDu && ties) {      // diagnostic build: cycle shares of a wave's life (tools/xwin_stamps.py)

@@ -4,7 +4,7 @@ import ctypes as C, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 defs = sys.argv[1:] or ['-DRISP_CONV_STAGGER']
-base = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off',
+base = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize',
         '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'reconfigisp_amd/csrc'), '-x', 'hip', '-shared']
 src = [os.path.join(ROOT, 'reconfigisp_amd/csrc', f) for f in ('risp_conv.hip', 'risp_core.cpp')]
 subprocess.check_call(base + ['-o', '/tmp/conv_a.so'] + src)

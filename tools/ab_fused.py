@@ -4,7 +4,7 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 variants = sys.argv[1:] or ['', '-DRISP_FUSED_WAVES=6', '-DRISP_FUSED_WAVES=8']
-base = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off',
+base = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize',
         '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'reconfigisp_amd/csrc'), '-x', 'hip', '-shared']
 core = os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_core.cpp')
 default_src = os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_fused.hip')

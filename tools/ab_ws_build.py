@@ -16,7 +16,7 @@ for i, v in enumerate(variants):
     ws = os.path.join(csrc, 'risp_conv_f16x2_ws.hip')
     if flags and flags[0].startswith('src='):                    # another source file in place of risp_conv_f16x2_ws.hip
         ws, flags = os.path.join(ROOT, flags[0][4:]), flags[1:]
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off',
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize',
                            '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-x', 'hip', '-shared', '-o', so] + flags +
                           [os.path.join(csrc, 'risp_conv_f16x2.hip'), ws, os.path.join(csrc, 'risp_core.cpp')])
     lib = C.CDLL(so)

@@ -14,7 +14,7 @@ n, h, w = (a + [32, 256, 256])[:3] if len(a) >= 3 else (32, 256, 256)
 G = a[3] if len(a) >= 4 else 8
 csrc = os.path.join(ROOT, 'reconfigisp_amd/csrc')
 so = '/tmp/ab_xwin_off.so'
-subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-DRISP_XWIN_OFF',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-DRISP_XWIN_OFF',
                        '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-x', 'hip', '-shared', '-o', so] +
                       [os.path.join(csrc, f) for f in ('risp_conv_toep_first.hip', 'risp_conv_xwin.hip', 'risp_core.cpp')])
 old = C.CDLL(so)
@@ -23,7 +23,7 @@ new = L.load()
 extra = {}
 for i, v in enumerate(variants):
     so_v = '/tmp/ab_xwin_v%d.so' % i
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off'] + v.split() +
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize'] + v.split() +
                           ['-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-x', 'hip', '-shared', '-o', so_v] +
                           [os.path.join(csrc, f) for f in ('risp_conv_toep_first.hip', 'risp_conv_xwin.hip', 'risp_core.cpp')])
     lv = C.CDLL(so_v)

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 so = '/tmp/librisp_stamps.so'
 import glob
 src = glob.glob(os.path.join(ROOT, 'reconfigisp_amd/csrc', '*.hip')) + [os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_core.cpp')]
-subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize',
                        '-DRISP_CONV_STAMPS', '-DRISP_W43_NO_GLDS', '-DRISP_W5_NO_GLDS',      # the stamps live in the register-staged kernels
                        '-I' + os.path.join(ROOT, 'include'),
                        '-I' + os.path.join(ROOT, 'reconfigisp_amd/csrc'), '-x', 'hip', '-shared', '-o', so] + src)

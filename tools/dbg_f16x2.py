@@ -2,7 +2,7 @@ import ctypes as C, os, subprocess, sys, torch
 ROOT='/root/repo'; sys.path.insert(0, ROOT)
 from reconfigisp_amd import lib as L, convnets as CN
 so='/tmp/f16x2_dbg.so'
-subprocess.check_call(['/opt/rocm/bin/hipcc','-O3','-std=c++17','-fPIC','--offload-arch=gfx950','-ffp-contract=off','-I'+ROOT+'/include','-I'+ROOT+'/reconfigisp_amd/csrc','-x','hip','-shared','-o',so,ROOT+'/reconfigisp_amd/csrc/risp_conv_f16x2.hip',ROOT+'/reconfigisp_amd/csrc/risp_core.cpp']+sys.argv[1:])
+subprocess.check_call(['/opt/rocm/bin/hipcc','-O3','-std=c++17','-fPIC','--offload-arch=gfx950','-ffp-contract=off', '-fno-slp-vectorize','-I'+ROOT+'/include','-I'+ROOT+'/reconfigisp_amd/csrc','-x','hip','-shared','-o',so,ROOT+'/reconfigisp_amd/csrc/risp_conv_f16x2.hip',ROOT+'/reconfigisp_amd/csrc/risp_core.cpp']+sys.argv[1:])
 l=C.CDLL(so); l.risp_conv2d_f16x2.restype=C.c_int; l.risp_conv2d_f16x2.argtypes=[C.c_void_p,C.c_void_p]
 torch.manual_seed(0)
 n,h,w,cin,cout=2,16,64,64,64

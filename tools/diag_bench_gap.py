@@ -27,7 +27,7 @@ def timeit(f, reps):
 
 import ctypes as C, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-base = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off',
+base = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize',
         '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'reconfigisp_amd/csrc'), '-x', 'hip', '-shared']
 subprocess.check_call(base + ['-o', '/tmp/f_only.so', os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_fused.hip'),
                               os.path.join(ROOT, 'reconfigisp_amd/csrc/risp_core.cpp')])

@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """GPU box: where the waves of risp_conv2d_tapout (risp_conv_tapout.hip) spend their life - a diagnostic build with in-kernel stamps
-(-DRISP_TO_STAMPS; extra -D flags as arguments).  python tools/tapout_stamps.py [k 9|5] [-D...]"""
+(-DRISP_TO_STAMPS; extra -D flags as arguments).  python tools/tapout_stamps.py [k 9|5] [sums] [-D...]"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from reconfigisp_amd import lib as L, convnets as CN
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-extra = sys.argv[2:]
+SUMS = 'sums' in sys.argv                                # risp_conv2d_tapout_sums (the training launch of config 3) instead
+extra = [a for a in sys.argv[2:] if a != 'sums']
 so = '/tmp/tapout_stamps.so'
 csrc = os.path.join(ROOT, 'reconfigisp_amd/csrc')
-subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-DRISP_TO_STAMPS',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-DRISP_TO_STAMPS',
                        '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-x', 'hip', '-shared', '-o', so] + extra +
                       [os.path.join(csrc, f) for f in ('risp_conv_tapout.hip', 'risp_core.cpp')])
 lib = C.CDLL(so)
@@ -30,12 +31,21 @@ d = L.ConvDesc(N=G * n, H=h, W=w, cin=cin, cout=3, ksize=k, load_mode=0, cin_img
                wpack=packs.data_ptr(), bias=None, cvals=buf.data_ptr(), add=add.data_ptr(), mask=None, y=y.data_ptr())
 d.group_n, d.group_flags, d.wpack_gs, d.bias_gs = n, 0, packs.stride(0) * packs.element_size() // 4, 0
 lib.risp_conv2d_tapout.restype, lib.risp_conv2d_tapout.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_void_p]
+lib.risp_conv2d_tapout_sums.restype, lib.risp_conv2d_tapout_sums.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+lib.risp_conv_tapout_items.restype, lib.risp_conv_tapout_items.argtypes = C.c_int, [C.c_int] * 4
+lib.risp_conv_tapout_seg_rows.restype, lib.risp_conv_tapout_seg_rows.argtypes = C.c_int, [C.c_int] * 3
+if SUMS:
+    seg = lib.risp_conv_tapout_seg_rows(G * n, h, w)
+    ps = torch.empty(G * n, lib.risp_conv_tapout_items(G * n, h, w, seg), 64, device='cuda')
+    run = lambda: lib.risp_conv2d_tapout_sums(C.byref(d), 0, ps.data_ptr(), None)
+else:
+    run = lambda: lib.risp_conv2d_tapout(C.byref(d), 0, None)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(5):
-    assert lib.risp_conv2d_tapout(C.byref(d), 0, None) == 0
+    assert run() == 0
 e0.record()
 for _ in range(20):
-    assert lib.risp_conv2d_tapout(C.byref(d), 0, None) == 0
+    assert run() == 0
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
@@ -49,3 +59,6 @@ print('  consumers: barrier wait %.3f, matrix phase (exponent, operand reads, pr
       % tuple(cons[..., i].sum().item() / cons[..., 3].sum().item() for i in (0, 1, 2)))
 print('  producers: work (stage, maxima, requests, waits for memory) %.3f, barrier wait %.3f of the life'
       % tuple(prod[..., i].sum().item() / prod[..., 3].sum().item() for i in (1, 0)))
+if any(a.startswith('-DTO_PSPLIT') for a in extra):
+    print('  producers, phase start up to the split point (%s): %.0f cycles per chunk; from there to the barrier: %.0f'
+          % ([a for a in extra if a.startswith('-DTO_PSPLIT')][0], prod[..., 2].median().item() / chunks, prod[..., 1].median().item() / chunks))

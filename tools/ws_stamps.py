@@ -10,7 +10,7 @@ mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 extra = sys.argv[2:]
 so = '/tmp/ws_stamps.so'
 csrc = os.path.join(ROOT, 'reconfigisp_amd/csrc')
-subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-DRISP_WS_STAMPS',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-DRISP_WS_STAMPS',
                        '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-x', 'hip', '-shared', '-o', so] + extra +
                       [os.path.join(csrc, f) for f in ('risp_conv_f16x2.hip', 'risp_conv_f16x2_ws.hip', 'risp_core.cpp')])
 lib = C.CDLL(so)

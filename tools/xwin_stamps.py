@@ -8,7 +8,7 @@ import torch
 from reconfigisp_amd import lib as L, convnets as CN
 so = '/tmp/xwin_stamps.so'
 csrc = os.path.join(ROOT, 'reconfigisp_amd/csrc')
-subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-DRISP_XW_STAMPS',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-slp-vectorize', '-DRISP_XW_STAMPS',
                        '-I' + os.path.join(ROOT, 'include'), '-I' + csrc, '-x', 'hip', '-shared', '-o', so] + sys.argv[1:] +
                       [os.path.join(csrc, f) for f in ('risp_conv_toep_first.hip', 'risp_conv_xwin.hip', 'risp_core.cpp')])
 lib = C.CDLL(so)
@@ -40,7 +40,7 @@ t = buf[:nwg * 64].view(nwg, 8, 8).double()
 cons, prod = t[:, :4], t[:, 4:]
 life = cons[..., 4].median().item()
 phases = G * n * ((w + 31) // 32) * (h // 4 + 1) / nwg
-print('9x9 3 -> 64, %d x 3 x %d x %d: %.0f us per launch (stamped build, with the tie-recompute launch); wave life %.0f cycles = %.0f per phase (a team's 216 16x16x32 matrix instructions every other phase = 3456 cycles); clock ~%.2f GHz'
+print('9x9 3 -> 64, %d x 3 x %d x %d: %.0f us per launch (stamped build, with the tie-recompute launch); wave life %.0f cycles = %.0f per phase (the 216 16x16x32 matrix instructions of a team every other phase = 3456 cycles); clock ~%.2f GHz'
       % (G * n, h, w, us, life, life / phases, life / us / 1e3))
 for nm, grp in (('team 0 (waves 0-3)', cons), ('team 1 (waves 4-7)', prod)):
     print('  %s: item preamble (weights, strip maximum) %.3f, barrier wait %.3f, products + expansion of input rows %.3f, epilogue %.3f of the life'
