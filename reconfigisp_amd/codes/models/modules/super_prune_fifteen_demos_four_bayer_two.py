@@ -27,6 +27,7 @@ _POINTWISE = {T.Skip: 'skip', T.WbManual: 'wb_manual', T.Gamma: 'gamma', T.GtmMa
               T.Grayworld: 'grayworld'}
 SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '2'))
 SLOT_STREAMS_MAX_PIXELS = 1 << 40
+SLOT_STREAMS_MIN_PIXELS = 1 << 16           # batch x H x W below which a second stream only adds event traffic (batch 4 of 48 x 48: 22 -> 20 ms per iteration on one)
 SLOT_STREAMS_MIN_JOBS = 3                   # jobs of a slot from which the streams are used
 
 
@@ -197,7 +198,8 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         order.  Measured in round 2 (tools/bench_darts.py, n_step 2, op-by-op jobs): batch 4 0.113 -> 0.097 s per
         iteration, batch 32 0.62 -> 0.60 s; 3 and 4 streams are no faster."""
         pixels = x.shape[0] * x.shape[2] * x.shape[3]
-        n_streams = SLOT_STREAMS if (x.is_cuda and len(jobs) >= SLOT_STREAMS_MIN_JOBS and pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
+        n_streams = SLOT_STREAMS if (x.is_cuda and len(jobs) >= SLOT_STREAMS_MIN_JOBS and
+                                     SLOT_STREAMS_MIN_PIXELS <= pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
         outs = [None] * n_out
         xs = xs if xs is not None else [x] * len(jobs)
         if n_streams <= 1:

@@ -144,7 +144,10 @@ __device__ __forceinline__ void lds_dma16_m(const void *sbase, unsigned voff, un
 inline int risp_bwd_blocks(int N, int HW) {
     const int hw4 = HW / 4;
     int bx = (hw4 + 1023) / 1024;
-    const int want = (512 + N - 1) / (N > 0 ? N : 1);          // ~512 workgroups in flight
+#ifndef RISP_BWD_WGS
+#define RISP_BWD_WGS 512
+#endif
+    const int want = (RISP_BWD_WGS + N - 1) / (N > 0 ? N : 1);          // ~512 workgroups in flight
     if (bx < want) bx = want;
     const int most = (hw4 + 255) / 256;                        // at least one vector per thread
     if (bx > most) bx = most;

@@ -161,13 +161,20 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
         const __amdgpu_buffer_rsrc_t rx = h2_rsrc(xin);
         float va[8], vb[8];
         auto fetch = [&](int b) {                                       // block b: input rows ys - 4 + 4 b + j
-            const int y = it.ys - P + 4 * b + sj;
-            const bool ok = b < nblocks && y >= 0 && y < d.H;
-            const unsigned ro = 4u * (unsigned)(ok ? y * d.W : 0);
+            // (the row is the wave's: its byte offset travels as the load's scalar offset, a row outside the image takes a uniform branch
+            // around the 16 loads.  As a per-lane select of the address hipcc built a divergent branch pair around EVERY load: 144
+            // instructions of the ~450 a serving phase issues beside the other team's products)
+            const int y = it.ys - P + 4 * b + (wave & 3);
+            if (b < nblocks && y >= 0 && y < d.H) {
+                const unsigned ro = 4u * (unsigned)(y * d.W);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {                               // (a valid row + an invalid column stays >= 2^31)
-                va[e] = h2_load4(rx, ok ? ro + offa[e] : 0x80000000u, 0u);
-                vb[e] = h2_load4(rx, ok ? ro + offb[e] : 0x80000000u, 0u);
+                for (int e = 0; e < 8; ++e) {                           // (an invalid column stays >= 2^31: the range check does not see the scalar offset)
+                    va[e] = h2_load4(rx, offa[e], ro);
+                    vb[e] = h2_load4(rx, offb[e], ro);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) va[e] = vb[e] = 0.f;
             }
         };
         auto stage = [&](int b) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
                             const int cc = 16 * cq + 8 * half + c8;
                             bb[half] = btab[cc];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) tvi[half][i] = (CASEB && !EDGE) ? bt9[cc * KS + xcase[i]] : 0.f;
+                            for (int i = 0; i < 4; ++i) tvi[half][i] = bb[half] + ((CASEB && !EDGE) ? bt9[cc * KS + xcase[i]] : 0.f);
                         }
                         // the transposition, one row ahead: row a + 1 goes into the scratch behind the reads of row a (a wave's LDS operations
                         // complete in order) while row a is finished and stored - one exposed LDS round trip per phase instead of four
@@ -325,19 +332,15 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
                             for (int half = 0; half < 2; ++half) {
                                 const int cc = 16 * cq + 8 * half + c8;                   // this lane's cout of the pass
                                 const bool ck = cc < d.cout;
-                                float tv[4];
+                                float tv[4];                    // bias + border-case value
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    if (CASEB && EDGE) tv[i] = h2_load4(rc, (ck && px_ + i < d.W) ? 4u * (unsigned)(cc * (KS * KS) + ycase * KS + xcase[i]) : 0x80000000u, 0u);
+                                    if (CASEB && EDGE) tv[i] = bb[half] + h2_load4(rc, (ck && px_ + i < d.W) ? 4u * (unsigned)(cc * (KS * KS) + ycase * KS + xcase[i]) : 0x80000000u, 0u);
                                     else tv[i] = tvi[half][i];
                                 }
                                 float o[4];
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    float v = raw[a & 1][half][i] * fin + bb[half];
-                                    if (CASEB) v += tv[i];
-                                    o[i] = v;
-                                }
+                                for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(raw[a & 1][half][i], fin, tv[i]);      // (one rounding; the scale is a power of two times 1 / s_w)
                                 // a pre-activation this close to zero has no reliable sign in fp32: listed for toep_first_ties_kernel
                                 const bool near = TIES && fminf(fminf(fabsf(o[0]), fabsf(o[1])), fminf(fabsf(o[2]), fabsf(o[3]))) < tau;
                                 if (TIES && __builtin_amdgcn_ballot_w64(near && rok && ck) != 0) {      // (rare: a wave-uniform test first)

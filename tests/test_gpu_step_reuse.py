@@ -101,3 +101,29 @@ def test_weight_step_without_alpha_gradients_changes_no_result():
     # after the weight step: the lean form leaves alpha.grad at what optimize_alphas set, the reference's form adds d loss / d alpha
     ga, gb = m_lean.netG.alpha_step1.grad, m_full.netG.alpha_step1.grad
     assert ga is not None and gb is not None and not torch.equal(ga, gb)
+
+
+@pytest.mark.filterwarnings('ignore:Detected call of')
+def test_search_iteration_identical_on_one_and_two_slot_streams(monkeypatch):
+    """the ops of a slot on two HIP streams (planes of >= 2^16 pixels by default; forced here on the golden's small planes) against one
+    stream: same kernels, same order of every sum - the same bits (super_prune_fifteen_demos_four_bayer_two.py:_run_jobs)"""
+    from reconfigisp_amd.codes.models.modules import super_prune_fifteen_demos_four_bayer_two as SP
+    assert SP.SLOT_STREAMS == 2 and SP.SLOT_STREAMS_MIN_PIXELS == 1 << 16
+    used = []
+    real = SP.SuperPruneFifteenDemosFourBayerTwo._run_jobs
+
+    def spy(self, jobs, n_out, x, args, xs=None):
+        pixels = x.shape[0] * x.shape[2] * x.shape[3]
+        used.append(len(jobs) >= SP.SLOT_STREAMS_MIN_JOBS and SP.SLOT_STREAMS_MIN_PIXELS <= pixels)
+        return real(self, jobs, n_out, x, args, xs)
+
+    monkeypatch.setattr(SP.SuperPruneFifteenDemosFourBayerTwo, '_run_jobs', spy)
+    one, _, _ = _run(True, iters=1)
+    assert used and not any(used)                                     # the golden's planes are below the threshold: one stream
+    del used[:]
+    monkeypatch.setattr(SP, 'SLOT_STREAMS_MIN_PIXELS', 0)
+    two, _, _ = _run(True, iters=1)
+    assert any(used)
+    assert len(one) == len(two)
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)

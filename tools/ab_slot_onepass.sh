@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for v in "" "$@"; do
   i=$((i + 1))
-  export RISP_HIP_LIBRARY=$(bash "$REPO/tools/build_variant.sh" /tmp/ab_slot_$i "$v" risp_slot.hip) || exit 1
+  export RISP_HIP_LIBRARY=$(bash "$REPO/tools/build_variant.sh" /tmp/ab_slot_$i "$v" ${RISP_AB_SRC:-risp_slot.hip}) || exit 1
   rm -rf /tmp/ab_slot_prof
   RISP_OPS_ONLY=slot RISP_OPS_REPS=24 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_slot_prof -o o -- python3 "$REPO/tools/bench_ops.py" > /tmp/ab_slot.log 2>&1
   echo "== build [$v]"
