@@ -114,7 +114,7 @@ def test_search_iteration_identical_on_one_and_two_slot_streams(monkeypatch):
 
     def spy(self, jobs, n_out, x, args, xs=None):
         pixels = x.shape[0] * x.shape[2] * x.shape[3]
-        used.append(len(jobs) >= SP.SLOT_STREAMS_MIN_JOBS and SP.SLOT_STREAMS_MIN_PIXELS <= pixels)
+        used.append(x.is_cuda and len(jobs) >= SP.SLOT_STREAMS_MIN_JOBS and SP.SLOT_STREAMS_MIN_PIXELS <= pixels)
         return real(self, jobs, n_out, x, args, xs)
 
     monkeypatch.setattr(SP.SuperPruneFifteenDemosFourBayerTwo, '_run_jobs', spy)
@@ -122,6 +122,7 @@ def test_search_iteration_identical_on_one_and_two_slot_streams(monkeypatch):
     assert used and not any(used)                                     # the golden's planes are below the threshold: one stream
     del used[:]
     monkeypatch.setattr(SP, 'SLOT_STREAMS_MIN_PIXELS', 0)
+    monkeypatch.setattr(SP, 'SLOT_STREAMS_MIN_JOBS', 2)               # (grouped launches leave the golden's slots two or three jobs)
     two, _, _ = _run(True, iters=1)
     assert any(used)
     assert len(one) == len(two)
