@@ -27,7 +27,7 @@ _POINTWISE = {T.Skip: 'skip', T.WbManual: 'wb_manual', T.Gamma: 'gamma', T.GtmMa
               T.Grayworld: 'grayworld'}
 SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '2'))
 SLOT_STREAMS_MAX_PIXELS = 1 << 40
-SLOT_STREAMS_MIN_PIXELS = 1 << 16           # batch x H x W below which a second stream only adds event traffic (batch 4 of 48 x 48: 22 -> 20 ms per iteration on one)
+SLOT_STREAMS_MIN_PIXELS = 1 << 16           # batch x H x W below which a second stream buys nothing (batch 4 of 48 x 48: 19-20 ms per iteration either way)
 SLOT_STREAMS_MIN_JOBS = 3                   # jobs of a slot from which the streams are used
 
 
