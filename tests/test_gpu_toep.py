@@ -464,3 +464,33 @@ def test_first_layer_exact_relu_decisions(mosaic, hw):
     L.call('risp_conv2d_toep_first_exact', C.byref(d), C.c_void_p(ws.data_ptr()), ws.stride(0), C.c_void_p(ties.data_ptr()), cap, None)
     torch.cuda.synchronize()
     assert int(ties[0].item()) == 0 and (y == 0).all()
+
+
+def test_first_layer_tie_list_holds_far_more_ties_than_a_workgroup_collects():
+    """the tap-index kernel collects an item's ties in a 511-entry LDS list and hands them over once per item; an item with more ties
+    (here: half of the couts have zero weights and no bias - every one of their pre-activations is an exact zero beside a non-zero
+    input, 40 960 ties per work item) sends the rest straight to the global list: every tie listed exactly once, none invented"""
+    from reconfigisp_amd import convnets as CN, lib as L
+    n, h, w, cout = 2, 40, 72, 64
+    wt = rnd(cout, 3, 9, 9, seed=330) * 0.1
+    wt[1::2] = 0.
+    ws = wt.unsqueeze(0).contiguous()
+    pack = CN.toep_first_weights(wt)
+    x = rnd(n, 3, h, w, seed=331)
+    y = torch.full((n, cout, h, w), float('nan'), device='cuda')
+    d = L.ConvDesc(N=n, H=h, W=w, cin=3, cout=cout, ksize=9, load_mode=0, cin_img=0, epilogue=CN.EPI_RELU | CN.EPI_NOBIAS, add_c=0, x=x.data_ptr(),
+                   wpack=pack.data_ptr(), bias=None, cvals=None, add=None, mask=None, y=y.data_ptr())
+    cap = 1 << 20
+    ties = torch.full((1 + cap,), -1, device='cuda', dtype=torch.int32)
+    L.call('risp_conv2d_toep_first_exact', C.byref(d), C.c_void_p(ws.data_ptr()), 0, C.c_void_p(ties.data_ptr()), cap, None)
+    torch.cuda.synchronize()
+    count = int(ties[0].item())
+    zero_outputs = n * (cout // 2) * h * w
+    assert zero_outputs <= count < zero_outputs + 1000, (count, zero_outputs)          # + the few genuine near-zeros of the other couts
+    idx = ties[1:1 + count].long()
+    assert idx.unique().numel() == count
+    listed = torch.zeros(y.numel(), dtype=torch.bool, device='cuda')
+    listed[idx] = True
+    assert listed.view(n, cout, h, w)[:, 1::2].all()
+    ref = torch.relu(TF.conv2d(x.double(), wt.double(), padding=4))
+    assert (y[:, 1::2] == 0).all() and err(y, ref)[1] < 3e-6
