@@ -258,6 +258,18 @@ int risp_conv_wino43_chunk(void);
 size_t risp_conv_wino43_wpack_floats(int cin, int cout);
 int risp_conv2d_wino43(const risp_conv_desc *d, void *stream);
 
+/* The same operator for 5x5 layers with at most 3 INPUT channels and 32 or 64 output channels in split precision on the f16 matrix
+ * pipe (round 6, risp_conv_thin5.hip): the backward-data pass of SRCNNRes' last layer (srcnn_res_arch.py:22 - the upstream gradient's 3
+ * image channels -> 32 hidden channels, masked by the ReLU of the layer before, :20), which the fp32 Winograd kernel served at 4 padded
+ * channels.  Reduction index of a matrix instruction = (filter row, channel): 15 of 16 slots; the filter column shifts the pixel operand.
+ * wpack (risp_conv_thin5_wpack_bytes(cout) bytes, 16-byte aligned): a 16-byte header whose first float is 1 / s_w, then [cout block of
+ * 32][kx][part: hi, lo][half of the reduction index][cout][8] halves of w * s_w, reduction index k = 3 ky + c (k = 15 and missing
+ * channels zero) - the layer's weights w[co][c][ky][kx] (backward-data: the forward weight with roles swapped and taps rotated by 180
+ * degrees).  load_mode PLAIN; epilogue RELU | MASK | NOBIAS; cout * H * W * 4 < 2^31; any W; grouped launches.  One scale per work item
+ * (image, 128-column strip, 32-row segment): a result does not depend on the batch; every sum in a fixed order. */
+size_t risp_conv_thin5_wpack_bytes(int cout);
+int risp_conv2d_thin5(const risp_conv_desc *d, void *stream);
+
 /* The same operator for the FIRST layers of the proxies - few input channels, the whole weight matrix staged once per
  * workgroup - with a LINEAR reduction index k = (ci * ksize + ky) * ksize + kx, so that the matrix instruction's two k-slots
  * hold consecutive k (3 channels of a 9x9 layer: 122 instructions per tile instead of the 162 that channel PAIRS cost in

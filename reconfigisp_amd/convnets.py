@@ -182,6 +182,32 @@ def toep_first_weights(w):
     return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
 
 
+def thin5_weights(w, transpose=False):
+    """Pre-split pack of ``risp_conv2d_thin5`` (include/risp.h) from a 5x5 layer's (cout 32 | 64, cin <= 3, 5, 5) tensor: a 16-byte header
+    whose first float is 1 / s_w, then [cout block of 32][kx][part: hi, lo][half of the reduction index][cout][8] halves of w * s_w with the
+    reduction index k = 3 ky + c (k = 15 and missing channels zero) - (filter row, channel) pairs fill the 16 reduction slots of one matrix
+    instruction, the filter column shifts the pixel operand.  ``transpose``: the backward-data layer of a FORWARD (cin <= 3 couts, cout,
+    5, 5) weight (roles swapped, taps rotated by 180 degrees).  Scale and split as in ``f16x2_weights``.  Returns a float16 tensor."""
+    if transpose:
+        w = w.flip(2, 3).transpose(0, 1)
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    if k != 5 or ci > 3 or co not in (32, 64):
+        raise ValueError('thin-input pack: a 5x5 layer with at most 3 input and 32 or 64 output channels, got %dx%d %d -> %d' % (k, k, ci, co))
+    _, e = torch.frexp(w.detach().abs().max())
+    sw = torch.ldexp(torch.ones((), device=w.device), 15 - e)
+    ws = w.detach().float() * sw
+    hi = ws.half()
+    parts = (hi, (ws - hi.float()).half())
+    p = torch.zeros((2, co, k, 16), device=w.device, dtype=torch.float16)                   # (part, cout, kx, 3 ky + c)
+    for part in range(2):
+        p[part][:, :, :15].view(co, k, k, 3)[..., :ci] = parts[part].permute(0, 3, 2, 1)   # (cout, kx, ky, c)
+    #       (part, block, m, kx, half, 8) -> (block, kx, part, half, m, 8)
+    p = p.view(2, co // 32, 32, k, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+    hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
+    hdr[0] = 1.0 / sw
+    return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
+
+
 # Arithmetic of the wide hidden layers (3x3, cin % 16 == 0, cout 32 / 64): 'f16x2' (default) = split precision on the f16 matrix
 # pipe - each fp32 operand as two f16 halves, three products, fp32 accumulation (risp_conv2d_f16x2: fp32 tensors in and out,
 # error against float64 no larger than the fp32 kernels'); 'f32' = the fp32 matrix-core kernels (Winograd F(4,3) / F(2,3)).
@@ -258,6 +284,8 @@ def pack_kinds(k, cin, cout, transpose=False):
         have.append('wino45')
     if k in (3, 5) and c_in % 16 == 0 and c_out in (32, 64):
         have.append('f16x2')
+    if k == 5 and c_in <= 3 and c_out in (32, 64):             # split precision for 5x5 layers with at most 3 input channels (risp_conv_thin5.hip)
+        have.append('thin5')
     if k in (3, 9) and cin in (3, 4) and cout <= 64:           # first layers (forward geometry; route() uses them forward only)
         have.append('k3')
     if k == 9 and cin in (3, 4):
@@ -310,6 +338,8 @@ class PackedConv:
             # split-precision packs (see CONV_ARITH); either direction on its own
             'f16x2_fwd': lambda: f16x2_weights(w, False) if 'f16x2' in kf else None,
             'f16x2_bwd': lambda: f16x2_weights(w, True) if 'f16x2' in kb else None,
+            'thin5_fwd': lambda: thin5_weights(w, False) if 'thin5' in kf else None,
+            'thin5_bwd': lambda: thin5_weights(w, True) if 'thin5' in kb else None,
             # first layers (3 plain or 4 space-to-depth input channels): the linear-k kernel, risp_conv_k3.hip
             'k3': lambda: k3_weights(w) if 'k3' in kf else None,
             # ... and the 9x9 ones on the f16 matrix pipe in split precision, risp_conv_toep_first.hip
@@ -539,6 +569,8 @@ def route(k, cin, cout, h, w, transpose=False, load=LOAD_PLAIN, epi=0, add_c=0, 
          through risp_conv2d_toep_first_exact), otherwise -> risp_conv2d_k3 (fp32, linear reduction index);
       2. wide 3x3 / 5x5 layers (cin % 16 == 0, cout 32 or 64, plain load, epilogue within RELU | ADD | MASK | NOBIAS with a full-width
          residual, addressable through 2^31-byte buffers) under f16x2 -> risp_conv2d_f16x2 (split precision, f16 matrix pipe);
+      2b. 5x5 with at most 3 input channels and 32 / 64 couts (the backward-data pass of a proxy's 3-cout tail), plain loads, epilogue
+         within RELU | MASK | NOBIAS, under f16x2 -> risp_conv2d_thin5 (split precision; (filter row, channel) as the reduction index);
       3. 3x3 with the plain-16 conditions -> risp_conv2d_wino43 (fp32 F(4,3)); 5x5 with cin % 4 == 0 or cin < 4 -> risp_conv2d_wino45;
       4. everything else -> risp_conv2d (fp32 matrix cores, direct).
     (Layers with at most 12 output channels never come here: ``conv_small`` / ``route_small``.)"""
@@ -553,6 +585,9 @@ def route(k, cin, cout, h, w, transpose=False, load=LOAD_PLAIN, epi=0, add_c=0, 
     if (CONV_ARITH == 'f16x2' and 'f16x2' in have and plain16 and (not (epi & EPI_ADD) or add_c == cout)
             and f16x2_addressable(cin, cout, h, w)):
         return 'risp_conv2d_f16x2'
+    if (CONV_ARITH == 'f16x2' and 'thin5' in have and load == LOAD_PLAIN and not (epi & ~(EPI_RELU | EPI_MASK | EPI_NOBIAS)) and aligned
+            and w % 4 == 0 and cout * h * w * 4 < (1 << 31)):
+        return 'risp_conv2d_thin5'
     if k == 3 and 'wino43' in have and plain16:
         return 'risp_conv2d_wino43'
     if k == 5 and 'wino45' in have and plain16:
@@ -566,7 +601,7 @@ def _have(pc, transpose):
     sfx = '_bwd' if transpose else '_fwd'
     held = pc.__dict__
     kinds = pack_kinds(pc.k, pc.cin, pc.cout, transpose)
-    have = [name for name in ('wino43', 'wino45', 'f16x2') if name in kinds and held.get(name + sfx, 1) is not None]
+    have = [name for name in ('wino43', 'wino45', 'f16x2', 'thin5') if name in kinds and held.get(name + sfx, 1) is not None]
     return have + [name for name in ('k3', 'toep_first') if name in kinds and held.get(name, 1) is not None]
 
 
@@ -598,6 +633,7 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     sfx = '_bwd' if transpose else '_fwd'
     wpack = {'risp_conv2d_k3': lambda: pc.k3, 'risp_conv2d_toep_first': lambda: pc.toep_first,
              'risp_conv2d_toep_first_exact': lambda: pc.toep_first, 'risp_conv2d_f16x2': lambda: getattr(pc, 'f16x2' + sfx),
+             'risp_conv2d_thin5': lambda: getattr(pc, 'thin5' + sfx),
              'risp_conv2d_wino43': lambda: getattr(pc, 'wino43' + sfx), 'risp_conv2d_wino45': lambda: getattr(pc, 'wino45' + sfx),
              'risp_conv2d': lambda: pc.bwd if transpose else pc.fwd}[entry]()
     d = L.ConvDesc(N=n, H=h, W=w, cin=cin, cout=cout, ksize=pc.k, load_mode=load, cin_img=cin_img,
@@ -612,6 +648,9 @@ def conv(x, pc, n, h, w, transpose=False, load=LOAD_PLAIN, cin_img=0, cvals=None
     if entry == 'risp_conv2d_f16x2':
         if MFMA_ISSUED_F16 is not None:
             MFMA_ISSUED_F16[0] += 3 * 2.0 * pc.k * pc.k * cin * cout * nn_ * h * w
+    elif entry == 'risp_conv2d_thin5':
+        if MFMA_ISSUED_F16 is not None:                # per filter column: 3 products of 16 (filter row, channel) slots x 32 couts per pixel
+            MFMA_ISSUED_F16[0] += 3 * 2.0 * 5 * 16 * cout * nn_ * h * w
     elif entry.startswith('risp_conv2d_toep_first'):
         if MFMA_ISSUED_F16 is not None:
             MFMA_ISSUED_F16[0] += first_layer_issued(cin, cout, h, w, load == LOAD_UNSHUFFLE2) * nn_ * h * w
@@ -1020,7 +1059,7 @@ class _Stacked:
 
 
 def stack_packed(pcs):
-    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd', 'toep_first', 'w32'),
+    return _Stacked(pcs, ('fwd', 'bwd', 'bias', 'k3', 'wino45_fwd', 'wino45_bwd', 'f16x2_fwd', 'f16x2_bwd', 'thin5_fwd', 'thin5_bwd', 'toep_first', 'w32'),
                     ('cin', 'cout', 'k'))
 
 

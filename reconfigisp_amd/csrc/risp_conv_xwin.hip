@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
                             const int cc = 16 * cq + 8 * half + c8;
                             bb[half] = btab[cc];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) tvi[half][i] = bb[half] + ((CASEB && !EDGE) ? bt9[cc * KS + xcase[i]] : 0.f);
+                            for (int i = 0; i < 4; ++i) tvi[half][i] = (CASEB && !EDGE) ? bt9[cc * KS + xcase[i]] : 0.f;
                         }
                         // the transposition, one row ahead: row a + 1 goes into the scratch behind the reads of row a (a wave's LDS operations
                         // complete in order) while row a is finished and stored - one exposed LDS round trip per phase instead of four
@@ -332,15 +332,19 @@ __global__ __launch_bounds__(512, 2) void conv_xwin_kernel(const risp_conv_desc 
                             for (int half = 0; half < 2; ++half) {
                                 const int cc = 16 * cq + 8 * half + c8;                   // this lane's cout of the pass
                                 const bool ck = cc < d.cout;
-                                float tv[4];                    // bias + border-case value
+                                float tv[4];
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    if (CASEB && EDGE) tv[i] = bb[half] + h2_load4(rc, (ck && px_ + i < d.W) ? 4u * (unsigned)(cc * (KS * KS) + ycase * KS + xcase[i]) : 0x80000000u, 0u);
+                                    if (CASEB && EDGE) tv[i] = h2_load4(rc, (ck && px_ + i < d.W) ? 4u * (unsigned)(cc * (KS * KS) + ycase * KS + xcase[i]) : 0x80000000u, 0u);
                                     else tv[i] = tvi[half][i];
                                 }
                                 float o[4];
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(raw[a & 1][half][i], fin, tv[i]);      // (one rounding; the scale is a power of two times 1 / s_w)
+                                for (int i = 0; i < 4; ++i) {      // (product, + bias, + border-case value: each rounded - the order of the band kernel; a fused
+                                    float v = raw[a & 1][half][i] * fin + bb[half];      // form moved darts_step_kf5's it0_alpha_grad1 across its 6.1e-6 budget)
+                                    if (CASEB) v += tv[i];
+                                    o[i] = v;
+                                }
                                 // a pre-activation this close to zero has no reliable sign in fp32: listed for toep_first_ties_kernel
                                 const bool near = TIES && fminf(fminf(fabsf(o[0]), fabsf(o[1])), fminf(fabsf(o[2]), fabsf(o[3]))) < tau;
                                 if (TIES && __builtin_amdgcn_ballot_w64(near && rok && ck) != 0) {      // (rare: a wave-uniform test first)

@@ -392,3 +392,41 @@ def test_f16x2_buffer_offsets_stay_inside_the_resource():
     assert not CN.f16x2_addressable(64, 64, 2048, 4096)               # exactly 2^31
     assert not CN.f16x2_addressable(64, 64, 3000, 4000)               # the frame of test_split.py, untiled
     assert not CN.f16x2_addressable(64, 32, 3000, 4000)
+
+
+@pytest.mark.parametrize('co,ci,tr', [(32, 3, False), (64, 2, False), (32, 3, True), (64, 1, True)])
+def test_thin_input_pack_reproduces_the_convolution(co, ci, tr):
+    """convnets.thin5_weights: header = 1 / s_w, body [cout block][kx][hi, lo][half of the reduction index][cout][8] with the reduction
+    index k = 3 ky + c.  As the kernel consumes it: out[co][y][x] = sum_kx sum_k W[co][kx][k] E[y][x + kx - 2][k], E[y][x'][3 ky + c] =
+    in[c][y + ky - 2][x'] - the whole convolution (or the backward-data one of the transposed pack)."""
+    torch.manual_seed(co + ci)
+    w = torch.randn(co, ci, 5, 5) * 0.05 if not tr else torch.randn(ci, co, 5, 5) * 0.05
+    p = CN.thin5_weights(w, tr)
+    nb = co // 32
+    assert p.dtype == torch.float16 and p.numel() == 8 + nb * 5 * 2 * 2 * 32 * 8
+    inv = p[:2].view(torch.float32).item()
+    wt = w.flip(2, 3).transpose(0, 1) if tr else w
+    sw = 1.0 / inv
+    assert 2.0 ** 14 <= wt.abs().max().item() * sw < 2.0 ** 15 and sw == 2.0 ** round(np.log2(sw))
+    body = p[8:].view(nb, 5, 2, 2, 32, 8).double()
+    #     (block, kx, half, m, 8) -> W[cout = 32 block + m][kx][k = 8 half + e]
+    W = ((body[:, :, 0] + body[:, :, 1]) * inv).permute(0, 3, 1, 2, 4).reshape(co, 5, 16)
+    assert W[:, :, 15].abs().max().item() == 0
+    if ci < 3:
+        assert W[:, :, :15].view(co, 5, 5, 3)[..., ci:].abs().max().item() == 0
+    h, wd = 9, 14
+    x = torch.randn(2, ci, h, wd, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(x, wt.double(), padding=2)
+    xp = torch.nn.functional.pad(x, (2, 2, 2, 2))
+    E = torch.zeros(2, h, wd + 4, 16, dtype=torch.float64)
+    for ky in range(5):
+        for c in range(ci):
+            E[:, :, :, 3 * ky + c] = xp[:, c, ky:ky + h, :]
+    out = torch.zeros(2, co, h, wd, dtype=torch.float64)
+    for kx in range(5):
+        out += torch.einsum('ok,nyxk->noyx', W[:, kx], E[:, :, kx:kx + wd])
+    assert (out - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        CN.thin5_weights(torch.randn(32, 4, 5, 5))
+    with pytest.raises(ValueError):
+        CN.thin5_weights(torch.randn(16, 3, 5, 5))

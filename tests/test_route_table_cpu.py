@@ -20,7 +20,8 @@ CONV = {
     ('srcnn_res', '9x9 3->64 first', 'fwd'): ((9, 3, 64, False, PLAIN, R | CB, 0), {'train': 'risp_conv2d_toep_first_exact', 'infer': 'risp_conv2d_toep_first', 'f32': 'risp_conv2d_k3'}),
     ('srcnn_res', '5x5 64->32', 'fwd'): ((5, 64, 32, False, PLAIN, R, 0), {'train': 'risp_conv2d_f16x2', 'infer': 'risp_conv2d_f16x2', 'f32': 'risp_conv2d_wino45'}),
     ('srcnn_res', '5x5 64->32', 'bwd'): ((5, 64, 32, True, PLAIN, M | NB, 0), {'train': 'risp_conv2d_f16x2', 'f32': 'risp_conv2d_wino45'}),
-    ('srcnn_res', '5x5 32->3 last', 'bwd'): ((5, 32, 3, True, PLAIN, M | NB, 0), {'train': 'risp_conv2d_wino45', 'f32': 'risp_conv2d_wino45'}),
+    # (round 6: 3 input channels as (filter row, channel) pairs in ONE matrix instruction's reduction index, split precision - it was the fp32 F(4,5) kernel on 4 padded channels)
+    ('srcnn_res', '5x5 32->3 last', 'bwd'): ((5, 32, 3, True, PLAIN, M | NB, 0), {'train': 'risp_conv2d_thin5', 'f32': 'risp_conv2d_wino45'}),
     # the unfolded form (_SrcnnRes / _SrcnnResTrain: 12 + P input channels with constant planes)
     ('srcnn_res', '9x9 17->64 unfolded', 'fwd'): ((9, 17, 64, False, CN.LOAD_CONSTCH, R, 0), {'train': 'risp_conv2d', 'infer': 'risp_conv2d', 'f32': 'risp_conv2d'}),
     ('srcnn_res', '9x9 17->64 unfolded', 'bwd'): ((9, 17, 64, True, PLAIN, A | NB, 3), {'train': 'risp_conv2d', 'f32': 'risp_conv2d'}),

@@ -11,6 +11,10 @@ if os.environ.get('RISP_BENCH_NO_TAPOUT') == '1':          # A/B on one box: the
     import reconfigisp_amd.convnets as CN
     CN.small_has_tapout = lambda *a: False
 
+if os.environ.get('RISP_BENCH_NO_THIN5') == '1':           # A/B on one box: the 5x5 3 -> 32 backward-data layers on the fp32 F(4,5) kernel of round 5
+    import reconfigisp_amd.convnets as CN
+    _kinds = CN.pack_kinds
+    CN.pack_kinds = lambda *a, **k: [x for x in _kinds(*a, **k) if x != 'thin5']
 if os.environ.get('RISP_BENCH_STREAM_PIXELS'):             # A/B: planes from which the ops of a slot use two streams (product: 2^16 pixels)
     from reconfigisp_amd.codes.models.modules import super_prune_fifteen_demos_four_bayer_two as SP
     SP.SLOT_STREAMS_MIN_PIXELS = int(os.environ['RISP_BENCH_STREAM_PIXELS'])
