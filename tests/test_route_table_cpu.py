@@ -98,6 +98,10 @@ def test_useful_over_issued_products_of_the_few_channel_kernels():
     assert CN.first_layer_form(3, 64, 256, 256, True) == 'band' and abs(useful / CN.first_layer_issued(3, 64, 256, 256, True) - 0.5625) < 1e-9
     assert CN.first_layer_form(3, 64, 3000, 4000) == 'band' and CN.first_layer_form(4, 64, 256, 256) == 'band'
     assert abs(3 * 2.0 * 81 * 3 * 32 / CN.first_layer_issued(3, 32, 256, 256) - 0.42) < 0.005      # 32 couts: half the rows carry zeros
+    # 5x5 3 -> 32 backward-data: (filter row, channel) pairs in one instruction's 16 reduction slots, 5 instructions x 3 products per pixel
+    assert abs(3 * 2.0 * 25 * 3 * 32 / (3 * 2.0 * 5 * 16 * 32) - 0.9375) < 1e-9
+    assert 'thin5' in CN.pack_kinds(5, 32, 3, True) and 'thin5' not in CN.pack_kinds(5, 32, 3, False) and 'thin5' in CN.pack_kinds(5, 3, 64, False)
+    assert 'thin5' not in CN.pack_kinds(5, 32, 4, True) and 'thin5' not in CN.pack_kinds(3, 32, 3, True)
     # the layers that stay on the band form: 4 couts (36 rows do not fit 32), 12 couts, channel counts that are no multiple of 16
     assert not CN.small_has_tapout(9, 64, 4) and not CN.small_has_tapout(5, 32, 12) and not CN.small_has_tapout(5, 7, 1)
     assert CN.small_has_tapout(9, 64, 3) and CN.small_has_tapout(5, 32, 3) and CN.small_has_tapout(5, 16, 1)

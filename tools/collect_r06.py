@@ -76,7 +76,7 @@ heads = {
     'small_batch.log': (TAG + '_small_batch_search_step.txt', '# tools/profile_r06.sh (profile_darts.sh r06_b4 4 2 10 + step_launches.py): the search step at the per-rank batch of the 8-GPU configuration (4 images, n_step 2)'),
     'shipped_geometry.log': (TAG + '_shipped_geometry_search_step.txt', "# tools/profile_r06.sh (profile_darts.sh r06_ship 4 3 20 48 + step_launches.py + host_profile_darts.py): the search step at the geometry the reference's search YAMLs ship (batch 4 of 48 x 48, n_step 3): launches per iteration, kernel time, wall time, host profile"),
     'batch32_nstep2.log': (TAG + '_batch32_search_step.txt', "# tools/profile_r06.sh (profile_darts.sh r06_b32 32 2 3): config 4's network at the global batch of 32 on one GPU"),
-    'few_channel_same_box.log': (TAG + '_few_channel_same_box.txt', "# tools/profile_r06.sh section 3: the search step with this round's few-channel kernels against round 5's Toeplitz-band kernels on the SAME box, alternating runs (RISP_BENCH_NO_TAPOUT=1 + a -DRISP_XWIN_OFF build of the library in /tmp): config 3 (batch 32, n_step 3), then the rank-of-8 shard (batch 4, n_step 2)"),
+    'few_channel_same_box.log': (TAG + '_few_channel_same_box.txt', "# tools/profile_r06.sh section 3: the search step with this round's few-channel kernels against round 5's Toeplitz-band kernels on the SAME box, alternating runs (RISP_BENCH_NO_TAPOUT=1 RISP_BENCH_NO_THIN5=1 + a -DRISP_XWIN_OFF build of the library in /tmp): config 3 (batch 32, n_step 3) against the round-5 kernels, then with and without risp_conv2d_thin5 alone (RISP_BENCH_NO_THIN5=1), then the rank-of-8 shard (batch 4, n_step 2)"),
     'f32_arith_same_box.log': (TAG + '_f32_arith_same_box.txt', '# tools/profile_r06.sh: RISP_CONV_ARITH=f32 (the fp32 matrix-core kernels) on the same box, wall time: config 3, the rank-of-8 shard, config 5'),
     'few_channel_ladder.txt': (TAG + '_few_channel_ladder.txt', "# tools/profile_r06.sh section 6: risp_conv2d_tapout (filter rows in the rows of the matrix instruction) and the tap-index first layer (risp_conv_xwin.hip) against the Toeplitz-band kernels they replace,\n# interleaved rounds in one process (tools/ab_tapout.py, tools/ab_xwin.py: grouped launches of 8 members x 32 / 4 images of 256 x 256 and 4 of 48 x 48), then in-kernel stamps (tools/tapout_stamps.py, tools/xwin_stamps.py)"),
     'ws_ladder.txt': (TAG + '_ws_ladder.txt', '# tools/profile_r06.sh section 6: risp_conv2d_f16x2 (wave-specialised) against risp_conv2d_f16x2_uniform (the round-4 kernel), interleaved rounds in one process (tools/ab_ws.py)'),
@@ -122,7 +122,8 @@ open('profiles/%s_conv_pmc.txt' % TAG, 'w').write(
     + pmc_block(R + '/conv_pmc_5x5.txt', '5x5 64->32, conv_f16x2_ws_kernel<5, 1>')
     + hbm_block(R + '/conv_pmc_first.txt', '9x9 3->64 first layer, grouped 8 x 32: conv_xwin_kernel (risp_conv_xwin.hip)', (64.0 * PIX + 3 * PIX / 8) * 4)
     + hbm_block(R + '/conv_pmc_bwd9.txt', '9x9 64->3 backward-data + residual, grouped 8 x 32: conv_tapout_kernel<9, ...> (risp_conv_tapout.hip)', (64.0 + 6) * PIX * 4)
-    + hbm_block(R + '/conv_pmc_fwd5.txt', '5x5 32->3 forward + residual, grouped 8 x 32: conv_tapout_kernel<5, ...>', (32.0 + 6) * PIX * 4))
+    + hbm_block(R + '/conv_pmc_fwd5.txt', '5x5 32->3 forward + residual, grouped 8 x 32: conv_tapout_kernel<5, ...>', (32.0 + 6) * PIX * 4)
+    + hbm_block(R + '/conv_pmc_bwd5.txt', '5x5 3->32 backward-data with a ReLU mask, grouped 8 x 32: conv_thin5_kernel (risp_conv_thin5.hip)', (3.0 + 64) * PIX * 4))
 if os.path.exists('gpurun_out/ops_r06/summary.txt'):
     shutil.copy('gpurun_out/ops_r06/summary.txt', 'profiles/%s_ops_kernel_stats.txt' % TAG)
 print('profiles/%s_* refreshed' % TAG)

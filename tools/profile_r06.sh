@@ -26,13 +26,18 @@ if want 3; then   # search step: BASELINE config 3, the per-rank batch of config
   timeout 600 bash "$REPO/tools/profile_darts.sh" r06_b32 32 2 3 > "$OUT/batch32_nstep2.log" 2>&1
   # ... the round-5 few-channel kernels (Toeplitz bands) against this round's on the same box, alternating: config 3 and the rank-of-8 shard
   OLD=$(bash "$REPO/tools/build_variant.sh" /tmp/r06_xwin_off "-DRISP_XWIN_OFF" risp_conv_toep_first.hip)
+  python3 "$REPO/tools/bench_darts.py" 32 256 3 1 > /dev/null 2>&1          # (warm the box: the first process after an idle period measures slow)
   { for r in 1 2 3; do
       echo -n "round 6 kernels        : "; python3 "$REPO/tools/bench_darts.py" 32 256 3 2 2>&1 | tail -1
-      echo -n "round 5 band kernels   : "; RISP_BENCH_NO_TAPOUT=1 RISP_HIP_LIBRARY=$OLD python3 "$REPO/tools/bench_darts.py" 32 256 3 2 2>&1 | tail -1
+      echo -n "round 5 kernels        : "; RISP_BENCH_NO_TAPOUT=1 RISP_BENCH_NO_THIN5=1 RISP_HIP_LIBRARY=$OLD python3 "$REPO/tools/bench_darts.py" 32 256 3 2 2>&1 | tail -1
+    done
+    for r in 1 2 3; do
+      echo -n "round 6 kernels        : "; python3 "$REPO/tools/bench_darts.py" 32 256 3 2 2>&1 | tail -1
+      echo -n "... without thin5      : "; RISP_BENCH_NO_THIN5=1 python3 "$REPO/tools/bench_darts.py" 32 256 3 2 2>&1 | tail -1
     done
     for r in 1 2; do
       echo -n "round 6 kernels        : "; python3 "$REPO/tools/bench_darts.py" 4 256 2 8 2>&1 | tail -1
-      echo -n "round 5 band kernels   : "; RISP_BENCH_NO_TAPOUT=1 RISP_HIP_LIBRARY=$OLD python3 "$REPO/tools/bench_darts.py" 4 256 2 8 2>&1 | tail -1
+      echo -n "round 5 kernels        : "; RISP_BENCH_NO_TAPOUT=1 RISP_BENCH_NO_THIN5=1 RISP_HIP_LIBRARY=$OLD python3 "$REPO/tools/bench_darts.py" 4 256 2 8 2>&1 | tail -1
     done; } > "$OUT/few_channel_same_box.log" 2>&1
   # ... and the fp32 arithmetic on the same box, wall time only
   { RISP_CONV_ARITH=f32 python3 "$REPO/tools/bench_darts.py" 32 256 3 2 2>&1 | tail -1; RISP_CONV_ARITH=f32 python3 "$REPO/tools/bench_darts.py" 4 256 2 8 2>&1 | tail -1; RISP_CONV_ARITH=f32 python3 "$REPO/tools/bench_split.py" 16 2>&1 | tail -1; } > "$OUT/f32_arith_same_box.log" 2>&1
@@ -50,6 +55,7 @@ if want 5; then   # counters: the 64 -> 64 3x3 and 5x5 64 -> 32 layers (wave-spe
   RISP_PMC_KERNELS=conv_xwin timeout 600 bash "$REPO/tools/conv_pmc.sh" r06_first first > "$OUT/conv_pmc_first.txt" 2>&1
   RISP_PMC_KERNELS=conv_tapout timeout 600 bash "$REPO/tools/conv_pmc.sh" r06_bwd9 bwd9 > "$OUT/conv_pmc_bwd9.txt" 2>&1
   RISP_PMC_KERNELS=conv_tapout timeout 600 bash "$REPO/tools/conv_pmc.sh" r06_fwd5 fwd5 > "$OUT/conv_pmc_fwd5.txt" 2>&1
+  RISP_PMC_KERNELS=conv_thin5 timeout 600 bash "$REPO/tools/conv_pmc.sh" r06_bwd5 bwd5 > "$OUT/conv_pmc_bwd5.txt" 2>&1
   unset RISP_PMC_PROG RISP_PMC_HBM
 fi
 if want 6; then   # this round's few-channel kernels against the Toeplitz-band kernels they replace (interleaved rounds, one process), and where their waves' time goes
@@ -60,6 +66,7 @@ if want 6; then   # this round's few-channel kernels against the Toeplitz-band k
     python3 "$REPO/tools/ab_xwin.py" 2>&1 | grep "band"
     python3 "$REPO/tools/ab_xwin.py" 4 256 256 2>&1 | grep "band"
     python3 "$REPO/tools/ab_xwin.py" 4 48 48 2>&1 | grep "band"
+    for r in 1 2; do python3 "$REPO/tools/few_channel_bench.py" bwd5 2>&1 | tail -1; RISP_FCB_WINO=1 python3 "$REPO/tools/few_channel_bench.py" bwd5 2>&1 | tail -1 | sed 's/^bwd5/bwd5 (fp32 F(4,5) kernel)/'; done
     python3 "$REPO/tools/tapout_stamps.py" 2>&1 | tail -12
     python3 "$REPO/tools/xwin_stamps.py" 2>&1 | tail -12
   } > "$OUT/few_channel_ladder.txt" 2>&1
