@@ -346,6 +346,22 @@ def search_opt(n_step, distributed):
                                   lr_gamma=0.5, clear_state=False))
 
 
+def _family(name, args):
+    """kernel family of a C-ABI call (the convolution entries by their descriptor's filter size)"""
+    k = 0
+    if name.startswith('risp_conv2d') and args and hasattr(args[0], '_obj'):
+        k = getattr(args[0]._obj, 'ksize', 0)
+    if name in ('risp_conv2d_f16x2', 'risp_conv2d_f16x2_uniform'):
+        return 'wide %dx%d layers (split precision)' % (k, k)
+    if name.startswith(('risp_conv2d_tapout', 'risp_conv2d_toep', 'risp_conv2d_thin5')):
+        return 'few-channel layer ends (split precision)'
+    if name.startswith('risp_conv') or name.startswith('risp_rect_sums') or name.startswith('risp_srcnn') or name == 'risp_group_sum':
+        return 'other convolution launches (fp32 kernels, sums for the constant planes)'
+    if name.startswith(('risp_slot', 'risp_mix', 'risp_chain', 'risp_prune', 'risp_param_blocks')) or name.endswith(('_fwd', '_bwd')):
+        return 'slot mixtures and element-wise operators'
+    return 'step glue (losses, virtual step, optimizers, reductions)'
+
+
 def search_step_times(device, rank, world, distributed, global_batch, size, n_step, iters, counts=None):
     """Seconds per DARTS iteration (train.py's loop body: feed_data, update_learning_rate, optimize_alphas,
     optimize_parameters) on this rank's shard of the global batch, and the seconds of it spent inside the gradient
@@ -403,6 +419,28 @@ def search_step_times(device, rank, world, distributed, global_batch, size, n_st
             counts.update(f32_flop=CN.MFMA_ISSUED[0], f16_flop=CN.MFMA_ISSUED_F16[0], c_abi_calls=sum(L.CALLS.values()))
         finally:
             CN.MFMA_ISSUED = CN.MFMA_ISSUED_F16 = L.CALLS = None
+        if counts.get('families'):
+            # one more iteration with every C-ABI call between two events on the stream it is issued to: kernel time by family
+            marks, real = [], L.call
+
+            def timed(name, *a):
+                st = torch.cuda.current_stream(device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                real(name, *a)
+                e1.record(st)
+                marks.append((_family(name, a), e0, e1))
+
+            L.call = timed
+            try:
+                step(3 + 2 * iters)
+                torch.cuda.synchronize(device)
+            finally:
+                L.call = real
+            fam = {}
+            for f, e0, e1 in marks:
+                fam[f] = fam.get(f, 0.0) + e0.elapsed_time(e1)
+            counts['family_ms'] = fam
     del model, data
     torch.cuda.empty_cache()
     return sec, comm, loss, per_rank
@@ -441,9 +479,10 @@ def config3_leg(device, batch=32, size=256, n_step=3, iters=2):
     """BASELINE config 3: the 5-slot search step (n_step 3) at batch 32 on one GPU - what train.py:162,220 prints as 'Average time
     per iter'.  The matrix pipes' share: FLOPs the step's launches issue over the step time, f16 against the nameplate and against
     what the pipe sustains on random halves under the chip's power limit (profiles/r04_mfma_f16_power.txt)."""
-    c = {}
+    c = {'families': True}
     sec, _, loss, _ = search_step_times(device, 0, 1, False, batch, size, n_step, iters, counts=c)
     pix = 2 * batch * size * size
+    total = sum(c['family_ms'].values()) or 1.0
     tf16, tf32 = c['f16_flop'] / sec / 1e12, c['f32_flop'] / sec / 1e12
     return {'workload': 'DARTS iteration, 5-slot super-net (n_step %d, prune 0.2, alpha = 0), batch %d train + %d val %dx%d'
                         % (n_step, batch, batch, size, size),
@@ -453,9 +492,11 @@ def config3_leg(device, batch=32, size=256, n_step=3, iters=2):
             'mfma_f16_issued_of_nameplate': round(tf16 / MFMA_F16_PEAK_TFLOPS, 4),
             'mfma_f16_issued_of_sustained': round(tf16 / MFMA_F16_SUSTAINED_TFLOPS, 4),
             'mfma_f32_issued_of_peak': round(tf32 / MFMA_F32_PEAK_TFLOPS, 4),
+            'kernel_ms_per_step_between_events': round(total, 1),
+            'kernel_time_share': {k: round(v / total, 3) for k, v in sorted(c['family_ms'].items(), key=lambda kv: -kv[1])},
             'note': 'issued = FLOPs of the matrix instructions the launches execute over the WHOLE step time (element-wise launches, '
-                    'reductions and host gaps included); nameplate %.1f, sustained %.0f TFLOP/s; kernel-time shares by family: '
-                    'profiles/r06_config3_darts_step_kernel_stats.txt' % (MFMA_F16_PEAK_TFLOPS, MFMA_F16_SUSTAINED_TFLOPS)}
+                    'reductions and host gaps included); nameplate %.1f, sustained %.0f TFLOP/s; kernel_time_share: one more iteration with every C-ABI call between '
+                    'two events on its stream (kernel by kernel: profiles/r06_config3_darts_step_kernel_stats.txt)' % (MFMA_F16_PEAK_TFLOPS, MFMA_F16_SUSTAINED_TFLOPS)}
 
 
 def shipped_search_leg(device, rank=0, world=1, iters=10):

@@ -45,6 +45,9 @@ def test_bench_line_is_self_consistent():
     c3, c5, sh = extra['config3'], extra['config5'], extra['search_step_shipped']
     assert 'error' not in c3 and 'error' not in c5 and 'error' not in sh, (c3, c5, sh)
     assert 0.05 < c3['s_per_step'] < 2 and 0 < c3['mfma_f16_issued_of_nameplate'] < c3['mfma_f16_issued_of_sustained'] < 1
+    shares = c3['kernel_time_share']
+    assert abs(sum(shares.values()) - 1) < 0.01 and sum(v for k, v in shares.items() if 'wide' in k) > 0.4 and any('few-channel' in k for k in shares)
+    assert 0.5 * c3['s_per_step'] * 1e3 < c3['kernel_ms_per_step_between_events'] < 1.5 * c3['s_per_step'] * 1e3
     assert 2 < c5['ms_per_frame'] < 200 and c5['finite'] and c5['first_frame_ms'] >= c5['ms_per_frame'] * 0.9
     assert sh['per_rank_batch'] == 4 and sh['iters_per_s'] > 1 and sh['c_abi_calls_per_iter'] > 100
     assert not any(k.endswith('frac') and isinstance(v, float) and v > 1 for k, v in extra.items())
