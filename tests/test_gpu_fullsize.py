@@ -196,3 +196,51 @@ def test_config5_tile_and_reference_yaml_image_within_the_float64_budget_at_thei
     bay, _ = O.synthetic_raw(1, 256, 256, seed=4)
     _stages_within_budget(net, bay, arch, [O.make_weights('path14l_bayer', 500), O.make_weights('srcnn_demosaic', 501), None, None, None], 'SID_isp.yml 256 x 256')
 
+
+
+def test_grouped_srcnn_res_slot_forward_and_backward_within_the_float64_budget_at_256():
+    """The eight SRCNNRes proxies of an sRGB slot as the search step launches them - one grouped launch per layer on 256 x 256 planes,
+    forward and backward: the 9x9 first layers on the tap-index kernel with exact ReLU ties, the 5x5 64 <-> 32 layers on the wave-
+    specialised kernel, the 5x5 32 -> 3 tails and the 9x9 64 -> 3 backward-data launches on the tap-row kernel (with the channel sums
+    behind the constant planes' gradient), the 5x5 3 -> 32 backward-data launch on risp_conv2d_thin5 - against the oracle in float64 on
+    the CPU, outputs member by member, the slot's parameter gradients as one vector, and the input gradient through a random linear functional (a dense
+    gradient through two ReLUs has mask flips at pre-activations within rounding of zero in every fp32 arithmetic; a sum over the
+    plane does not care which)."""
+    from conftest import ErrorBudget
+    from test_gpu_group import _family, _inputs, _run_group
+    from reconfigisp_amd import convnets as CN
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    n, h, w = 1, 256, 256
+    mods = _family(seed0=80)
+    x, pvs, gys = _inputs(n, h, w, seed=9)
+    calls, real = [], CN.L.call
+    CN.L.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    try:
+        outs, grads, _ = _run_group(mods, x, pvs, gys, True)
+    finally:
+        CN.L.call = real
+    if CN.CONV_ARITH == 'f16x2' and CN.TOEP_FIRST == 'train':
+        for entry in ('risp_conv2d_toep_first_exact', 'risp_conv2d_f16x2', 'risp_conv2d_tapout', 'risp_conv2d_tapout_sums', 'risp_conv2d_thin5'):
+            assert entry in calls, (entry, sorted(set(calls)))
+    r = torch.Generator().manual_seed(3)
+    probe = torch.randn((n, 3, h, w), generator=r)
+    budget = ErrorBudget()
+    refs = {}
+    for dt in (torch.float32, torch.float64):
+        xc = x.cpu().to(dt).requires_grad_(True)
+        pc = [p.cpu().to(dt).requires_grad_(True) for p in pvs]
+        ys = [O.srcnn_res(xc, pc[j], {k: v.detach().cpu().to(dt) for k, v in m.state_dict().items()}) for j, m in enumerate(mods)]
+        gr = torch.autograd.grad(ys, [xc] + pc, [g.cpu().to(dt) for g in gys])
+        refs[dt] = ([y.detach() for y in ys], gr)
+    (y32, g32), (y64, g64) = refs[torch.float32], refs[torch.float64]
+    for j in range(len(mods)):
+        budget(outs[j], y32[j], y64[j], 'member %d output' % j, 'outputs')
+    # the members' parameter gradients as ONE vector of the slot (18 numbers), relative to its largest: each is a sum over the plane
+    # through two ReLU layers and the min / max features - the reference's own fp32 run is 1e-6 .. 3e-2 of a member's gradient away
+    # from its float64 run (this build 3e-6 .. 7e-4 on the same members): member by member the comparison is a coin toss on which
+    # member a flipped mask lands, for every fp32 arithmetic
+    cat = lambda gs: torch.cat([g.detach().flatten().double().cpu() for g in gs])
+    budget(cat(grads[1:]), cat(g32[1:]), cat(g64[1:]), 'parameter gradients of the slot', 'parameter gradients')
+    dot = lambda g: (g.double().cpu() * probe.double()).sum().reshape(1)
+    budget(dot(grads[0]), dot(g32[0]), dot(g64[0]), 'input gradient against a random functional', 'input gradient')
+    budget.finish()
