@@ -244,3 +244,53 @@ def test_grouped_srcnn_res_slot_forward_and_backward_within_the_float64_budget_a
     dot = lambda g: (g.double().cpu() * probe.double()).sum().reshape(1)
     budget(dot(grads[0]), dot(g32[0]), dot(g64[0]), 'input gradient against a random functional', 'input gradient')
     budget.finish()
+
+
+@pytest.mark.parametrize('kind,cin', [('path14l_bgr', 3), ('path14l_bayer', 1), ('srcnn_demosaic', 1)])
+def test_proxy_networks_forward_and_backward_within_the_float64_budget_at_256(kind, cin):
+    """Path-Restore (14 layers: the wave-specialised 3x3 kernel forward, its masked / residual backward forms) and the proxy demosaic on
+    one 256 x 256 plane (the mosaic: 512 x 512), random weights, training launches, five (image, weights) draws - against the oracle in
+    float64.  The output: conftest.ErrorBudget.  The dense input gradient: in the 2-norm, || g - g64 || / || g64 ||, against the same
+    distance of the oracle's own fp32 run.  Through 13 ReLU layers every fp32 arithmetic flips masks at pre-activations within rounding
+    of zero; one flip is an O(1) error on its footprint, so the largest element error (1e-2 .. 5e-2 of the gradient's magnitude for
+    this build AND for the oracle's fp32 run) and single draws (ratios 0.4 .. 3) are coin tosses; the median over draws is not: it
+    must not exceed 1.5 x the oracle's fp32 error, no draw 4 x.  Measured (round 6, six draws): split precision 0.4 .. 2.1, median 1.0
+    (Path-Restore BGR) / 0.8 (Bayer); RISP_CONV_ARITH=f32 0.7 .. 2.0, median 1.4 / 1.6; proxy demosaic (one ReLU layer pair) 0.8."""
+    from conftest import ErrorBudget
+    from reconfigisp_amd.codes.models.modules import tools_proxy as TP
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    cls = {'srcnn_demosaic': TP.ProxyDemosaicNet, 'path14l_bayer': TP.PathRestore14lBayer, 'path14l_bgr': TP.PathRestore14lBgr}[kind]
+    oracle = {'srcnn_demosaic': O.srcnn_demosaic, 'path14l_bayer': O.path14l_bayer, 'path14l_bgr': O.path14l_bgr}[kind]
+    hw = (256, 256) if cin == 3 else (512, 512)
+    budget = ErrorBudget()
+    ratios = []
+    for draw in range(5):
+        g = np.random.Generator(np.random.PCG64(100 + draw))
+        x = torch.from_numpy(g.random((1, cin) + hw).astype(np.float32))
+        w = O.make_weights(kind, 700 + draw, 0)
+        m = cls(0, None)
+        m.load_state_dict(w)
+        m = m.cuda()
+        xg = x.cuda().requires_grad_(True)
+        yg = m(xg, None)
+        gy = torch.from_numpy(g.standard_normal(tuple(yg.shape)).astype(np.float32))
+        gxg, = torch.autograd.grad(yg, xg, gy.cuda())
+        refs = {}
+        for dt in (torch.float32, torch.float64):
+            xc = x.to(dt).requires_grad_(True)
+            yc = oracle(xc, {k: v.to(dt) for k, v in w.items()})
+            gxc, = torch.autograd.grad(yc, xc, gy.to(dt))
+            refs[dt] = (yc.detach(), gxc)
+        budget(yg, refs[torch.float32][0], refs[torch.float64][0], '%s output, draw %d' % (kind, draw), 'outputs')
+        g64 = refs[torch.float64][1]
+        e_hip = ((gxg.double().cpu() - g64).norm() / g64.norm()).item()
+        e_ref = ((refs[torch.float32][1].double() - g64).norm() / g64.norm()).item()
+        ratios.append(e_hip / max(e_ref, 1e-30))
+        assert e_hip < 1e-2, (kind, draw, e_hip)                     # (a wrong backward kernel is an error of order 1)
+    budget.finish()
+    from reconfigisp_amd import convnets as CN
+    if CN.CONV_ARITH == 'f16x2' and CN.TOEP_FIRST == 'train':
+        assert sorted(ratios)[2] <= 1.5 and max(ratios) <= 4.0, (kind, ratios)
+    # (RISP_CONV_ARITH=f32: medians 1.5 - 1.6 on Path-Restore; its first layers decide their ReLU ties in fp32, and ONE flipped mask of the
+    # proxy demosaic's first layer is 6e-4 of the gradient in the 2-norm against the oracle's 5e-7 on a draw without one: the sanity bound
+    # above is all that can be asserted there)
