@@ -18,6 +18,9 @@ if os.environ.get('RISP_BENCH_NO_THIN5') == '1':           # A/B on one box: the
 if os.environ.get('RISP_BENCH_STREAM_PIXELS'):             # A/B: planes from which the ops of a slot use two streams (product: 2^16 pixels)
     from reconfigisp_amd.codes.models.modules import super_prune_fifteen_demos_four_bayer_two as SP
     SP.SLOT_STREAMS_MIN_PIXELS = int(os.environ['RISP_BENCH_STREAM_PIXELS'])
+if os.environ.get('RISP_BENCH_STREAM_JOBS'):               # A/B: jobs of a slot from which its ops use two streams (product: 3)
+    from reconfigisp_amd.codes.models.modules import super_prune_fifteen_demos_four_bayer_two as SP
+    SP.SLOT_STREAMS_MIN_JOBS = int(os.environ['RISP_BENCH_STREAM_JOBS'])
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 n_step = int(sys.argv[3]) if len(sys.argv) > 3 else 3
