@@ -431,12 +431,13 @@ def search_step_times(device, rank, world, distributed, global_batch, size, n_st
                 e1.record(st)
                 marks.append((_family(name, a), e0, e1))
 
-            L.call = timed
+            from reconfigisp_amd.codes.models.modules import super_prune_fifteen_demos_four_bayer_two as SP
+            L.call, streams, SP.SLOT_STREAMS = timed, SP.SLOT_STREAMS, 1      # (one stream: intervals on two streams would overlap)
             try:
                 step(3 + 2 * iters)
                 torch.cuda.synchronize(device)
             finally:
-                L.call = real
+                L.call, SP.SLOT_STREAMS = real, streams
             fam = {}
             for f, e0, e1 in marks:
                 fam[f] = fam.get(f, 0.0) + e0.elapsed_time(e1)

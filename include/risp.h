@@ -270,6 +270,18 @@ int risp_conv2d_wino43(const risp_conv_desc *d, void *stream);
 size_t risp_conv_thin5_wpack_bytes(int cout);
 int risp_conv2d_thin5(const risp_conv_desc *d, void *stream);
 
+/* The same operator for 3x3 layers with at most 4 OUTPUT channels and 16 .. 64 input channels (a multiple of 16) in split precision on
+ * the f16 matrix pipe (round 6, risp_conv_narrow3.hip): Path-Restore's last layer (path_14l_bgr_arch.py, path_14l_bayer_arch.py: 64 -> 3,
+ * 64 -> 4 + PixelShuffle) and the backward-data pass of its first layer.  Rows of a matrix instruction = (filter row, cout), reduction
+ * index = 16 channels, the filter column shifts the pixel operand; a wave walks down the rows and the three filter rows' contributions
+ * meet in registers.  wpack (risp_conv_narrow3_wpack_bytes(cin) bytes, 16-byte aligned): a 16-byte header whose first float is 1 / s_w,
+ * then [chunk of 16 cin][kx][part: hi, lo][channel half][row m, 32][8 channels] halves of w * s_w, row m = 4 ky + co (other rows zero) -
+ * the layer's weights w[co][ci][ky][kx] (backward-data: the forward weight with roles swapped and taps rotated by 180 degrees).
+ * load_mode PLAIN; epilogue RELU | SHUFFLE2 (cout == 4) | NOBIAS; cin * H * W * 4 < 2^31; any W; grouped launches.  One scale per wave
+ * and input row: a result depends neither on the batch nor on how the launch cuts its row segments; every sum in a fixed order. */
+size_t risp_conv_narrow3_wpack_bytes(int cin);
+int risp_conv2d_narrow3(const risp_conv_desc *d, void *stream);
+
 /* The same operator for the FIRST layers of the proxies - few input channels, the whole weight matrix staged once per
  * workgroup - with a LINEAR reduction index k = (ci * ksize + ky) * ksize + kx, so that the matrix instruction's two k-slots
  * hold consecutive k (3 channels of a 9x9 layer: 122 instructions per tile instead of the 162 that channel PAIRS cost in

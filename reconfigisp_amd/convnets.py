@@ -208,6 +208,32 @@ def thin5_weights(w, transpose=False):
     return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
 
 
+def narrow3_weights(w, transpose=False, keep=None):
+    """Pre-split pack of ``risp_conv2d_narrow3`` (include/risp.h) from a 3x3 layer's (cout <= 4, cin in 16 .. 64 and a multiple of 16, 3, 3)
+    tensor: a 16-byte header whose first float is 1 / s_w, then [chunk of 16 cin][kx][part: hi, lo][channel half][row m, 32][8 channels]
+    halves of w * s_w with row m = 4 ky + co - (filter row, cout) pairs in the rows of the matrix instruction, the filter column a
+    shift of the pixel operand.  ``transpose``: the backward-data layer of a FORWARD weight (roles swapped, taps rotated by 180
+    degrees) restricted to its first ``keep`` input channels.  Scale and split as in ``f16x2_weights``.  Returns a float16 tensor."""
+    if transpose:
+        w = w[:, :keep].flip(2, 3).transpose(0, 1)
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    if k != 3 or co > 4 or ci % 16 or not 16 <= ci <= 64:
+        raise ValueError('narrow 3x3 pack: at most 4 output channels, 16 .. 64 input channels (a multiple of 16), 3 taps; got %d -> %d, %d taps' % (ci, co, k))
+    _, e = torch.frexp(w.detach().abs().max())
+    sw = torch.ldexp(torch.ones((), device=w.device), 15 - e)
+    ws = w.detach().float() * sw
+    hi = ws.half()
+    parts = (hi, (ws - hi.float()).half())
+    rows = torch.zeros((2, ci, k, 32), device=w.device, dtype=torch.float16)                 # (part, ci, kx, m)
+    for part in range(2):                            # (co, ci, ky, kx) -> (ci, kx, ky, co) -> rows 4 ky + co
+        rows[part][:, :, :12].view(ci, k, 3, 4)[..., :co] = parts[part].permute(1, 3, 2, 0)
+    #       (part, chunk, half, 8, kx, m) -> (chunk, kx, part, half, m, 8)
+    p = rows.view(2, ci // 16, 2, 8, k, 32).permute(1, 4, 0, 2, 5, 3).contiguous()
+    hdr = torch.zeros(4, device=w.device, dtype=torch.float32)
+    hdr[0] = 1.0 / sw
+    return torch.cat([hdr.view(torch.float16), p.reshape(-1)])
+
+
 # Arithmetic of the wide hidden layers (3x3, cin % 16 == 0, cout 32 / 64): 'f16x2' (default) = split precision on the f16 matrix
 # pipe - each fp32 operand as two f16 halves, three products, fp32 accumulation (risp_conv2d_f16x2: fp32 tensors in and out,
 # error against float64 no larger than the fp32 kernels'); 'f32' = the fp32 matrix-core kernels (Winograd F(4,3) / F(2,3)).
@@ -303,6 +329,11 @@ def small_has_tapout(k, cin, cout):
     return k in (5, 9) and cout <= 3 and cin % 16 == 0 and cin > 0
 
 
+def small_has_narrow3(k, cin, cout):
+    """... and a (filter row, cout) pack for risp_conv2d_narrow3: 3x3, at most 4 couts, 16 .. 64 input channels in whole chunks of 16"""
+    return k == 3 and cout <= 4 and cin % 16 == 0 and 16 <= cin <= 64
+
+
 class PackedConv:
     """Device-side packed weights of one layer, forward and backward-data.  Every pack is built on FIRST USE (round 6): a layer holds up to
     nine packs and a launch reads one - the fp32 Winograd packs (einsum -> a Tensile GEMM and ~10 torch launches each) only serve
@@ -367,10 +398,12 @@ class SmallConv:
 
     def __getattr__(self, name):                     # the matrix-pipe packs, built when a launch first asks for them
         src = self.__dict__.get('_src')
-        if src is None or name not in ('toep', 'tapout'):
+        if src is None or name not in ('toep', 'tapout', 'narrow3'):
             raise AttributeError(name)
         w, transpose, keep = src
-        if name == 'toep':      # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts (12 for 5 taps)
+        if name == 'narrow3':   # 3x3 tails on the f16 matrix pipe (risp_conv2d_narrow3)
+            val = narrow3_weights(w, transpose, keep) if small_has_narrow3(self.k, self.cin, self.cout) else None
+        elif name == 'toep':      # the same layer for the f16 matrix pipe (risp_conv2d_toep): 5- and 9-tap rows, at most 4 couts (12 for 5 taps)
             val = toep_weights(w, transpose, keep) if small_has_toep(self.k, self.cout) else None
         else:                   # ... and with the filter rows in the rows of the matrix instruction (risp_conv2d_tapout)
             val = tapout_weights(w, transpose, keep) if small_has_tapout(self.k, self.cin, self.cout) else None
@@ -453,15 +486,20 @@ def tapout_seg(images, h, w, infer):
     return min(TAPOUT_INFER_SEG, h) if infer else L.load().risp_conv_tapout_seg_rows(images, h, w)
 
 
-def route_small(k, cin, cout, h, w, images, infer=False, has_mask=False, has_toep=True, split=None, has_tapout=False):
+def route_small(k, cin, cout, h, w, images, infer=False, has_mask=False, has_toep=True, split=None, has_tapout=False, has_narrow3=False):
     """The dispatch of ``conv_small`` (layers with at most 12 output channels).  Under RISP_CONV_ARITH=f16x2, W % 4 == 0, no mask:
     layers that hold a tap-row pack (at most 3 couts, cin % 16 == 0, 5 or 9 taps) run on risp_conv2d_tapout, the other 5- and 9-tap
     layers that hold a Toeplitz-band pack (4 couts, or 5 .. 12 with 5 taps, or odd channel counts) on risp_conv2d_toep (both: f16 matrix
     pipe, split precision) - ALWAYS for inference (a tile's result must not depend on the batch it travels in), for training when the
     grid holds enough work (TAPOUT_MIN_ITEMS / TOEP_MIN_TILES; or the caller forces ``split`` = 0: the per-member form of a grouped
     launch follows the grouped grid); everything else on risp_conv2d_small (vector FMAs; small training grids split their input
-    channels over several workgroups per tile: risp_conv2d_small_split, never for inference)."""
+    channels over several workgroups per tile: risp_conv2d_small_split, never for inference).  3x3 layers that hold a (filter row,
+    cout) pack (at most 4 couts, 16 .. 64 input channels; ``has_narrow3``: the caller also checks the epilogue) run on
+    risp_conv2d_narrow3 in inference launches, whatever the grid."""
     mat = CONV_ARITH == 'f16x2' and w % 4 == 0 and cin * h * w < (1 << 30) and not has_mask
+    if mat and has_narrow3 and infer:                 # 3x3 tails (at most 4 couts) of inference launches: one scale per wave and row - any grid,
+        return 'risp_conv2d_narrow3'                  # any batch.  (Training keeps the vector kernel: equal at batch 32 - both read 64 planes at
+        #                                               2.6 TB/s - and the search step's goldens keep their arithmetic.)
     if mat and has_tapout and h * w < (1 << 24) and (infer or (split == 0 if split is not None else tapout_grid_ok(images, h, w))):
         return 'risp_conv2d_tapout'
     if mat and has_toep and (infer or (split == 0 if split is not None else toep_grid_ok(images, h, w))):
@@ -488,7 +526,16 @@ def conv_small(x, sc, n, h, w, epi=0, add=None, add_c=0, mask=None, infer=False,
                    y=_p(out))
     has_toep = small_has_toep(sc.k, sc.cout)          # (the packs themselves are built when a launch first asks for them)
     has_tapout = small_has_tapout(sc.k, sc.cin, sc.cout) and not (epi & EPI_SHUFFLE2)
-    entry = route_small(sc.k, sc.cin, sc.cout, h, w, nn_, infer, mask is not None, has_toep, split, has_tapout)
+    has_narrow3 = small_has_narrow3(sc.k, sc.cin, sc.cout) and not (epi & ~(EPI_RELU | EPI_SHUFFLE2 | EPI_NOBIAS)) and add is None
+    entry = route_small(sc.k, sc.cin, sc.cout, h, w, nn_, infer, mask is not None, has_toep, split, has_tapout, has_narrow3)
+    if entry == 'risp_conv2d_narrow3':
+        pack = sc.narrow3
+        d.wpack = _p(pack)
+        _group_fields(d, n, group, pack, sc.bias)
+        L.call(entry, C.byref(d), _stream())
+        if MFMA_ISSUED_F16 is not None:                # per filter column and chunk of 16 channels: 3 products of 32 rows x 16 channels per pixel
+            MFMA_ISSUED_F16[0] += 3 * 2.0 * 32 * sc.k * sc.cin * nn_ * h * w
+        return out
     if entry == 'risp_conv2d_tapout':
         # the f16 matrix pipe with the filter rows as the rows of the matrix instruction: half the matrix work of the band form
         tapout = sc.tapout
@@ -1064,7 +1111,7 @@ def stack_packed(pcs):
 
 
 def stack_small(scs):
-    return _Stacked(scs, ('wpack', 'bias', 'toep', 'tapout'), ('cin', 'cout', 'k'))
+    return _Stacked(scs, ('wpack', 'bias', 'toep', 'tapout', 'narrow3'), ('cin', 'cout', 'k'))
 
 
 def _stack_grads(gys, like):

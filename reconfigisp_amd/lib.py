@@ -151,6 +151,8 @@ SIGNATURES = {
     'risp_conv2d_tapout_sums': (_i, [C.POINTER(ConvDesc), _i, _f, _s]),
     'risp_conv_toep_first_wpack_bytes': (_z, [_i, _i]),
     'risp_conv2d_toep_first': (_i, [C.POINTER(ConvDesc), _s]),
+    'risp_conv_narrow3_wpack_bytes': (_z, [_i]),
+    'risp_conv2d_narrow3': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv_thin5_wpack_bytes': (_z, [_i]),
     'risp_conv2d_thin5': (_i, [C.POINTER(ConvDesc), _s]),
     'risp_conv2d_toep_first_exact': (_i, [C.POINTER(ConvDesc), _f, C.c_longlong, C.c_void_p, C.c_uint, _s]),

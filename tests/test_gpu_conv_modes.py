@@ -617,6 +617,7 @@ def test_conv_launches_what_route_says(arith, monkeypatch):
             for infer in (False, True):
                 calls.clear()
                 y = CN.conv_small(x, sc, n, h, w, infer=infer)
-                want = CN.route_small(k, cin, cout, h, w, n, infer, False, CN.small_has_toep(k, cout), None, CN.small_has_tapout(k, cin, cout))
+                want = CN.route_small(k, cin, cout, h, w, n, infer, False, CN.small_has_toep(k, cout), None, CN.small_has_tapout(k, cin, cout),
+                                      CN.small_has_narrow3(k, cin, cout))
                 assert calls[-1] in (want, want + '_split'), (k, cin, cout, infer, calls, want)
                 assert_close(y, TF.conv2d(x, wt, b, padding=k // 2), what='%s k%d %d->%d' % (want, k, cin, cout))

@@ -430,3 +430,36 @@ def test_thin_input_pack_reproduces_the_convolution(co, ci, tr):
         CN.thin5_weights(torch.randn(32, 4, 5, 5))
     with pytest.raises(ValueError):
         CN.thin5_weights(torch.randn(16, 3, 5, 5))
+
+
+@pytest.mark.parametrize('co,ci,tr', [(3, 64, False), (4, 16, False), (4, 64, True), (1, 32, True)])
+def test_narrow_3x3_pack_reproduces_the_convolution(co, ci, tr):
+    """convnets.narrow3_weights: header = 1 / s_w, body [chunk of 16 cin][kx][hi, lo][channel half][row m][8 channels] with row m = 4 ky + co.
+    As the kernel consumes it: per INPUT row y' one matrix pass D[m][x] = sum_kx sum_ci W[m][ci][kx] in[ci][y'][x + kx - 1], then
+    out[co][y] = (D[4 * 0 + co][y - 1] + D[4 * 1 + co][y]) + D[4 * 2 + co][y + 1]."""
+    torch.manual_seed(co + ci)
+    w = torch.randn(co, ci, 3, 3) * 0.05 if not tr else torch.randn(ci, co + 2, 3, 3) * 0.05
+    p = CN.narrow3_weights(w, tr, co if tr else None)
+    nch = ci // 16
+    assert p.dtype == torch.float16 and p.numel() == 8 + nch * 3 * 2 * 2 * 32 * 8
+    inv = p[:2].view(torch.float32).item()
+    wt = w[:, :co].flip(2, 3).transpose(0, 1) if tr else w
+    sw = 1.0 / inv
+    assert 2.0 ** 14 <= wt.abs().max().item() * sw < 2.0 ** 15 and sw == 2.0 ** round(np.log2(sw))
+    body = p[8:].view(nch, 3, 2, 2, 32, 8).double()
+    #     (chunk, kx, half, m, 8) -> W[m][ci = 16 chunk + 8 half + e][kx]
+    W = ((body[:, :, 0] + body[:, :, 1]) * inv).permute(3, 0, 2, 4, 1).reshape(32, ci, 3)
+    used = sorted(4 * ky + c for c in range(co) for ky in range(3))
+    unused = [m for m in range(32) if m not in used]
+    assert W[unused].abs().max().item() == 0
+    h, wd = 7, 12
+    x = torch.randn(2, ci, h, wd, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(x, wt.double(), padding=1)
+    D = torch.nn.functional.conv2d(x, W.view(32, ci, 1, 3), padding=(0, 1))               # (n, 32, h, wd): one pass per input row
+    Dp = torch.nn.functional.pad(D, (0, 0, 1, 1))                                         # rows -1 and h are zero
+    out = torch.stack([(Dp[:, c, 0:h] + Dp[:, 4 + c, 1:h + 1]) + Dp[:, 8 + c, 2:h + 2] for c in range(co)], 1)
+    assert (out - ref).abs().max().item() <= 2.0 ** -21 * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        CN.narrow3_weights(torch.randn(5, 64, 3, 3))
+    with pytest.raises(ValueError):
+        CN.narrow3_weights(torch.randn(3, 24, 3, 3))

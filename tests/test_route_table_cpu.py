@@ -49,8 +49,10 @@ SMALLS = {
     ('srcnn_res', '9x9 64->3 first', 'bwd'): ((9, 64, 3, False), {('train', BIG): 'risp_conv2d_tapout', ('train', SMALL): 'risp_conv2d_small', ('train', 8): 'risp_conv2d_tapout', ('f32', BIG): 'risp_conv2d_small'}),
     ('srcnn_demosaic', '5x5 32->12 last + PixelShuffle', 'fwd'): ((5, 32, 12, False), {('train', BIG): 'risp_conv2d_toep', ('train', SMALL): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_toep', ('f32', BIG): 'risp_conv2d_small'}),
     ('srcnn_demosaic', '9x9 64->4 first (through PixelShuffle)', 'bwd'): ((9, 64, 4, False), {('train', BIG): 'risp_conv2d_toep', ('train', SMALL): 'risp_conv2d_small', ('f32', BIG): 'risp_conv2d_small'}),
-    ('path14l_bayer', '3x3 64->4 last + PixelShuffle', 'fwd'): ((3, 64, 4, False), {('train', BIG): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_small', ('f32', BIG): 'risp_conv2d_small'}),
-    ('path14l_bgr', '3x3 64->3 last', 'fwd'): ((3, 64, 3, False), {('train', BIG): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_small', ('f32', BIG): 'risp_conv2d_small'}),
+    # (round 6: Path-Restore's 3x3 tails of INFERENCE launches with (filter row, cout) pairs in the rows of the matrix instruction - one scale per
+    # wave and row, so any grid and any batch give the same bits; training launches keep the vector kernel)
+    ('path14l_bayer', '3x3 64->4 last + PixelShuffle', 'fwd'): ((3, 64, 4, False), {('train', BIG): 'risp_conv2d_small', ('infer', BIG): 'risp_conv2d_narrow3', ('infer', SMALL): 'risp_conv2d_narrow3', ('f32', BIG): 'risp_conv2d_small'}),
+    ('path14l_bgr', '3x3 64->3 last', 'fwd'): ((3, 64, 3, False), {('train', BIG): 'risp_conv2d_small', ('infer', SMALL): 'risp_conv2d_narrow3', ('f32', BIG): 'risp_conv2d_small'}),
     ('path14l', '3x3 64->4 / 3 first', 'bwd'): ((3, 64, 4, False), {('train', BIG): 'risp_conv2d_small', ('f32', BIG): 'risp_conv2d_small'}),
 }
 
@@ -82,7 +84,8 @@ def test_route_small_table(key, monkeypatch):
     (k, cin, cout, has_mask), want = SMALLS[key]
     for (mode, images), entry in want.items():
         infer = _mode(monkeypatch, mode)
-        got = CN.route_small(k, cin, cout, H, W, images, infer, has_mask, CN.small_has_toep(k, cout), None, CN.small_has_tapout(k, cin, cout))
+        got = CN.route_small(k, cin, cout, H, W, images, infer, has_mask, CN.small_has_toep(k, cout), None, CN.small_has_tapout(k, cin, cout),
+                             CN.small_has_narrow3(k, cin, cout))
         assert got == entry, (key, mode, images, got)
 
 
@@ -102,6 +105,9 @@ def test_useful_over_issued_products_of_the_few_channel_kernels():
     assert abs(3 * 2.0 * 25 * 3 * 32 / (3 * 2.0 * 5 * 16 * 32) - 0.9375) < 1e-9
     assert 'thin5' in CN.pack_kinds(5, 32, 3, True) and 'thin5' not in CN.pack_kinds(5, 32, 3, False) and 'thin5' in CN.pack_kinds(5, 3, 64, False)
     assert 'thin5' not in CN.pack_kinds(5, 32, 4, True) and 'thin5' not in CN.pack_kinds(3, 32, 3, True)
+    # Path-Restore's 3x3 64 -> 3 / 4 tails: rows (filter row, cout) 9 / 12 of 32 - an HBM-bound layer, the matrix pipe is idle either way
+    assert CN.small_has_narrow3(3, 64, 3) and CN.small_has_narrow3(3, 16, 4) and not CN.small_has_narrow3(3, 64, 5) and not CN.small_has_narrow3(3, 80, 3)
+    assert not CN.small_has_narrow3(3, 24, 3) and not CN.small_has_narrow3(5, 64, 3)
     # the layers that stay on the band form: 4 couts (36 rows do not fit 32), 12 couts, channel counts that are no multiple of 16
     assert not CN.small_has_tapout(9, 64, 4) and not CN.small_has_tapout(5, 32, 12) and not CN.small_has_tapout(5, 7, 1)
     assert CN.small_has_tapout(9, 64, 3) and CN.small_has_tapout(5, 32, 3) and CN.small_has_tapout(5, 16, 1)

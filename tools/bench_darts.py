@@ -11,6 +11,9 @@ if os.environ.get('RISP_BENCH_NO_TAPOUT') == '1':          # A/B on one box: the
     import reconfigisp_amd.convnets as CN
     CN.small_has_tapout = lambda *a: False
 
+if os.environ.get('RISP_BENCH_NO_NARROW3') == '1':         # A/B on one box: Path-Restore's 3x3 tails back on the vector kernel
+    import reconfigisp_amd.convnets as CN
+    CN.small_has_narrow3 = lambda *a: False
 if os.environ.get('RISP_BENCH_NO_THIN5') == '1':           # A/B on one box: the 5x5 3 -> 32 backward-data layers on the fp32 F(4,5) kernel of round 5
     import reconfigisp_amd.convnets as CN
     _kinds = CN.pack_kinds

@@ -5,6 +5,9 @@ bilinear demosaic -> WbQuadratic); MPix/s is quoted on the 12 MPix frame."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get('RISP_BENCH_NO_NARROW3') == '1':         # A/B on one box: Path-Restore's 3x3 tails back on the vector kernel
+    import reconfigisp_amd.convnets as CN
+    CN.small_has_narrow3 = lambda *a: False
 from collections import OrderedDict
 from reconfigisp_amd.codes.models import create_model
 from reconfigisp_amd.codes.test_split import run_frame

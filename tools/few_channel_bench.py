@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """GPU box: the three few-channel layers of the SRCNNRes family as the search step launches them (grouped: 8 members x 32 images of
 256 x 256), product kernels only - the program tools/conv_pmc.sh profiles for their counters.
-python tools/few_channel_bench.py first|first_exact|bwd9|bwd9_sums|fwd5|bwd5 [images h w members reps]
+python tools/few_channel_bench.py first|first_exact|bwd9|bwd9_sums|fwd5|bwd5|tail3 [images h w members reps]
   (first_exact = the training forward: ties of the ReLU listed and recomputed; bwd9_sums = with the per-item channel sums of the input;
    RISP_FCB_SERIES=1: the launch time over consecutive blocks of launches - what sustained load does to it)
   first = 9x9 3 -> 64, ReLU + border-case bias (risp_conv2d_toep_first -> conv_xwin_kernel)
   bwd9  = 9x9 64 -> 3 backward-data + residual (risp_conv2d_tapout)        fwd5 = 5x5 32 -> 3 forward + residual (risp_conv2d_tapout)
+  tail3 = 3x3 64 -> 3, Path-Restore's last layer, members x images in one launch (risp_conv2d_narrow3; RISP_FCB_SMALL=1: the vector kernel)
   bwd5  = 5x5 3 -> 32 backward-data with a ReLU mask (risp_conv2d_thin5; RISP_FCB_WINO=1: the fp32 F(4,5) kernel it replaces)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,6 +31,17 @@ if what.startswith('first'):
         ties = torch.zeros(1 + CN.TIES_MAX, device='cuda', dtype=torch.int32)
         fn = lambda: L.call('risp_conv2d_toep_first_exact', C.byref(d), w32.data_ptr(), w32.stride(0), ties.data_ptr(), CN.TIES_MAX, None)
     useful, alg = 3 * 2.0 * 81 * 3 * 64 * G * n * h * w, (64 * G + 3) * 4.0 * n * h * w
+elif what == 'tail3':
+    wt = torch.randn(3, 64, 3, 3, device='cuda') * 0.05
+    b = torch.randn(3, device='cuda') * 0.1
+    x = torch.randn(G * n, 64, h, w, device='cuda')
+    y = torch.empty(G * n, 3, h, w, device='cuda')
+    small = os.environ.get('RISP_FCB_SMALL') == '1'
+    pack = CN.SmallConv(wt, b).wpack if small else CN.narrow3_weights(wt)
+    d = L.ConvDesc(N=G * n, H=h, W=w, cin=64, cout=3, ksize=3, load_mode=0, cin_img=0, epilogue=0, add_c=0, x=x.data_ptr(),
+                   wpack=pack.data_ptr(), bias=b.data_ptr(), cvals=None, add=None, mask=None, y=y.data_ptr())
+    fn = lambda: L.call('risp_conv2d_small' if small else 'risp_conv2d_narrow3', C.byref(d), None)
+    useful, alg = 3 * 2.0 * 9 * 64 * 3 * G * n * h * w, (64 + 3) * 4.0 * G * n * h * w
 elif what == 'bwd5':
     wfs = [torch.randn(3, 32, 5, 5, device='cuda') * 0.05 for _ in range(G)]
     gy = torch.randn(G * n, 3, h, w, device='cuda') * 1e-3
