@@ -16,10 +16,13 @@
 
 namespace {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int N3_WO = 30, N3_TW = 4 * N3_WO, N3_MAXCH = 4;            // output columns of a wave (its 32 loaded columns minus one each side), of a workgroup; chunks of 16 channels
+#ifndef N3_WAVES
+#define N3_WAVES 4                 /* waves of a workgroup (8 and 16 measured: 266 / 211 us against 218 at 32 x 256 x 256 - no DRAM-page effect) */
+#endif
+constexpr int N3_WO = 30, N3_TW = N3_WAVES * N3_WO, N3_MAXCH = 4;            // output columns of a wave (its 32 loaded columns minus one each side), of a workgroup; chunks of 16 channels
 
 template <bool SHUF>
-__global__ __launch_bounds__(256) void conv_narrow3_kernel(const risp_conv_desc d_in, int strips, int segs, int seg_rows) {
+__global__ __launch_bounds__(64 * N3_WAVES) void conv_narrow3_kernel(const risp_conv_desc d_in, int strips, int segs, int seg_rows) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];      // weights [chunk][kx][part][64 lanes], then per wave the operand row of ONE chunk [part][hl][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hl = lane >> 5;
     int t = blockIdx.x;
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(256) void conv_narrow3_kernel(const risp_conv_desc 
     const int x0 = st * N3_TW + N3_WO * wave, ys = sg * seg_rows, ye = ys + seg_rows < H ? ys + seg_rows : H;
     const uint4 *wp = reinterpret_cast<const uint4 *>(d.wpack);
     uint4 *wl = smem, *eb = smem + nch * 3 * 2 * 64 + wave * (2 * 2 * 32);
-    for (int s = tid; s < nch * 3 * 2 * 64; s += 256) wl[s] = wp[1 + s];
+    for (int s = tid; s < nch * 3 * 2 * 64; s += 64 * N3_WAVES) wl[s] = wp[1 + s];
     __syncthreads();
     if (x0 >= W) return;                                              // (a strip's waves beyond the image's last column; no barrier below)
     const float inv_sw = *reinterpret_cast<const float *>(wp);
@@ -170,11 +173,11 @@ int risp_conv2d_narrow3(const risp_conv_desc *dp, void *stream) {
     const int segs = (d.H + seg - 1) / seg;
     const long long items = (long long)d.N * strips * segs;
     RISP_CHECK_ARG(items <= 0x7fffffff, "risp_conv2d_narrow3: too many work items");
-    const size_t lds = ((size_t)(d.cin / 16) * 3 * 2 * 64 + 4 * (2 * 2 * 32)) * 16;
+    const size_t lds = ((size_t)(d.cin / 16) * 3 * 2 * 64 + N3_WAVES * (2 * 2 * 32)) * 16;
     if (d.epilogue & RISP_EPI_SHUFFLE2)
-        hipLaunchKernelGGL(conv_narrow3_kernel<true>, dim3((unsigned)items), dim3(256), lds, (hipStream_t)stream, d, strips, segs, seg);
+        hipLaunchKernelGGL(conv_narrow3_kernel<true>, dim3((unsigned)items), dim3(64 * N3_WAVES), lds, (hipStream_t)stream, d, strips, segs, seg);
     else
-        hipLaunchKernelGGL(conv_narrow3_kernel<false>, dim3((unsigned)items), dim3(256), lds, (hipStream_t)stream, d, strips, segs, seg);
+        hipLaunchKernelGGL(conv_narrow3_kernel<false>, dim3((unsigned)items), dim3(64 * N3_WAVES), lds, (hipStream_t)stream, d, strips, segs, seg);
     RISP_LAUNCH_CHECK("risp_conv2d_narrow3");
     return 0;
 }
