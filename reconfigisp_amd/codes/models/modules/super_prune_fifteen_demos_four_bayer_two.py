@@ -28,11 +28,10 @@ _POINTWISE = {T.Skip: 'skip', T.WbManual: 'wb_manual', T.Gamma: 'gamma', T.GtmMa
 SLOT_STREAMS = int(os.environ.get('RISP_SLOT_STREAMS', '2'))
 SLOT_STREAMS_MAX_PIXELS = 1 << 40
 SLOT_STREAMS_MIN_PIXELS = 1 << 16           # batch x H x W below which a second stream buys nothing (batch 4 of 48 x 48: 19-20 ms per iteration either way)
-SLOT_STREAMS_MIN_JOBS = 3                   # jobs of a slot from which the streams are used ...
-SLOT_STREAMS_BIG_PIXELS = 1 << 20           # ... and from two jobs on planes of at least this many pixels (batch 32 of 256 x 256: the grouped proxies
-#                                             and Path-Restore of a slot side by side, 0.354 -> 0.350 s per iteration in alternating runs;
-#                                             batch 4: 0.034 -> 0.035, so not there)
-
+SLOT_STREAMS_MIN_JOBS = 3                   # jobs of a slot from which the streams are used
+# (Round 6 tried two jobs - the grouped proxies and Path-Restore of an sRGB slot side by side - on planes of at least 2^20 pixels: config 3
+# 0.354 -> 0.350 s in alternating runs, but test_search_network_full_size_gradient_properties (two backward passes of the same graph give the
+# same bits) then failed once in four long suite runs and never alone: not kept.)
 
 class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
     def __init__(self, n_step, threshold, module_path):
@@ -201,8 +200,7 @@ class SuperPruneFifteenDemosFourBayerTwo(nn.Module):
         order.  Measured in round 2 (tools/bench_darts.py, n_step 2, op-by-op jobs): batch 4 0.113 -> 0.097 s per
         iteration, batch 32 0.62 -> 0.60 s; 3 and 4 streams are no faster."""
         pixels = x.shape[0] * x.shape[2] * x.shape[3]
-        min_jobs = min(SLOT_STREAMS_MIN_JOBS, 2) if pixels >= SLOT_STREAMS_BIG_PIXELS else SLOT_STREAMS_MIN_JOBS
-        n_streams = SLOT_STREAMS if (x.is_cuda and len(jobs) >= min_jobs and
+        n_streams = SLOT_STREAMS if (x.is_cuda and len(jobs) >= SLOT_STREAMS_MIN_JOBS and
                                      SLOT_STREAMS_MIN_PIXELS <= pixels <= SLOT_STREAMS_MAX_PIXELS) else 1
         outs = [None] * n_out
         xs = xs if xs is not None else [x] * len(jobs)
