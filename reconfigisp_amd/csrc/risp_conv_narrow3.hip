@@ -40,6 +40,16 @@ __global__ __launch_bounds__(64 * N3_WAVES) void conv_narrow3_kernel(const risp_
     __syncthreads();
     if (x0 >= W) return;                                              // (a strip's waves beyond the image's last column; no barrier below)
     const float inv_sw = *reinterpret_cast<const float *>(wp);
+#ifdef N3_WREG                                               /* (experiment: the weights in registers instead of 24 LDS reads per row - 196 registers, two
+                                                                waves per SIMD: 290 us against 213 at 32 x 256 x 256; the kernel lives on its occupancy) */
+    h8 wr[N3_MAXCH][3][2];
+#pragma unroll
+    for (int c = 0; c < N3_MAXCH; ++c)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) wr[c][kx][part] = __builtin_bit_cast(h8, wl[((c < nch ? c : 0) * 3 + kx) * 2 * 64 + part * 64 + lane]);
+#endif
 
     // ---- input: lane (l31, hl) owns column x0 - 1 + l31 and channels 8 hl .. 8 hl + 7 of every chunk: all 64 lanes load and convert; the
     // wave's first and last column are its neighbours' (30 output columns per wave).  A column or row outside the image reads zeros.
@@ -107,7 +117,11 @@ __global__ __launch_bounds__(64 * N3_WAVES) void conv_narrow3_kernel(const risp_
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const h8 bh = __builtin_bit_cast(h8, eb[hl * 32 + bcol[kx]]), bl = __builtin_bit_cast(h8, eb[64 + hl * 32 + bcol[kx]]);
+#ifdef N3_WREG
+                    const h8 ah = wr[c][kx][0], al = wr[c][kx][1];
+#else
                     const h8 ah = __builtin_bit_cast(h8, wl[((c * 3 + kx) * 2 + 0) * 64 + lane]), al = __builtin_bit_cast(h8, wl[((c * 3 + kx) * 2 + 1) * 64 + lane]);
+#endif
                     f32x16 &a = acc[(c * 3 + kx) & 1];
                     a = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a, 0, 0, 0);
